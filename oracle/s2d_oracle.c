@@ -1,0 +1,729 @@
+/*
+ * s2d_oracle.c -- CPU ORACLE for the reach_ball hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker, never the product: only tests/, __graft_entry__.smoke() and
+ * bench.py's `cpu_baseline` leg may load it.  The product path (gym-soccer-2d-env_amd/)
+ * never imports, links or calls anything here and fails loudly without its HIP library.
+ *
+ * It is a plain-C scalar restatement of the reference's algorithm for the path
+ * (SURVEY.md section 8a).  Two builds of this one source:
+ *     -DS2DO_F64  REAL=double, libm sin/cos/atan2/exp  -- "what the reference's Python
+ *                 (float64) computes"; pinned against tests/golden/ JSON files, which were
+ *                 produced by running the reference's own ReachBallEnv methods.
+ *     (default)   REAL=float, the deterministic fp32 math spec of DESIGN.md section 4
+ *                 (explicit fmaf polynomials, correctly-rounded / and sqrt, no
+ *                 contraction) -- what the HIP kernels must reproduce BIT FOR BIT.
+ *
+ * PARITY PINNING.  Rows A2-A5 (action map, observation, reward/done/result, reset
+ * sampler) are pinned by the golden fixtures.  Rows S/P (dash / turn / stamina /
+ * integrate / decay / collision = rcssserver's arithmetic) live in third-party binaries
+ * that are NOT under /root/reference (clsframework/rcssserver, GitHub releases/latest,
+ * no version pinned: scripts/download-rcssserver.sh:30) and the reference holds no test
+ * or golden vector at that boundary: for those rows this oracle restates rcssserver's
+ * published model and is "parity unpinned" against a real
+ * rcssserver; it is pinned only by the hand-derived known answers of appendix B.
+ *
+ * Each function cites the reference file:line it follows.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/s2d.h"
+
+#ifdef S2DO_F64
+typedef double REAL;
+#define R(x) x
+#else
+typedef float REAL;
+#define R(x) x##f
+#endif
+
+#define API __attribute__((visibility("default")))
+
+/* ======================================================================================
+ * Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11).
+ * Counter layout of this project:
+ *   ctr = { gid_lo, gid_hi, cycle, (stream << 16) | block },  key = { seed_lo, seed_hi }
+ * ==================================================================================== */
+enum { ST_RESET = 0, ST_POLICY = 1, ST_SELECT = 2, ST_NOISE = 3 };
+
+API void s2do_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static void draw(uint64_t seed, uint64_t gid, uint32_t cycle, uint32_t stream, uint32_t block,
+                 uint32_t w[4]) {
+  uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), cycle, (stream << 16) | block};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  s2do_philox4x32_10(ctr, key, w);
+}
+/* integer in [0, span): multiply-high (bias <= span / 2^32) */
+static int32_t rnd_below(uint32_t w, uint32_t span) { return (int32_t)(((uint64_t)w * span) >> 32); }
+/* uniform in [0,1) with 24 bits, exact in float and double */
+static REAL rnd_u01(uint32_t w) { return (REAL)(w >> 8) * R(5.9604644775390625e-8); }
+
+/* ======================================================================================
+ * Elementary functions.  F64: libm, as pyrusgeom / numpy do.  F32: DESIGN.md section 4.
+ * ==================================================================================== */
+#ifdef S2DO_F64
+static void sincos_deg(REAL deg, REAL *s, REAL *c) {
+  const double DEG2RAD = 3.14159265358979323846 / 180.0;
+  *s = sin(deg * DEG2RAD);
+  *c = cos(deg * DEG2RAD);
+}
+/* pyrusgeom AngleDeg.atan2_deg: 0 for the zero vector */
+static REAL atan2_deg(REAL y, REAL x) {
+  const double RAD2DEG = 180.0 / 3.14159265358979323846;
+  if (x == 0.0 && y == 0.0) return 0.0;
+  return atan2(y, x) * RAD2DEG;
+}
+static REAL hypot2(REAL x, REAL y) { return sqrt(x * x + y * y); }
+static REAL exp_r(REAL x) { return exp(x); }
+#else
+static void sincos_deg(REAL deg, REAL *s, REAL *c) {
+  float q = rintf(deg * 0.011111111111111112f);
+  float r = fmaf(-q, 90.0f, deg);            /* exact: r in [-45, 45] */
+  float x = r * 0.017453292519943295f;
+  float z = x * x;
+  float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(z, ps, -1.6666654611e-1f);
+  ps = fmaf(x * z, ps, x);
+  float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(z, pc, 4.166664568298827e-2f);
+  pc = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  switch (((int)q) & 3) {
+    case 0: *s = ps; *c = pc; break;
+    case 1: *s = pc; *c = -ps; break;
+    case 2: *s = -ps; *c = -pc; break;
+    default: *s = -pc; *c = ps; break;
+  }
+}
+static REAL atan2_deg(REAL y, REAL x) {
+  float ax = fabsf(x), ay = fabsf(y);
+  float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  if (mx == 0.0f) return 0.0f;
+  float t = mn / mx;
+  float base = 0.0f;
+  if (t > 0.41421356237f) {
+    t = (t - 1.0f) / (t + 1.0f);
+    base = 45.0f;
+  }
+  float z = t * t;
+  float p = fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f);
+  p = fmaf(z, p, 1.99777106478e-1f);
+  p = fmaf(z, p, -3.33329491539e-1f);
+  float a = fmaf(p * z, t, t);
+  a = fmaf(a, 57.29577951308232f, base);
+  if (ay > ax) a = 90.0f - a;
+  if (x < 0.0f) a = 180.0f - a;
+  if (y < 0.0f) a = -a;
+  return a;
+}
+static REAL hypot2(REAL x, REAL y) { return sqrtf(fmaf(x, x, y * y)); }
+static REAL exp_r(REAL x) {
+  float k = rintf(x * 1.44269504088896341f);
+  float r = fmaf(-k, 0.693359375f, x);
+  r = fmaf(-k, -2.12194440e-4f, r);
+  float z = r * r;
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  float y = fmaf(p, z, r) + 1.0f;
+  return ldexpf(y, (int)k);
+}
+#endif
+
+/* pyrusgeom AngleDeg.__init__/normal(): fmod by 360 when |d| > 360, then one +-360. */
+static REAL norm_deg(REAL d) {
+  if (d < R(-360.0) || R(360.0) < d) d = R(fmod)(d, R(360.0));
+  if (d < R(-180.0)) d += R(360.0);
+  if (d > R(180.0)) d -= R(360.0);
+  return d;
+}
+
+API void s2do_sincos_deg(double deg, double *s, double *c) { REAL a, b; sincos_deg((REAL)deg, &a, &b); *s = a; *c = b; }
+API double s2do_atan2_deg(double y, double x) { return atan2_deg((REAL)y, (REAL)x); }
+API double s2do_exp(double x) { return exp_r((REAL)x); }
+API double s2do_norm_deg(double d) { return norm_deg((REAL)d); }
+API int s2do_real_bytes(void) { return (int)sizeof(REAL); }
+
+/* ======================================================================================
+ * Parameters rounded once to REAL.
+ * ==================================================================================== */
+typedef struct P {
+  REAL half_l, half_w;
+  REAL player_size, player_decay, player_rand, player_speed_max, player_accel_max, inertia_moment;
+  REAL stamina_max, stamina_inc_max, stamina_capacity, extra_stamina;
+  REAL recover_init, recover_dec_thr_value, recover_min, recover_dec;
+  REAL effort_init, effort_dec_thr_value, effort_min, effort_dec, effort_inc_thr_value, effort_inc;
+  REAL dash_power_rate, max_dash_power, min_dash_power, max_dash_angle, min_dash_angle;
+  REAL dash_angle_step, side_dash_rate, back_dash_rate, max_moment, min_moment;
+  REAL ball_size, ball_decay, ball_rand, ball_speed_max;
+  REAL collision_vel_rate;
+  /* task */
+  int change_ball_position, change_ball_velocity, max_steps, use_continuous, n_actions, use_turning;
+  REAL ball_position_x, ball_position_y, ball_speed, ball_direction, min_distance_to_ball;
+  REAL travel_factor; /* (1 - 0.96^max_steps) / (1 - 0.96), reach_ball_env.py:207 */
+  uint64_t seed;
+  int64_t env_id_offset;
+  int auto_reset, noise;
+} P;
+
+static void params_from_config(const S2DConfig *c, P *p) {
+  const S2DServerParams *s = &c->sp;
+  const S2DReachBallParams *t = &c->task;
+  p->half_l = (REAL)s->pitch_half_length; p->half_w = (REAL)s->pitch_half_width;
+  p->player_size = (REAL)s->player_size; p->player_decay = (REAL)s->player_decay;
+  p->player_rand = (REAL)s->player_rand; p->player_speed_max = (REAL)s->player_speed_max;
+  p->player_accel_max = (REAL)s->player_accel_max; p->inertia_moment = (REAL)s->inertia_moment;
+  p->stamina_max = (REAL)s->stamina_max; p->stamina_inc_max = (REAL)s->stamina_inc_max;
+  p->stamina_capacity = (REAL)s->stamina_capacity; p->extra_stamina = (REAL)s->extra_stamina;
+  p->recover_init = (REAL)s->recover_init;
+  p->recover_dec_thr_value = (REAL)(s->recover_dec_thr * s->stamina_max);
+  p->recover_min = (REAL)s->recover_min; p->recover_dec = (REAL)s->recover_dec;
+  p->effort_init = (REAL)s->effort_init;
+  p->effort_dec_thr_value = (REAL)(s->effort_dec_thr * s->stamina_max);
+  p->effort_min = (REAL)s->effort_min; p->effort_dec = (REAL)s->effort_dec;
+  p->effort_inc_thr_value = (REAL)(s->effort_inc_thr * s->stamina_max);
+  p->effort_inc = (REAL)s->effort_inc;
+  p->dash_power_rate = (REAL)s->dash_power_rate; p->max_dash_power = (REAL)s->max_dash_power;
+  p->min_dash_power = (REAL)s->min_dash_power; p->max_dash_angle = (REAL)s->max_dash_angle;
+  p->min_dash_angle = (REAL)s->min_dash_angle; p->dash_angle_step = (REAL)s->dash_angle_step;
+  p->side_dash_rate = (REAL)s->side_dash_rate; p->back_dash_rate = (REAL)s->back_dash_rate;
+  p->max_moment = (REAL)s->max_moment; p->min_moment = (REAL)s->min_moment;
+  p->ball_size = (REAL)s->ball_size; p->ball_decay = (REAL)s->ball_decay;
+  p->ball_rand = (REAL)s->ball_rand; p->ball_speed_max = (REAL)s->ball_speed_max;
+  p->collision_vel_rate = (REAL)s->collision_vel_rate;
+  p->change_ball_position = t->change_ball_position; p->change_ball_velocity = t->change_ball_velocity;
+  p->max_steps = t->max_steps; p->use_continuous = t->use_continuous_action;
+  p->n_actions = t->action_space_size; p->use_turning = t->use_turning;
+  p->ball_position_x = (REAL)t->ball_position_x; p->ball_position_y = (REAL)t->ball_position_y;
+  p->ball_speed = (REAL)t->ball_speed; p->ball_direction = (REAL)t->ball_direction;
+  p->min_distance_to_ball = (REAL)t->min_distance_to_ball;
+  p->travel_factor = (REAL)((1.0 - pow(t->reset_ball_decay, (double)t->max_steps)) / (1.0 - t->reset_ball_decay));
+  p->seed = c->seed; p->env_id_offset = c->env_id_offset;
+  p->auto_reset = c->auto_reset; p->noise = c->noise;
+}
+
+/* ======================================================================================
+ * A2  ReachBallEnv.action_to_rpc_actions   reach_ball_env.py:53-85
+ * `a` points at 1 (discrete/continuous) or 4 (turning) values; `u` is the uniform draw of
+ * line 71.  step_number += 1 (line 55) is done by the caller (env_step).
+ * ==================================================================================== */
+static void action_map(const P *p, const REAL *a, REAL u, int *cmd, REAL *power, REAL *dir) {
+  if (p->use_continuous) {
+    if (p->use_turning) {
+      REAL v[4];
+      for (int k = 0; k < 4; ++k) v[k] = a[k] < R(-1.0) ? R(-1.0) : (a[k] > R(1.0) ? R(1.0) : a[k]); /* :64 */
+      REAL turn_prob = v[0], turn_angle = v[1], dash_prob = v[2], dash_angle = v[3];             /* :65-68 */
+      REAL e0 = exp_r(dash_prob), e1 = exp_r(turn_prob);                                         /* :69-70 */
+      REAL p0 = e0 / (e0 + e1);
+      if (u < p0) {            /* :71-75  (quirk: "turn" is chosen with the DASH probability) */
+        *cmd = S2D_CMD_TURN; *power = R(0.0); *dir = turn_angle * R(180.0);
+      } else {                 /* :76-79 */
+        *cmd = S2D_CMD_DASH; *power = R(100.0); *dir = dash_angle * R(180.0);
+      }
+    } else {                   /* :81-82  not clipped */
+      *cmd = S2D_CMD_DASH; *power = R(100.0); *dir = a[0] * R(180.0);
+    }
+  } else {                     /* :84-85  Python float modulo: result has the sign of the divisor */
+    REAL t = a[0] * R(360.0) / (REAL)p->n_actions;
+    REAL m = R(fmod)(t, R(360.0));
+    if (m < R(0.0)) m += R(360.0);
+    *cmd = S2D_CMD_DASH; *power = R(100.0); *dir = m - R(180.0);
+  }
+}
+
+API void s2do_action_map(const S2DConfig *cfg, const double *a, double u, int *cmd, double *power, double *dir) {
+  P p; params_from_config(cfg, &p);
+  REAL v[4] = {(REAL)a[0], 0, 0, 0};
+  if (p.use_continuous && p.use_turning) for (int k = 1; k < 4; ++k) v[k] = (REAL)a[k];
+  REAL pw, d;
+  action_map(&p, v, (REAL)u, cmd, &pw, &d);
+  *power = pw; *dir = d;
+}
+
+/* ======================================================================================
+ * A3  ReachBallEnv.state_to_observation    reach_ball_env.py:87-111
+ * ==================================================================================== */
+static void observation(const P *p, REAL bx, REAL by, REAL bvx, REAL bvy, REAL px, REAL py, REAL body,
+                        REAL *obs) {
+  REAL ball_speed = hypot2(bvx, bvy);                      /* :91 */
+  REAL ball_direction = atan2_deg(bvy, bvx);               /* :92 */
+  REAL player_body = norm_deg(body);                       /* :94 */
+  REAL player_to_ball = atan2_deg(by - py, bx - px);       /* :95 */
+  REAL rel = norm_deg(player_to_ball - player_body);       /* :96 */
+  obs[0] = rel / R(180.0);                                 /* :98 */
+  obs[1] = player_body / R(180.0);
+  obs[2] = px / p->half_l;                                 /* 52.5 */
+  obs[3] = py / p->half_w;                                 /* 34.0 */
+  obs[4] = bx / p->half_l;
+  obs[5] = by / p->half_w;
+  obs[6] = ball_speed / R(3.0);
+  obs[7] = ball_direction / R(360.0);
+  obs[8] = bvx / R(3.0);
+  obs[9] = bvy / R(3.0);                                   /* :107 */
+}
+
+API void s2do_observation(const S2DConfig *cfg, const double *in7, double *obs10) {
+  P p; params_from_config(cfg, &p);
+  REAL o[10];
+  observation(&p, (REAL)in7[0], (REAL)in7[1], (REAL)in7[2], (REAL)in7[3], (REAL)in7[4], (REAL)in7[5], (REAL)in7[6], o);
+  for (int k = 0; k < 10; ++k) obs10[k] = o[k];
+}
+
+/* ======================================================================================
+ * A4  ReachBallEnv.check_trainer_observation   reach_ball_env.py:113-161
+ * ==================================================================================== */
+static void check_trainer(const P *p, REAL bx, REAL by, REAL px, REAL py, REAL body, int step_number,
+                          REAL *carry_dist, REAL *carry_angle, int *done, REAL *reward, int *result) {
+  REAL dx = bx - px, dy = by - py;
+  REAL distance_to_ball = hypot2(dx, dy);                               /* :121 */
+  REAL player_body = norm_deg(body);                                    /* :122 */
+  REAL ball_direction = atan2_deg(dy, dx);                              /* :123 */
+  REAL diff = norm_deg(ball_direction - player_body);                   /* :124 */
+  int d = 0, res = S2D_RESULT_NONE;
+  REAL r = R(0.0);
+  REAL distance_reward = *carry_dist - distance_to_ball;                /* :130 */
+  r += distance_reward;
+  REAL angle_reward = (R(fabs)(norm_deg(*carry_angle)) - R(fabs)(diff)) / R(180.0); /* :133 */
+  r += angle_reward;
+  if (distance_to_ball < p->min_distance_to_ball) { d = 1; r += R(10.0); res = S2D_RESULT_GOAL; }   /* :137-140 */
+  if (R(fabs)(px) > p->half_l || R(fabs)(py) > p->half_w) { d = 1; r -= R(-10.0); res = S2D_RESULT_OUT; } /* :142-145 (+10, quirk) */
+  if (step_number > p->max_steps) { d = 1; r -= R(5.0); res = S2D_RESULT_TIMEOUT; }                 /* :147-150 strict > */
+  *carry_dist = distance_to_ball;                                       /* :158 */
+  *carry_angle = diff;                                                  /* :159 */
+  *done = d; *reward = r; *result = res;
+}
+
+API void s2do_check_trainer(const S2DConfig *cfg, const double *in5, int step_number, double *carry_dist,
+                            double *carry_angle, int *done, double *reward, int *result) {
+  P p; params_from_config(cfg, &p);
+  REAL cd = (REAL)*carry_dist, ca = (REAL)*carry_angle, rw;
+  check_trainer(&p, (REAL)in5[0], (REAL)in5[1], (REAL)in5[2], (REAL)in5[3], (REAL)in5[4], step_number, &cd, &ca, done, &rw, result);
+  *carry_dist = cd; *carry_angle = ca; *reward = rw;
+}
+
+/* ======================================================================================
+ * A5  ReachBallEnv.trainer_reset_actions + get_ball_velocity   reach_ball_env.py:170-218
+ * The sampler is written against an abstract draw source so that the SAME code consumes
+ * (a) the recorded draws of tests/golden/reset.json and (b) the engine's Philox stream.
+ * ==================================================================================== */
+typedef struct DrawSrc {
+  /* (a) recorded */
+  const double *rec; int n_rec, i_rec, underflow;
+  /* (b) philox */
+  uint64_t seed, gid; uint32_t cycle; int pos; /* pos: sequential word index in the RESET stream */
+} DrawSrc;
+
+static uint32_t src_word(DrawSrc *s) {
+  uint32_t w[4];
+  draw(s->seed, s->gid, s->cycle, ST_RESET, (uint32_t)(s->pos >> 2), w);
+  return w[(s->pos++) & 3];
+}
+static void src_skip_to_block(DrawSrc *s, int block) { s->pos = block * 4; }
+/* random.randint(lo, hi), inclusive */
+static int src_randint(DrawSrc *s, int lo, int hi) {
+  if (s->rec) { if (s->i_rec >= s->n_rec) { s->underflow = 1; return lo; } return (int)s->rec[s->i_rec++]; }
+  return lo + rnd_below(src_word(s), (uint32_t)(hi - lo + 1));
+}
+/* random.random() */
+static REAL src_random(DrawSrc *s) {
+  if (s->rec) { if (s->i_rec >= s->n_rec) { s->underflow = 1; return 0; } return (REAL)s->rec[s->i_rec++]; }
+  return rnd_u01(src_word(s));
+}
+
+#define S2DO_MAX_VEL_TRIES 256
+
+typedef struct ResetDraw { REAL px, py, body, bx, by, bvx, bvy; int tries; } ResetDraw;
+
+static void reset_sample(const P *p, DrawSrc *s, ResetDraw *o) {
+  /* Philox layout: block 0 = {player x, player y, body, ball x}, block 1 = {ball y},
+   * velocity attempt k = block 2+k {speed, dir}.  Same ORDER as the reference's draws. */
+  o->px = (REAL)src_randint(s, -50, 50);                 /* :173 */
+  o->py = (REAL)src_randint(s, -30, 30);                 /* :174 */
+  o->body = (REAL)src_randint(s, 0, 360);                /* :175 */
+  if (p->change_ball_position) {                         /* :176-181 */
+    o->bx = (REAL)src_randint(s, -50, 50);
+    o->by = (REAL)src_randint(s, -30, 30);
+  } else {
+    o->bx = p->ball_position_x;
+    o->by = p->ball_position_y;
+  }
+  o->tries = 0;
+  if (p->change_ball_velocity) {                         /* :202-212 */
+    REAL vx = R(0.0), vy = R(0.0);
+    int ok = 0;
+    for (int k = 0; k < S2DO_MAX_VEL_TRIES && !ok; ++k) {
+      if (!s->rec) src_skip_to_block(s, 2 + k);
+      REAL speed = src_random(s) * R(3.0);               /* :204 */
+      REAL dir = (REAL)src_randint(s, 0, 360);           /* :205 */
+      if (s->rec && s->underflow) break;
+      REAL sn, cs;
+      sincos_deg(dir, &sn, &cs);
+      vx = speed * cs; vy = speed * sn;                  /* :206 from_polar */
+      REAL travel = speed * p->travel_factor;            /* :207 */
+      REAL tx = o->bx + travel * cs, ty = o->by + travel * sn; /* :208-209 */
+      o->tries = k + 1;
+      if (R(fabs)(tx) <= p->half_l && R(fabs)(ty) <= p->half_w) ok = 1; /* :211 */
+    }
+    if (!ok) { vx = R(0.0); vy = R(0.0); }               /* cap reached (p < 1e-18): ball at rest */
+    o->bvx = vx; o->bvy = vy;
+  } else {                                               /* :213-216 */
+    REAL sn, cs;
+    sincos_deg(p->ball_direction, &sn, &cs);
+    o->bvx = p->ball_speed * cs; o->bvy = p->ball_speed * sn;
+  }
+}
+
+/* fixture entry: consume recorded draws, return the trainer actions' fields */
+API int s2do_reset_from_draws(const S2DConfig *cfg, const double *draws, int n_draws, double *out7, int *n_used) {
+  P p; params_from_config(cfg, &p);
+  DrawSrc s; memset(&s, 0, sizeof s);
+  s.rec = draws; s.n_rec = n_draws;
+  ResetDraw o;
+  reset_sample(&p, &s, &o);
+  out7[0] = o.bx; out7[1] = o.by; out7[2] = o.bvx; out7[3] = o.bvy; out7[4] = o.px; out7[5] = o.py; out7[6] = o.body;
+  *n_used = s.i_rec;
+  return s.underflow ? -1 : 0;
+}
+
+/* ======================================================================================
+ * S  rcssserver dynamics for one player + one ball (EXT).
+ * ==================================================================================== */
+typedef struct Env {
+  REAL px, py, vx, vy, body, stamina, effort, recovery, capacity;
+  REAL bx, by, bvx, bvy, prev_dist, prev_angle;
+  int32_t step_number, cycle;
+} Env;
+
+static REAL clampr(REAL v, REAL lo, REAL hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* Player::dash -- appendix A "Dash(power, dir)" */
+static void cmd_dash(const P *p, Env *e, REAL power, REAL dir, REAL *ax, REAL *ay) {
+  power = clampr(power, p->min_dash_power, p->max_dash_power);
+  dir = clampr(dir, p->min_dash_angle, p->max_dash_angle);
+  if (p->dash_angle_step > R(0.0)) dir = p->dash_angle_step * R(rint)(dir / p->dash_angle_step);
+  int back = power < R(0.0);
+  REAL need = back ? power * R(-2.0) : power;
+  REAL avail = e->stamina + p->extra_stamina;
+  if (need > avail) need = avail;
+  REAL st = e->stamina - need;
+  e->stamina = st > R(0.0) ? st : R(0.0);
+  power = back ? need / R(-2.0) : need;
+  REAL ad = R(fabs)(dir);
+  REAL dir_rate = ad > R(90.0)
+      ? p->back_dash_rate - ((p->back_dash_rate - p->side_dash_rate) * (R(1.0) - (ad - R(90.0)) / R(90.0)))
+      : p->side_dash_rate + ((R(1.0) - p->side_dash_rate) * (R(1.0) - ad / R(90.0)));
+  dir_rate = clampr(dir_rate, R(0.0), R(1.0));
+  REAL acc = R(fabs)(e->effort * power * dir_rate * p->dash_power_rate);
+  if (back) dir += R(180.0);
+  REAL sn, cs;
+  sincos_deg(norm_deg(e->body + dir), &sn, &cs);
+  *ax += acc * cs;
+  *ay += acc * sn;
+}
+
+/* Player::turn -- appendix A "Turn(moment)"; `noise_u` in [0,1) or 0.5 for none */
+static void cmd_turn(const P *p, Env *e, REAL moment, REAL noise_u) {
+  moment = clampr(moment, p->min_moment, p->max_moment);
+  REAL speed = hypot2(e->vx, e->vy);
+  REAL f = R(1.0);
+  if (p->noise) f = R(1.0) + (noise_u * R(2.0) - R(1.0)) * p->player_rand;
+  e->body = norm_deg(e->body + f * moment / (R(1.0) + p->inertia_moment * speed));
+}
+
+/* MPObject::_inc for one object (accel clamp, vel += accel, speed clamp, noise, pos += vel) */
+static void obj_inc(REAL *x, REAL *y, REAL *vx, REAL *vy, REAL ax, REAL ay, REAL accel_max, REAL speed_max,
+                    int noise, REAL rnd, REAL u_mag, REAL u_ang) {
+  if (ax != R(0.0) || ay != R(0.0)) {
+    REAL a = hypot2(ax, ay);
+    if (a > accel_max) { REAL k = accel_max / a; ax *= k; ay *= k; }
+    *vx += ax; *vy += ay;
+  }
+  if (*vx != R(0.0) || *vy != R(0.0)) {
+    REAL s = hypot2(*vx, *vy);
+    if (s > speed_max) { REAL k = speed_max / s; *vx *= k; *vy *= k; }
+  }
+  if (noise) {
+    REAL s = hypot2(*vx, *vy);
+    REAL mag = u_mag * (rnd * s);
+    REAL sn, cs;
+    sincos_deg(u_ang * R(360.0) - R(180.0), &sn, &cs);
+    *vx += mag * cs; *vy += mag * sn;
+  }
+  *x += *vx; *y += *vy;
+}
+
+/* Stadium::collisions for the single player-ball pair: symmetric separation about the
+ * midpoint to exact contact, both velocities *= collision_vel_rate (-0.1). */
+static void collide(const P *p, Env *e) {
+  REAL dx = e->bx - e->px, dy = e->by - e->py;
+  REAL d = hypot2(dx, dy);
+  REAL rsum = p->player_size + p->ball_size;
+  if (d < rsum) {
+    REAL ux, uy;
+    if (d > R(0.0)) { ux = dx / d; uy = dy / d; } else { ux = R(1.0); uy = R(0.0); }
+    REAL mx = (e->px + e->bx) * R(0.5), my = (e->py + e->by) * R(0.5);
+    REAL h = rsum * R(0.5);
+    e->px = mx - ux * h; e->py = my - uy * h;
+    e->bx = mx + ux * h; e->by = my + uy * h;
+    e->vx *= p->collision_vel_rate; e->vy *= p->collision_vel_rate;
+    e->bvx *= p->collision_vel_rate; e->bvy *= p->collision_vel_rate;
+  }
+}
+
+/* Player::updateStamina -- appendix A */
+static void update_stamina(const P *p, Env *e) {
+  if (e->stamina <= p->recover_dec_thr_value) {
+    if (e->recovery > p->recover_min) { REAL r = e->recovery - p->recover_dec; e->recovery = r > p->recover_min ? r : p->recover_min; }
+  }
+  if (e->stamina <= p->effort_dec_thr_value) {
+    if (e->effort > p->effort_min) { REAL f = e->effort - p->effort_dec; e->effort = f > p->effort_min ? f : p->effort_min; }
+  }
+  if (e->stamina >= p->effort_inc_thr_value) {
+    if (e->effort < p->effort_init) { REAL f = e->effort + p->effort_inc; e->effort = f < p->effort_init ? f : p->effort_init; }
+  }
+  REAL inc = e->recovery * p->stamina_inc_max;
+  REAL room = p->stamina_max - e->stamina;
+  if (inc > room) inc = room;
+  if (p->stamina_capacity >= R(0.0)) { if (inc > e->capacity) inc = e->capacity; }
+  e->stamina += inc;
+  if (e->stamina > p->stamina_max) e->stamina = p->stamina_max;
+  if (p->stamina_capacity >= R(0.0)) { REAL c = e->capacity - inc; e->capacity = c > R(0.0) ? c : R(0.0); }
+}
+
+/* One simulator cycle (appendix A "Per-cycle order", play_on, referee off in coach mode:
+ * soccer_2d_env.py:363-366 starts rcssserver with coach=true and no coach_w_referee). */
+static void sim_cycle(const P *p, Env *e, uint64_t gid, int cmd, REAL power, REAL dir) {
+  uint32_t nz[4] = {0, 0, 0, 0}, nz2[4] = {0, 0, 0, 0};
+  if (p->noise) {
+    draw(p->seed, gid, (uint32_t)e->cycle, ST_NOISE, 0, nz);
+    draw(p->seed, gid, (uint32_t)e->cycle, ST_NOISE, 1, nz2);
+  }
+  REAL ax = R(0.0), ay = R(0.0);
+  if (cmd == S2D_CMD_DASH) cmd_dash(p, e, power, dir, &ax, &ay);
+  else if (cmd == S2D_CMD_TURN) cmd_turn(p, e, dir, rnd_u01(nz2[0]));
+  obj_inc(&e->px, &e->py, &e->vx, &e->vy, ax, ay, p->player_accel_max, p->player_speed_max,
+          p->noise, p->player_rand, rnd_u01(nz[0]), rnd_u01(nz[1]));
+  obj_inc(&e->bx, &e->by, &e->bvx, &e->bvy, R(0.0), R(0.0), R(0.0), p->ball_speed_max,
+          p->noise, p->ball_rand, rnd_u01(nz[2]), rnd_u01(nz[3]));
+  collide(p, e);
+  e->cycle += 1;                                        /* referee: time += 1 */
+  e->vx *= p->player_decay; e->vy *= p->player_decay;   /* _turn */
+  e->bvx *= p->ball_decay; e->bvy *= p->ball_decay;
+  update_stamina(p, e);
+}
+
+/* A5 + A6: trainer moves ball & player, recovers the player, then ONE cycle passes with
+ * no body command (soccer_2d_env.py:186-197); carry is seeded (reach_ball_env.py:166). */
+static void env_reset(const P *p, Env *e, uint64_t gid, REAL *obs) {
+  DrawSrc s; memset(&s, 0, sizeof s);
+  s.seed = p->seed; s.gid = gid; s.cycle = (uint32_t)e->cycle;
+  ResetDraw o;
+  reset_sample(p, &s, &o);
+  e->step_number = 0;                                    /* :172 */
+  e->bx = o.bx; e->by = o.by; e->bvx = o.bvx; e->bvy = o.bvy;      /* (move (ball) x y 0 vx vy) */
+  e->px = o.px; e->py = o.py; e->body = norm_deg(o.body); e->vx = R(0.0); e->vy = R(0.0); /* (move (player..)) */
+  e->stamina = p->stamina_max; e->recovery = p->recover_init;     /* (recover) */
+  e->effort = p->effort_init; e->capacity = p->stamina_capacity;
+  sim_cycle(p, e, gid, S2D_CMD_NONE, R(0.0), R(0.0));
+  observation(p, e->bx, e->by, e->bvx, e->bvy, e->px, e->py, e->body, obs);
+  int d, res; REAL rw;
+  check_trainer(p, e->bx, e->by, e->px, e->py, e->body, e->step_number, &e->prev_dist, &e->prev_angle, &d, &rw, &res);
+}
+
+/* ======================================================================================
+ * Vectorised engine (struct-of-arrays host memory), mirror of the s2d_* C ABI.
+ * ==================================================================================== */
+typedef struct S2DOEngine {
+  P p; S2DConfig cfg; int64_t n;
+  Env *env;
+  REAL *obs, *terminal_obs, *reward, *action_dir;
+  uint8_t *done, *result, *action_cmd;
+  unsigned long long stats[8];
+} S2DOEngine;
+
+API S2DOEngine *s2do_create(const S2DConfig *cfg, int64_t n) {
+  if (!cfg || n <= 0) return NULL;
+  S2DOEngine *h = (S2DOEngine *)calloc(1, sizeof *h);
+  params_from_config(cfg, &h->p);
+  h->cfg = *cfg; h->n = n;
+  h->env = (Env *)calloc((size_t)n, sizeof(Env));
+  h->obs = (REAL *)calloc((size_t)n * 10, sizeof(REAL));
+  h->terminal_obs = (REAL *)calloc((size_t)n * 10, sizeof(REAL));
+  h->reward = (REAL *)calloc((size_t)n, sizeof(REAL));
+  h->action_dir = (REAL *)calloc((size_t)n, sizeof(REAL));
+  h->done = (uint8_t *)calloc((size_t)n, 1);
+  h->result = (uint8_t *)calloc((size_t)n, 1);
+  h->action_cmd = (uint8_t *)calloc((size_t)n, 1);
+  for (int64_t i = 0; i < n; ++i) {                      /* initial state = after (recover) */
+    Env *e = &h->env[i];
+    e->stamina = h->p.stamina_max; e->recovery = h->p.recover_init;
+    e->effort = h->p.effort_init; e->capacity = h->p.stamina_capacity;
+  }
+  return h;
+}
+API void s2do_destroy(S2DOEngine *h) {
+  if (!h) return;
+  free(h->env); free(h->obs); free(h->terminal_obs); free(h->reward); free(h->action_dir);
+  free(h->done); free(h->result); free(h->action_cmd); free(h);
+}
+
+API void s2do_reset(S2DOEngine *h, const uint8_t *mask) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < h->n; ++i) {
+    if (mask && !mask[i]) continue;
+    env_reset(&h->p, &h->env[i], (uint64_t)(h->p.env_id_offset + i), &h->obs[i * 10]);
+    h->reward[i] = R(0.0); h->done[i] = 0; h->result[i] = 0;
+  }
+}
+
+/* decode the action of env i for this cycle (caller layouts of include/s2d.h, or the
+ * in-engine random policy) */
+static void fetch_action(const S2DOEngine *h, int64_t i, const void *actions, int kind, uint32_t cycle,
+                         REAL a[4], void *rollout_action_out) {
+  const P *p = &h->p;
+  uint64_t gid = (uint64_t)(p->env_id_offset + i);
+  a[0] = a[1] = a[2] = a[3] = R(0.0);
+  switch (kind) {
+    case S2D_ACT_DISCRETE_I32: a[0] = (REAL)((const int32_t *)actions)[i]; break;
+    case S2D_ACT_DISCRETE_I64: a[0] = (REAL)((const int64_t *)actions)[i]; break;
+    case S2D_ACT_CONTINUOUS: a[0] = (REAL)((const float *)actions)[i]; break;
+    case S2D_ACT_TURNING: for (int k = 0; k < 4; ++k) a[k] = (REAL)((const float *)actions)[i * 4 + k]; break;
+    default: {
+      uint32_t w[4];
+      draw(p->seed, gid, cycle, ST_POLICY, 0, w);
+      if (!p->use_continuous) a[0] = (REAL)rnd_below(w[0], (uint32_t)p->n_actions);
+      else if (!p->use_turning) a[0] = rnd_u01(w[0]) * R(2.0) - R(1.0);
+      else for (int k = 0; k < 4; ++k) a[k] = rnd_u01(w[k]) * R(2.0) - R(1.0);
+    }
+  }
+  if (rollout_action_out) {
+    if (!p->use_continuous) ((int32_t *)rollout_action_out)[i] = (int32_t)a[0];
+    else if (!p->use_turning) ((float *)rollout_action_out)[i] = (float)a[0];
+    else for (int k = 0; k < 4; ++k) ((float *)rollout_action_out)[i * 4 + k] = (float)a[k];
+  }
+}
+
+/* A1  Soccer2DEnv.step   soccer_2d_env.py:226-269 */
+static void step_one(S2DOEngine *h, int64_t i, const void *actions, int kind, void *rollout_action_out,
+                     unsigned long long local_stats[4]) {
+  const P *p = &h->p;
+  Env *e = &h->env[i];
+  uint64_t gid = (uint64_t)(p->env_id_offset + i);
+  REAL a[4];
+  fetch_action(h, i, actions, kind, (uint32_t)e->cycle, a, rollout_action_out);
+  e->step_number += 1;                                   /* reach_ball_env.py:55 */
+  REAL u = R(0.0);
+  if (p->use_continuous && p->use_turning) {
+    uint32_t w[4];
+    draw(p->seed, gid, (uint32_t)e->cycle, ST_SELECT, 0, w);
+    u = rnd_u01(w[0]);
+  }
+  int cmd; REAL power, dir;
+  action_map(p, a, u, &cmd, &power, &dir);               /* :238 */
+  h->action_cmd[i] = (uint8_t)cmd; h->action_dir[i] = dir;
+  sim_cycle(p, e, gid, cmd, power, dir);                 /* rcssserver cycle; trainer forces PlayOn :242 */
+  REAL *obs = &h->obs[i * 10];
+  observation(p, e->bx, e->by, e->bvx, e->bvy, e->px, e->py, e->body, obs);   /* :249 */
+  int d, res; REAL rw;
+  check_trainer(p, e->bx, e->by, e->px, e->py, e->body, e->step_number, &e->prev_dist, &e->prev_angle, &d, &rw, &res); /* :266 */
+  h->reward[i] = rw; h->done[i] = (uint8_t)d; h->result[i] = (uint8_t)res;
+  local_stats[res] += 1;
+  if (d && p->auto_reset) {
+    memcpy(&h->terminal_obs[i * 10], obs, 10 * sizeof(REAL));
+    env_reset(p, e, gid, obs);
+  }
+}
+
+API void s2do_step(S2DOEngine *h, const void *actions, int kind) {
+  unsigned long long s1 = 0, s2 = 0, s3 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : s1, s2, s3)
+  for (int64_t i = 0; i < h->n; ++i) {
+    unsigned long long ls[4] = {0, 0, 0, 0};
+    step_one(h, i, actions, kind, NULL, ls);
+    s1 += ls[1]; s2 += ls[2]; s3 += ls[3];
+  }
+  h->stats[0] += (unsigned long long)h->n; h->stats[1] += s1; h->stats[2] += s2; h->stats[3] += s3;
+}
+
+/* T steps; outputs time-major like S2DRollout but in REAL for obs/reward */
+API void s2do_rollout(S2DOEngine *h, int n_steps, const void *actions, int kind, REAL *obs, void *action,
+                      REAL *reward, uint8_t *done, uint8_t *result) {
+  const P *p = &h->p;
+  size_t aw = !p->use_continuous ? 4 : (p->use_turning ? 16 : 4);
+  size_t in_w = kind == S2D_ACT_DISCRETE_I64 ? 8 : (kind == S2D_ACT_TURNING ? 16 : 4);
+  for (int t = 0; t < n_steps; ++t) {
+    const void *act_t = actions ? (const char *)actions + (size_t)t * (size_t)h->n * in_w : NULL;
+    void *act_out = action ? (char *)action + (size_t)t * (size_t)h->n * aw : NULL;
+    unsigned long long s1 = 0, s2 = 0, s3 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : s1, s2, s3)
+    for (int64_t i = 0; i < h->n; ++i) {
+      unsigned long long ls[4] = {0, 0, 0, 0};
+      step_one(h, i, act_t, kind, act_out, ls);
+      s1 += ls[1]; s2 += ls[2]; s3 += ls[3];
+    }
+    h->stats[0] += (unsigned long long)h->n; h->stats[1] += s1; h->stats[2] += s2; h->stats[3] += s3;
+    size_t off = (size_t)t * (size_t)h->n;
+    if (obs) memcpy(obs + off * 10, h->obs, (size_t)h->n * 10 * sizeof(REAL));
+    if (reward) memcpy(reward + off, h->reward, (size_t)h->n * sizeof(REAL));
+    if (done) memcpy(done + off, h->done, (size_t)h->n);
+    if (result) memcpy(result + off, h->result, (size_t)h->n);
+  }
+}
+
+/* field ids for s2do_get_state: order of S2DBuffers' state pointers */
+API int s2do_get_state(const S2DOEngine *h, int field, double *out) {
+  for (int64_t i = 0; i < h->n; ++i) {
+    const Env *e = &h->env[i];
+    double v;
+    switch (field) {
+      case 0: v = e->px; break; case 1: v = e->py; break; case 2: v = e->vx; break; case 3: v = e->vy; break;
+      case 4: v = e->body; break; case 5: v = e->stamina; break; case 6: v = e->effort; break;
+      case 7: v = e->recovery; break; case 8: v = e->capacity; break; case 9: v = e->bx; break;
+      case 10: v = e->by; break; case 11: v = e->bvx; break; case 12: v = e->bvy; break;
+      case 13: v = e->prev_dist; break; case 14: v = e->prev_angle; break;
+      case 15: v = e->step_number; break; case 16: v = e->cycle; break;
+      default: return -1;
+    }
+    out[i] = v;
+  }
+  return 0;
+}
+/* overwrite one env's state (tests: hand-placed scenarios) -- 17 values in field order */
+API int s2do_set_env(S2DOEngine *h, int64_t i, const double *v17) {
+  if (i < 0 || i >= h->n) return -1;
+  Env *e = &h->env[i];
+  e->px = (REAL)v17[0]; e->py = (REAL)v17[1]; e->vx = (REAL)v17[2]; e->vy = (REAL)v17[3]; e->body = (REAL)v17[4];
+  e->stamina = (REAL)v17[5]; e->effort = (REAL)v17[6]; e->recovery = (REAL)v17[7]; e->capacity = (REAL)v17[8];
+  e->bx = (REAL)v17[9]; e->by = (REAL)v17[10]; e->bvx = (REAL)v17[11]; e->bvy = (REAL)v17[12];
+  e->prev_dist = (REAL)v17[13]; e->prev_angle = (REAL)v17[14];
+  e->step_number = (int32_t)v17[15]; e->cycle = (int32_t)v17[16];
+  return 0;
+}
+API const REAL *s2do_obs(const S2DOEngine *h) { return h->obs; }
+API const REAL *s2do_terminal_obs(const S2DOEngine *h) { return h->terminal_obs; }
+API const REAL *s2do_reward(const S2DOEngine *h) { return h->reward; }
+API const REAL *s2do_action_dir(const S2DOEngine *h) { return h->action_dir; }
+API const uint8_t *s2do_done(const S2DOEngine *h) { return h->done; }
+API const uint8_t *s2do_result(const S2DOEngine *h) { return h->result; }
+API const uint8_t *s2do_action_cmd(const S2DOEngine *h) { return h->action_cmd; }
+API const unsigned long long *s2do_stats(const S2DOEngine *h) { return h->stats; }

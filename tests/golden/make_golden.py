@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.json by RUNNING the reference's own
+Python (`/root/reference/sample_environments/reach_ball_env.py`) in this container.
+
+Only the four pure hooks of ``ReachBallEnv`` are executed (an instance is made with
+``__new__`` so that ``Soccer2DEnv.__init__`` -- which would spawn rcssserver / proxy /
+gRPC processes, soccer_2d_env.py:71-95 -- never runs):
+
+  A2  action_to_rpc_actions      reach_ball_env.py:53-85
+  A3  state_to_observation       reach_ball_env.py:87-111
+  A4  check_trainer_observation  reach_ball_env.py:113-161
+  A5  trainer_reset_actions / get_ball_velocity  reach_ball_env.py:170-218
+
+``gym`` and ``pyrusgeom`` are absent here; tests/golden/_standins.py restates the tiny
+part of their published behaviour the path touches (see its docstring).  The fixtures
+are DATA ONLY (inputs + expected outputs); no reference source is copied.
+
+Run (in the build container, where /root/reference exists):
+    python tests/golden/make_golden.py
+The GPU box never runs this; it only reads the committed JSON.
+"""
+import json
+import logging
+import math
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("S2D_REFERENCE", "/root/reference")
+
+sys.path.insert(0, HERE)
+import _standins  # noqa: E402
+
+_standins.install()
+sys.path.insert(0, REF)
+
+import service_pb2 as pb2  # noqa: E402  (reference's generated protobuf module)
+from sample_environments.reach_ball_env import ReachBallEnv  # noqa: E402
+
+
+def make_env(**kwargs):
+    """ReachBallEnv without process spawning; attributes as __init__ would set them
+    (reach_ball_env.py:26-51)."""
+    env = ReachBallEnv.__new__(ReachBallEnv)
+    lg = logging.getLogger("golden-null")
+    lg.addHandler(logging.NullHandler())
+    lg.propagate = False
+    lg.setLevel(logging.CRITICAL)
+    env.logger = lg
+    env.change_ball_position = kwargs.get('change_ball_position', True)
+    env.change_ball_velocity = kwargs.get('change_ball_velocity', False)
+    env.ball_position_x = kwargs.get('ball_position_x', 0)
+    env.ball_position_y = kwargs.get('ball_position_y', 0)
+    env.ball_speed = kwargs.get('ball_speed', 0)
+    env.ball_direction = kwargs.get('ball_direction', 0)
+    env.min_distance_to_ball = kwargs.get('min_distance_to_ball', 5.0)
+    env.max_steps = kwargs.get('max_steps', 200)
+    env.use_continuous_action = kwargs.get('use_continuous_action', True)
+    env.action_space_size = kwargs.get('action_space_size', 16)
+    env.use_turning = kwargs.get('use_turning', False)
+    if env.use_continuous_action:
+        env.action_space = _standins.Box(-1, 1, shape=(4,) if env.use_turning else (1,), dtype=np.float32)
+    else:
+        env.action_space = _standins.Discrete(env.action_space_size)
+    env.distance_to_ball = 0.0
+    env.body_ball_angle_diff = 0.0
+    env.step_number = 0
+    return env
+
+
+def player_state(bx, by, bvx, bvy, px, py, body):
+    s = pb2.State()
+    wm = s.world_model
+    wm.ball.position.x, wm.ball.position.y = bx, by
+    wm.ball.velocity.x, wm.ball.velocity.y = bvx, bvy
+    wm.self.position.x, wm.self.position.y = px, py
+    wm.self.body_direction = body
+    return s
+
+
+def trainer_state(bx, by, px, py, body):
+    s = pb2.State()
+    wm = s.world_model
+    wm.ball.position.x, wm.ball.position.y = bx, by
+    p = wm.teammates.add()
+    p.position.x, p.position.y = px, py
+    p.body_direction = body
+    return s
+
+
+def action_fields(a):
+    kind = a.WhichOneof('action')
+    if kind == 'dash':
+        return {'type': 'dash', 'power': a.dash.power, 'dir': a.dash.relative_direction}
+    if kind == 'turn':
+        return {'type': 'turn', 'power': 0.0, 'dir': a.turn.relative_direction}
+    raise AssertionError(kind)
+
+
+# ----------------------------------------------------------------------------- A2
+def gen_action_map():
+    out = {'discrete': [], 'continuous': [], 'turning': []}
+    for n in (4, 8, 16, 32, 7):
+        env = make_env(use_continuous_action=False, action_space_size=n)
+        rows = []
+        for a in range(n):
+            for form in ('int', 'np0', 'np1'):
+                arg = a if form == 'int' else (np.array(a) if form == 'np0' else np.array([a]))
+                before = env.step_number
+                act = env.action_to_rpc_actions(arg, None)
+                assert env.step_number == before + 1
+                f = action_fields(act)
+                if form == 'int':
+                    rows.append({'a': a, **f})
+                else:
+                    assert rows[-1]['dir'] == f['dir']
+        out['discrete'].append({'n': n, 'rows': rows})
+    env = make_env(use_continuous_action=True, use_turning=False)
+    rng = random.Random(1234)
+    vals = [-1.0, -0.5, 0.0, 0.25, 1.0, 1.5, -2.0] + [rng.uniform(-1, 1) for _ in range(40)]
+    for v in vals:
+        v32 = float(np.float32(v))
+        act = env.action_to_rpc_actions(np.array([v32], dtype=np.float32), None)
+        out['continuous'].append({'a': v32, **action_fields(act)})
+    env = make_env(use_continuous_action=True, use_turning=True)
+    rs = np.random.RandomState(99)
+    for i in range(96):
+        a = rs.uniform(-1.6, 1.6, size=4).astype(np.float32)   # beyond [-1,1]: clip is pinned
+        u = float(rs.uniform())
+        real_rand = np.random.rand
+        np.random.rand = lambda u=u: u                         # inject the single uniform draw (line 71)
+        try:
+            act = env.action_to_rpc_actions(a, None)
+        finally:
+            np.random.rand = real_rand
+        out['turning'].append({'a': [float(x) for x in a], 'u': u, **action_fields(act)})
+    return out
+
+
+# ----------------------------------------------------------------------------- A3
+def gen_obs():
+    env = make_env()
+    rs = np.random.RandomState(7)
+    rows = []
+    specials = [
+        (10.0, -5.0, 1.0, -1.0, -20.0, 12.0, 170.0),     # SURVEY appendix-B KAT
+        (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0),             # everything zero (th() of zero vector)
+        (5.0, 5.0, 0.0, 0.0, 5.0, 5.0, 90.0),            # ball on player
+        (1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 270.0),           # body beyond 180 -> normalised
+        (1.0, 0.0, 0.0, 0.0, 0.0, 0.0, -200.0),
+        (-3.0, 4.0, -2.0, 0.5, 52.0, -33.5, 45.0),
+        (-52.5, 34.0, 3.0, 0.0, 52.5, -34.0, -179.0),
+        (0.0, 10.0, 0.0, -3.0, 0.0, -10.0, 179.0),
+        (20.0, 0.0, 0.1, 0.1, -20.0, 0.0, 400.0),        # fmod branch
+        (20.0, 1.0, -0.1, 0.0, 25.0, 1.0, -725.0),
+    ]
+    for i in range(256):
+        if i < len(specials):
+            v = specials[i]
+        else:
+            v = (rs.uniform(-55, 55), rs.uniform(-36, 36), rs.uniform(-3, 3), rs.uniform(-3, 3),
+                 rs.uniform(-55, 55), rs.uniform(-36, 36), rs.uniform(-180, 180))
+            if i % 17 == 0:
+                v = v[:2] + (0.0, 0.0) + v[4:]
+        s = player_state(*v)
+        wm = s.world_model
+        inp = [wm.ball.position.x, wm.ball.position.y, wm.ball.velocity.x, wm.ball.velocity.y,
+               wm.self.position.x, wm.self.position.y, wm.self.body_direction]   # float32-rounded by protobuf
+        obs = env.state_to_observation(s)
+        assert obs.dtype == np.float64 and obs.shape == (10,)
+        rows.append({'in': [float(x) for x in inp], 'obs': [float(x) for x in obs]})
+    return {'layout': ['bx', 'by', 'bvx', 'bvy', 'px', 'py', 'body'], 'rows': rows}
+
+
+# ----------------------------------------------------------------------------- A4
+def gen_reward():
+    rs = np.random.RandomState(11)
+    seqs = []
+
+    def run(env, frames, note):
+        """frames: list of (bx,by,px,py,body, force_step_number or None)"""
+        rows = []
+        # abs_reset path (reach_ball_env.py:163-168): first call seeds the carry, output discarded
+        for k, fr in enumerate(frames):
+            bx, by, px, py, body, force = fr
+            if k > 0:
+                if force is not None:
+                    env.step_number = force - 1
+                env.action_to_rpc_actions(0, None)          # increments step_number (line 55)
+            s = trainer_state(bx, by, px, py, body)
+            t = s.world_model.teammates[0]
+            inp = [s.world_model.ball.position.x, s.world_model.ball.position.y,
+                   t.position.x, t.position.y, t.body_direction]
+            done, reward, info = env.check_trainer_observation(s)
+            rows.append({'in': [float(x) for x in inp], 'step_number': env.step_number,
+                         'done': bool(done), 'reward': float(reward), 'result': info['result'],
+                         'carry_dist': float(env.distance_to_ball),
+                         'carry_angle': float(env.body_ball_angle_diff)})
+        seqs.append({'note': note, 'min_distance_to_ball': env.min_distance_to_ball,
+                     'max_steps': env.max_steps, 'rows': rows})
+
+    # SURVEY appendix-B KAT
+    run(make_env(use_continuous_action=False), [(10, -5, -20, 12, 170, None), (10, -5, -19.1, 12, 170, None)], 'survey-kat')
+    # all 2^3 combinations of Goal / Out / Timeout on the second frame
+    for goal in (0, 1):
+        for out_ in (0, 1):
+            for tmo in (0, 1):
+                if out_:
+                    px, py = 53.0, 10.0
+                else:
+                    px, py = 40.0, 10.0
+                if goal:
+                    bx, by = px + 1.5, py - 2.0
+                else:
+                    bx, by = px - 20.0, py + 3.0
+                step = 201 if tmo else 57
+                run(make_env(use_continuous_action=False),
+                    [(bx - 0.3, by, px - 0.8, py, 30.0, None), (bx, by, px, py, 35.0, step)],
+                    f'combo goal={goal} out={out_} timeout={tmo}')
+    # strict '>' boundary of the timeout (step 200 is not a timeout, 201 is)
+    for step in (199, 200, 201, 202):
+        run(make_env(use_continuous_action=False),
+            [(0, 0, 30, 0, 180, None), (0, 0, 29, 0, 180, step)], f'timeout-boundary step={step}')
+    # exact-threshold cases: d == min_distance is NOT a goal; |x| == 52.5 is NOT out
+    run(make_env(use_continuous_action=False), [(0, 0, 6, 0, 180, None), (0, 0, 5, 0, 180, None), (0, 0, 4.75, 0, 180, None)], 'goal-threshold')
+    run(make_env(use_continuous_action=False), [(0, 0, 52, 0, 0, None), (0, 0, 52.5, 0, 0, None), (0, 0, 52.75, 0, 0, None)], 'out-threshold-x')
+    run(make_env(use_continuous_action=False), [(0, 0, 0, -33.5, -90, None), (0, 0, 0, -34.0, -90, None), (0, 0, 0, -34.25, -90, None)], 'out-threshold-y')
+    run(make_env(use_continuous_action=False, min_distance_to_ball=1.0, max_steps=5),
+        [(0, 0, 3, 0, 180, None), (0, 0, 2, 0, 180, None), (0, 0, 1.5, 0, 170, None), (0, 0, 0.5, 0, 170, None)], 'kwargs min_dist=1 max_steps=5')
+    run(make_env(use_continuous_action=False, max_steps=3),
+        [(0, 0, 30, 0, 0, None)] + [(0, 0, 30 - k, 0, 10 * k, None) for k in range(1, 6)], 'kwargs max_steps=3 natural timeout')
+    # random walks
+    for i in range(48):
+        env = make_env(use_continuous_action=False)
+        bx, by = rs.uniform(-50, 50), rs.uniform(-30, 30)
+        px, py, body = rs.uniform(-50, 50), rs.uniform(-30, 30), rs.uniform(-180, 180)
+        frames = [(bx, by, px, py, body, None)]
+        for k in range(int(rs.randint(3, 12))):
+            bx += rs.uniform(-1, 1)
+            by += rs.uniform(-1, 1)
+            px += rs.uniform(-1.05, 1.05)
+            py += rs.uniform(-1.05, 1.05)
+            body = rs.uniform(-180, 180) if rs.rand() < 0.5 else body
+            frames.append((bx, by, px, py, body, None))
+        run(env, frames, f'random-walk {i}')
+    return seqs
+
+
+# ----------------------------------------------------------------------------- A5
+class _Recorder:
+    """Wraps a seeded random.Random; records every draw the reference makes."""
+
+    def __init__(self, seed):
+        self.r = random.Random(seed)
+        self.draws = []
+
+    def randint(self, a, b):
+        v = self.r.randint(a, b)
+        self.draws.append({'f': 'randint', 'a': a, 'b': b, 'v': v})
+        return v
+
+    def random(self):
+        v = self.r.random()
+        self.draws.append({'f': 'random', 'v': v})
+        return v
+
+
+def gen_reset():
+    import sample_environments.reach_ball_env as mod
+    rows = []
+    configs = [
+        dict(change_ball_position=True, change_ball_velocity=True),
+        dict(change_ball_position=True, change_ball_velocity=False),
+        dict(change_ball_position=False, change_ball_velocity=True, ball_position_x=40, ball_position_y=-25),
+        dict(change_ball_position=False, change_ball_velocity=False, ball_position_x=10, ball_position_y=5,
+             ball_speed=1.5, ball_direction=30),
+        dict(change_ball_position=True, change_ball_velocity=True, max_steps=50),
+    ]
+    real_random = mod.random
+    try:
+        for ci, cfg in enumerate(configs):
+            for seed in range(24):
+                env = make_env(use_continuous_action=False, **cfg)
+                env.step_number = 17
+                rec = _Recorder(1000 * ci + seed)
+                mod.random = rec
+                acts = env.trainer_reset_actions()
+                assert env.step_number == 0
+                kinds = [a.WhichOneof('action') for a in acts]
+                assert kinds == ['do_move_ball', 'do_move_player', 'do_recover'], kinds
+                mb, mp = acts[0].do_move_ball, acts[1].do_move_player
+                assert mp.our_side is True and mp.uniform_number == 1
+                rows.append({'cfg': cfg, 'max_steps': env.max_steps, 'draws': rec.draws,
+                             'ball_pos': [mb.position.x, mb.position.y],
+                             'ball_vel': [mb.velocity.x, mb.velocity.y],       # float32 (protobuf field)
+                             'player_pos': [mp.position.x, mp.position.y],
+                             'player_body': mp.body_direction})
+    finally:
+        mod.random = real_random
+    return rows
+
+
+def main():
+    out = {
+        'action_map.json': gen_action_map(),
+        'obs.json': gen_obs(),
+        'reward.json': gen_reward(),
+        'reset.json': gen_reset(),
+    }
+    for name, data in out.items():
+        with open(os.path.join(HERE, name), 'w') as f:
+            json.dump(data, f, indent=None, separators=(',', ':'))
+            f.write('\n')
+        print(name, os.path.getsize(os.path.join(HERE, name)), 'bytes')
+
+
+if __name__ == '__main__':
+    main()

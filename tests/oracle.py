@@ -1,0 +1,305 @@
+"""ctypes wrapper around the CPU oracle (oracle/_build/libs2d_oracle_{f32,f64}.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'gym-soccer-2d-env_amd')
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+from soccer2d_amd import _capi  # noqa: E402  (struct layouts of include/s2d.h only)
+
+ORACLE_DIR = os.path.join(ROOT, 'oracle')
+
+# The test suite's OWN table of defaults (SURVEY.md appendix A + reach_ball_env.py:26-36),
+# deliberately not read from the product so that a wrong product default is caught.
+SERVER_DEFAULTS = dict(
+    pitch_half_length=52.5, pitch_half_width=34.0,
+    player_size=0.3, player_decay=0.4, player_rand=0.1, player_speed_max=1.05, player_accel_max=1.0,
+    inertia_moment=5.0,
+    stamina_max=8000.0, stamina_inc_max=45.0, stamina_capacity=130600.0, extra_stamina=50.0,
+    recover_init=1.0, recover_dec_thr=0.3, recover_min=0.5, recover_dec=0.002,
+    effort_init=1.0, effort_dec_thr=0.3, effort_min=0.6, effort_dec=0.005, effort_inc_thr=0.6, effort_inc=0.01,
+    dash_power_rate=0.006, max_dash_power=100.0, min_dash_power=0.0,
+    max_dash_angle=180.0, min_dash_angle=-180.0, dash_angle_step=1.0, side_dash_rate=0.4, back_dash_rate=0.6,
+    max_moment=180.0, min_moment=-180.0,
+    ball_size=0.085, ball_decay=0.94, ball_rand=0.05, ball_speed_max=3.0, ball_accel_max=2.7,
+    collision_vel_rate=-0.1)
+TASK_DEFAULTS = dict(
+    change_ball_position=True, change_ball_velocity=False, ball_position_x=0, ball_position_y=0,
+    ball_speed=0, ball_direction=0, min_distance_to_ball=5.0, max_steps=200,
+    use_continuous_action=True, action_space_size=16, use_turning=False, reset_ball_decay=0.96)
+# kwargs of dqn_stable_baselines3.py:18-31 (the benchmark workload)
+DQN_KWARGS = dict(change_ball_position=True, change_ball_velocity=True, min_distance_to_ball=5.0,
+                  max_steps=200, use_continuous_action=False, action_space_size=16, use_turning=False)
+
+
+def make_config(seed=0x5EED, env_id_offset=0, auto_reset=1, noise=0, server=None, **task):
+    cfg = _capi.S2DConfig()
+    cfg.abi_version = _capi.S2D_ABI_VERSION
+    cfg.struct_bytes = C.sizeof(_capi.S2DConfig)
+    sp = dict(SERVER_DEFAULTS)
+    sp.update(server or {})
+    for k, v in sp.items():
+        setattr(cfg.sp, k, float(v))
+    tk = dict(TASK_DEFAULTS)
+    for k in task:
+        if k not in tk:
+            raise KeyError(k)
+    tk.update(task)
+    for k, v in tk.items():
+        setattr(cfg.task, k, type(getattr(cfg.task, k))(v))
+    cfg.seed = seed
+    cfg.env_id_offset = env_id_offset
+    cfg.auto_reset = auto_reset
+    cfg.noise = noise
+    return cfg
+
+
+def build_oracle(force=False):
+    out = os.path.join(ORACLE_DIR, '_build')
+    libs = [os.path.join(out, f'libs2d_oracle_{p}.so') for p in ('f32', 'f64')]
+    src = os.path.join(ORACLE_DIR, 's2d_oracle.c')
+    stale = force or any((not os.path.exists(l)) or os.path.getmtime(l) < os.path.getmtime(src) for l in libs)
+    if stale:
+        subprocess.run(['make', '-C', ORACLE_DIR] + (['-B'] if force else []), check=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return libs
+
+
+_libs = {}
+
+
+def lib(precision='f32'):
+    if precision in _libs:
+        return _libs[precision]
+    build_oracle()
+    L = C.CDLL(os.path.join(ORACLE_DIR, '_build', f'libs2d_oracle_{precision}.so'))
+    real = C.c_float if precision == 'f32' else C.c_double
+    cfgp = C.POINTER(_capi.S2DConfig)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int)
+    L.s2do_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+    L.s2do_philox4x32_10.restype = None
+    L.s2do_sincos_deg.argtypes = [C.c_double, dp, dp]
+    L.s2do_sincos_deg.restype = None
+    for n in ('s2do_atan2_deg',):
+        getattr(L, n).argtypes = [C.c_double, C.c_double]
+        getattr(L, n).restype = C.c_double
+    for n in ('s2do_exp', 's2do_norm_deg'):
+        getattr(L, n).argtypes = [C.c_double]
+        getattr(L, n).restype = C.c_double
+    L.s2do_real_bytes.restype = C.c_int
+    L.s2do_action_map.argtypes = [cfgp, dp, C.c_double, ip, dp, dp]
+    L.s2do_action_map.restype = None
+    L.s2do_observation.argtypes = [cfgp, dp, dp]
+    L.s2do_observation.restype = None
+    L.s2do_check_trainer.argtypes = [cfgp, dp, C.c_int, dp, dp, ip, dp, ip]
+    L.s2do_check_trainer.restype = None
+    L.s2do_reset_from_draws.argtypes = [cfgp, dp, C.c_int, dp, ip]
+    L.s2do_reset_from_draws.restype = C.c_int
+    L.s2do_create.argtypes = [cfgp, C.c_int64]
+    L.s2do_create.restype = C.c_void_p
+    L.s2do_destroy.argtypes = [C.c_void_p]
+    L.s2do_destroy.restype = None
+    L.s2do_reset.argtypes = [C.c_void_p, C.c_void_p]
+    L.s2do_reset.restype = None
+    L.s2do_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.s2do_step.restype = None
+    L.s2do_rollout.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    L.s2do_rollout.restype = None
+    L.s2do_get_state.argtypes = [C.c_void_p, C.c_int, dp]
+    L.s2do_get_state.restype = C.c_int
+    L.s2do_set_env.argtypes = [C.c_void_p, C.c_int64, dp]
+    L.s2do_set_env.restype = C.c_int
+    for n, t in (('s2do_obs', real), ('s2do_terminal_obs', real), ('s2do_reward', real),
+                 ('s2do_action_dir', real), ('s2do_done', C.c_uint8), ('s2do_result', C.c_uint8),
+                 ('s2do_action_cmd', C.c_uint8), ('s2do_stats', C.c_ulonglong)):
+        getattr(L, n).argtypes = [C.c_void_p]
+        getattr(L, n).restype = C.POINTER(t)
+    L._real = real
+    L._np_real = np.float32 if precision == 'f32' else np.float64
+    _libs[precision] = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def philox(ctr, key):
+    L = lib('f32')
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    L.s2do_philox4x32_10(c, k, o)
+    return list(o)
+
+
+def sincos_deg(deg, precision='f32'):
+    s, c = C.c_double(), C.c_double()
+    lib(precision).s2do_sincos_deg(float(deg), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def atan2_deg(y, x, precision='f32'):
+    return lib(precision).s2do_atan2_deg(float(y), float(x))
+
+
+def exp(x, precision='f32'):
+    return lib(precision).s2do_exp(float(x))
+
+
+def action_map(cfg, a, u=0.0, precision='f64'):
+    a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+    if a.size < 4:
+        a = np.concatenate([a, np.zeros(4 - a.size)])
+    cmd, power, d = C.c_int(), C.c_double(), C.c_double()
+    lib(precision).s2do_action_map(C.byref(cfg), _dp(a), float(u), C.byref(cmd), C.byref(power), C.byref(d))
+    return cmd.value, power.value, d.value
+
+
+def observation(cfg, in7, precision='f64'):
+    a = np.asarray(in7, dtype=np.float64)
+    o = np.zeros(10)
+    lib(precision).s2do_observation(C.byref(cfg), _dp(a), _dp(o))
+    return o
+
+
+def check_trainer(cfg, in5, step_number, carry, precision='f64'):
+    """carry = [dist, angle] (mutated list). Returns (done, reward, result)."""
+    a = np.asarray(in5, dtype=np.float64)
+    cd, ca = C.c_double(carry[0]), C.c_double(carry[1])
+    done, res, rw = C.c_int(), C.c_int(), C.c_double()
+    lib(precision).s2do_check_trainer(C.byref(cfg), _dp(a), int(step_number), C.byref(cd), C.byref(ca),
+                                      C.byref(done), C.byref(rw), C.byref(res))
+    carry[0], carry[1] = cd.value, ca.value
+    return bool(done.value), rw.value, res.value
+
+
+def reset_from_draws(cfg, draws, precision='f64'):
+    d = np.asarray(draws, dtype=np.float64)
+    out = np.zeros(7)
+    used = C.c_int()
+    rc = lib(precision).s2do_reset_from_draws(C.byref(cfg), _dp(d), len(d), _dp(out), C.byref(used))
+    return rc, out, used.value
+
+
+STATE_FIELDS = _capi.STATE_FIELDS
+
+
+class OracleEngine:
+    """Vectorised CPU engine with the same semantics as the s2d_* C ABI."""
+
+    def __init__(self, cfg, n, precision='f32'):
+        self.L = lib(precision)
+        self.cfg = cfg
+        self.n = int(n)
+        self.precision = precision
+        self.h = self.L.s2do_create(C.byref(cfg), self.n)
+        if not self.h:
+            raise RuntimeError('s2do_create failed')
+
+    def close(self):
+        if self.h:
+            self.L.s2do_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, mask=None):
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            self.L.s2do_reset(self.h, mask.ctypes.data)
+        else:
+            self.L.s2do_reset(self.h, None)
+        return self.obs()
+
+    @staticmethod
+    def _kind_and_array(actions, cfg):
+        if actions is None:
+            return _capi.ACT_RANDOM, None
+        a = np.asarray(actions)
+        if not cfg.task.use_continuous_action:
+            if a.dtype == np.int64:
+                return _capi.ACT_DISCRETE_I64, np.ascontiguousarray(a)
+            return _capi.ACT_DISCRETE_I32, np.ascontiguousarray(a, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return (_capi.ACT_TURNING if cfg.task.use_turning else _capi.ACT_CONTINUOUS), a
+
+    def step(self, actions=None):
+        kind, a = self._kind_and_array(actions, self.cfg)
+        self.L.s2do_step(self.h, a.ctypes.data if a is not None else None, kind)
+        return self.obs(), self.reward(), self.done(), self.result()
+
+    def rollout(self, T, actions=None):
+        kind, a = self._kind_and_array(actions, self.cfg)
+        n, real = self.n, self.L._np_real
+        obs = np.zeros((T, n, 10), dtype=real)
+        if not self.cfg.task.use_continuous_action:
+            act = np.zeros((T, n), dtype=np.int32)
+        elif self.cfg.task.use_turning:
+            act = np.zeros((T, n, 4), dtype=np.float32)
+        else:
+            act = np.zeros((T, n, 1), dtype=np.float32)
+        rew = np.zeros((T, n), dtype=real)
+        done = np.zeros((T, n), dtype=np.uint8)
+        res = np.zeros((T, n), dtype=np.uint8)
+        self.L.s2do_rollout(self.h, T, a.ctypes.data if a is not None else None, kind,
+                            obs.ctypes.data, act.ctypes.data, rew.ctypes.data, done.ctypes.data, res.ctypes.data)
+        return dict(obs=obs, action=act, reward=rew, done=done, result=res)
+
+    def _arr(self, fn, dtype, shape):
+        p = fn(self.h)
+        return np.ctypeslib.as_array(p, shape=shape).astype(dtype, copy=True)
+
+    def obs(self):
+        return self._arr(self.L.s2do_obs, self.L._np_real, (self.n, 10))
+
+    def terminal_obs(self):
+        return self._arr(self.L.s2do_terminal_obs, self.L._np_real, (self.n, 10))
+
+    def reward(self):
+        return self._arr(self.L.s2do_reward, self.L._np_real, (self.n,))
+
+    def action_dir(self):
+        return self._arr(self.L.s2do_action_dir, self.L._np_real, (self.n,))
+
+    def action_cmd(self):
+        return self._arr(self.L.s2do_action_cmd, np.uint8, (self.n,))
+
+    def done(self):
+        return self._arr(self.L.s2do_done, np.uint8, (self.n,))
+
+    def result(self):
+        return self._arr(self.L.s2do_result, np.uint8, (self.n,))
+
+    def stats(self):
+        return self._arr(self.L.s2do_stats, np.uint64, (8,))
+
+    def state(self, field):
+        idx = STATE_FIELDS.index(field) if isinstance(field, str) else int(field)
+        out = np.zeros(self.n)
+        assert self.L.s2do_get_state(self.h, idx, _dp(out)) == 0
+        if idx >= 15:
+            return out.astype(np.int32)
+        return out.astype(self.L._np_real)
+
+    def set_env(self, i, **kw):
+        cur = [float(self.state(f)[i]) for f in STATE_FIELDS]
+        for k, v in kw.items():
+            cur[STATE_FIELDS.index(k)] = float(v)
+        a = np.asarray(cur, dtype=np.float64)
+        assert self.L.s2do_set_env(self.h, int(i), _dp(a)) == 0
