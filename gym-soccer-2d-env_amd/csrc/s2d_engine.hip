@@ -1,0 +1,666 @@
+// s2d_engine.hip -- kernels and C ABI (include/s2d.h) of the MI355X-native reach_ball engine.
+//
+// Layout in HBM: one arena; the 17 state words of an env live in 17
+// struct-of-arrays planes of `stride` (= N rounded up to 256) 4-byte words, so a wave's 64
+// lanes read/write 256 contiguous bytes per plane.  Observations are emitted row-major
+// [N][10] (what a PyTorch policy consumes): each wave transposes its 64x10 block through a
+// wave-private LDS tile and stores 2560 contiguous bytes with 16-byte-per-lane stores.
+// One thread = one env; there is no cross-env communication, so the only cross-lane work is
+// the LDS transposition and the ballot/popcount reduction of the episode counters.
+// No MFMA: the path has no dense contraction (arithmetic intensity ~0.5 flop/byte).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "s2d_device.h"
+
+#define S2D_API extern "C" __attribute__((visibility("default")))
+
+static constexpr int kBlock = 256;
+static constexpr int kWave = 64;
+static constexpr int kWavesPerBlock = kBlock / kWave;
+static constexpr int kObsTile = kWave * S2D_OBS_DIM;  // 640 floats per wave
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+struct StepOut {
+  float* obs;            // [N][10]
+  float* reward;         // [N]
+  uint8_t* done;         // [N]
+  uint8_t* result;       // [N]
+  float* terminal_obs;   // [N][10]
+  float* action_dir;     // [N]
+  uint8_t* action_cmd;   // [N]
+  unsigned long long* stats;
+};
+
+// LDS ops of one wave execute in order, so a wave-private tile needs no s_barrier; the
+// wavefront-scope fences only stop the compiler from reordering the cross-lane accesses.
+S2D_DEV void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Transpose this wave's [64][10] observation block through LDS and store it as one
+// contiguous run.  `dst` = address of the wave's first row (wave-uniform); `valid` = number
+// of floats of the run that exist (640, or fewer in the last wave).
+S2D_DEV void store_obs_tile(float* tile, const ObsOut& ob, int lane, bool active, float* __restrict__ dst,
+                            int valid) {
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < S2D_OBS_DIM; ++k) tile[lane * S2D_OBS_DIM + k] = ob.o[k];
+  }
+  wave_lds_fence();
+  const bool vec = (valid == kObsTile) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+  if (vec) {
+    const float4* t4 = reinterpret_cast<const float4*>(tile);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    d4[lane] = t4[lane];
+    d4[kWave + lane] = t4[kWave + lane];
+    if (lane < 32) d4[2 * kWave + lane] = t4[2 * kWave + lane];
+  } else {
+#pragma unroll
+    for (int j = 0; j < S2D_OBS_DIM; ++j) {
+      int idx = j * kWave + lane;
+      if (idx < valid) dst[idx] = tile[idx];
+    }
+  }
+  wave_lds_fence();
+}
+
+// episode counters: one popcount of a 64-lane ballot per label, one atomic per wave
+S2D_DEV void wave_count_results(int res, bool active, int lane, unsigned long long* stats) {
+#pragma unroll
+  for (int r = S2D_RESULT_GOAL; r <= S2D_RESULT_TIMEOUT; ++r) {
+    unsigned long long m = __ballot(active && res == r);
+    if (m != 0ull && lane == 0) atomicAdd(&stats[r], (unsigned long long)__popcll(m));
+  }
+}
+
+struct Action4 { float a0, a1, a2, a3; };
+
+// caller-provided action of env i at rollout step t (layouts of include/s2d.h), or the
+// in-kernel uniform random policy (Philox POLICY stream at (gid, cycle))
+S2D_DEV Action4 fetch_action(const S2DDevParams& p, const void* __restrict__ actions, int kind, int64_t idx,
+                             uint32_t gid_lo, uint32_t gid_hi, uint32_t cycle) {
+  Action4 a{0.0f, 0.0f, 0.0f, 0.0f};
+  switch (kind) {
+    case S2D_ACT_DISCRETE_I32: a.a0 = (float)static_cast<const int32_t*>(actions)[idx]; break;
+    case S2D_ACT_DISCRETE_I64: a.a0 = (float)static_cast<const long long*>(actions)[idx]; break;
+    case S2D_ACT_CONTINUOUS: a.a0 = static_cast<const float*>(actions)[idx]; break;
+    case S2D_ACT_TURNING: {
+      float4 v = static_cast<const float4*>(actions)[idx];
+      a.a0 = v.x; a.a1 = v.y; a.a2 = v.z; a.a3 = v.w;
+      break;
+    }
+    default: {
+      U4 w = s2d_draw(p, gid_lo, gid_hi, cycle, S2D_ST_POLICY, 0);
+      if (!p.use_continuous) a.a0 = (float)rnd_below(w.x, (uint32_t)p.n_actions);
+      else if (!p.use_turning) a.a0 = rnd_u01(w.x) * 2.0f - 1.0f;
+      else {
+        a.a0 = rnd_u01(w.x) * 2.0f - 1.0f; a.a1 = rnd_u01(w.y) * 2.0f - 1.0f;
+        a.a2 = rnd_u01(w.z) * 2.0f - 1.0f; a.a3 = rnd_u01(w.w) * 2.0f - 1.0f;
+      }
+    }
+  }
+  return a;
+}
+
+// A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269) for the env held in registers.
+// Returns the observation to hand back (post auto-reset), reward/done/result of the step.
+S2D_DEV void step_env(const S2DDevParams& p, Env& e, uint32_t gid_lo, uint32_t gid_hi, const Action4& a,
+                      ObsOut& ob, float& reward, int& done, int& result, int& cmd, float& dir,
+                      float* __restrict__ terminal_row) {
+  e.step_number += 1;                                    // reach_ball_env.py:55
+  float u = 0.0f;
+  if (p.use_continuous && p.use_turning)
+    u = rnd_u01(s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_SELECT, 0).x);
+  float power;
+  action_map(p, a.a0, a.a1, a.a2, a.a3, u, cmd, power, dir);
+  sim_cycle(p, e, gid_lo, gid_hi, cmd, power, dir);      // trainer forces PlayOn each cycle (:242)
+  observe_and_check(p, e, ob, done, reward, result);
+  if (done && p.auto_reset) {                            // SB3 VecEnv convention
+    if (terminal_row) {
+#pragma unroll
+      for (int k = 0; k < S2D_OBS_DIM; ++k) terminal_row[k] = ob.o[k];
+    }
+    env_reset(p, e, gid_lo, gid_hi);
+    int d2, r2; float w2;
+    observe_and_check(p, e, ob, d2, w2, r2);             // reach_ball_env.py:166: carry seeded, outputs dropped
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void s2d_init_kernel(S2DDevParams p, float* __restrict__ S, int64_t stride,
+                                                          int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  S[F_STAMINA * stride + i] = p.stamina_max;             // state after a trainer (recover)
+  S[F_RECOVERY * stride + i] = p.recover_init;
+  S[F_EFFORT * stride + i] = p.effort_init;
+  S[F_CAPACITY * stride + i] = p.stamina_capacity;
+}
+
+__global__ __launch_bounds__(kBlock) void s2d_reach_reset_kernel(S2DDevParams p, float* __restrict__ S,
+                                                                 int64_t stride, int64_t n,
+                                                                 const uint8_t* __restrict__ mask, StepOut o) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t wave_first = i - lane;
+  const bool in_range = i < n;
+  const bool active = in_range && (mask == nullptr || mask[i] != 0);
+  const bool any = __ballot(active) != 0ull;
+  if (!any) return;                                      // wave-uniform
+  ObsOut ob;
+  if (in_range) {
+    Env e;
+    env_load(e, S, stride, i);
+    if (active) {
+      uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
+      env_reset(p, e, (uint32_t)gid, (uint32_t)(gid >> 32));
+      int d, r; float w;
+      observe_and_check(p, e, ob, d, w, r);
+      env_store(e, S, stride, i);
+      o.reward[i] = 0.0f; o.done[i] = 0; o.result[i] = 0;
+    } else {                                             // keep the row this env already has
+#pragma unroll
+      for (int k = 0; k < S2D_OBS_DIM; ++k) ob.o[k] = o.obs[i * S2D_OBS_DIM + k];
+    }
+  }
+  int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
+  store_obs_tile(lds[wv], ob, lane, in_range, o.obs + wave_first * S2D_OBS_DIM, (int)rows * S2D_OBS_DIM);
+}
+
+__global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DDevParams p, float* __restrict__ S,
+                                                                int64_t stride, int64_t n,
+                                                                const void* __restrict__ actions, int kind,
+                                                                StepOut o) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t wave_first = i - lane;
+  if (wave_first >= n) return;                           // wave-uniform
+  const bool active = i < n;
+  ObsOut ob;
+  int res = 0;
+  if (active) {
+    Env e;
+    env_load(e, S, stride, i);
+    uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
+    uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
+    Action4 a = fetch_action(p, actions, kind, i, gl, gh, (uint32_t)e.cycle);
+    float reward, dir; int done, cmd;
+    step_env(p, e, gl, gh, a, ob, reward, done, res, cmd, dir, o.terminal_obs + i * S2D_OBS_DIM);
+    env_store(e, S, stride, i);
+    o.reward[i] = reward;
+    o.done[i] = (uint8_t)done;
+    o.result[i] = (uint8_t)res;
+    o.action_dir[i] = dir;
+    o.action_cmd[i] = (uint8_t)cmd;
+  }
+  int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
+  store_obs_tile(lds[wv], ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, (int)rows * S2D_OBS_DIM);
+  wave_count_results(res, active, lane, o.stats);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&o.stats[0], (unsigned long long)n);
+}
+
+// T fused cycles per launch: the 17 state words stay in registers, only the rollout record
+// (obs 40 B + action 4 B + reward 4 B + done 1 B + result 1 B per env-step) streams out.
+struct RolloutOut {
+  float* obs; void* action; float* reward; uint8_t* done; uint8_t* result;
+};
+
+__global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DDevParams p, float* __restrict__ S,
+                                                                   int64_t stride, int64_t n, int n_steps,
+                                                                   const void* __restrict__ actions, int kind,
+                                                                   RolloutOut ro, StepOut o) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t wave_first = i - lane;
+  if (wave_first >= n) return;
+  const bool active = i < n;
+  int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
+  const int valid = (int)rows * S2D_OBS_DIM;
+  Env e;
+  uint32_t gl = 0, gh = 0;
+  if (active) {
+    env_load(e, S, stride, i);
+    uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
+    gl = (uint32_t)gid; gh = (uint32_t)(gid >> 32);
+  }
+  ObsOut ob;
+  float reward = 0.0f, dir = 0.0f; int done = 0, res = 0, cmd = 0;
+  unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
+  for (int t = 0; t < n_steps; ++t) {
+    const int64_t row = (int64_t)t * n;
+    res = 0;
+    if (active) {
+      Action4 a = fetch_action(p, actions, kind, row + i, gl, gh, (uint32_t)e.cycle);
+      if (ro.action) {
+        if (!p.use_continuous) static_cast<int32_t*>(ro.action)[row + i] = (int32_t)a.a0;
+        else if (!p.use_turning) static_cast<float*>(ro.action)[row + i] = a.a0;
+        else static_cast<float4*>(ro.action)[row + i] = make_float4(a.a0, a.a1, a.a2, a.a3);
+      }
+      step_env(p, e, gl, gh, a, ob, reward, done, res, cmd, dir, o.terminal_obs + i * S2D_OBS_DIM);
+      if (ro.reward) ro.reward[row + i] = reward;
+      if (ro.done) ro.done[row + i] = (uint8_t)done;
+      if (ro.result) ro.result[row + i] = (uint8_t)res;
+      cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
+    }
+    if (ro.obs) store_obs_tile(lds[wv], ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
+  }
+  if (active) {
+    env_store(e, S, stride, i);
+    o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
+    o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
+  }
+  store_obs_tile(lds[wv], ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, valid);
+  // wave-level reduction of the per-lane episode counters (shuffle tree), one atomic per wave
+  if (!active) { cnt1 = cnt2 = cnt3 = 0; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt1 += __shfl_down(cnt1, off); cnt2 += __shfl_down(cnt2, off); cnt3 += __shfl_down(cnt3, off);
+  }
+  if (lane == 0) {
+    if (cnt1) atomicAdd(&o.stats[1], (unsigned long long)cnt1);
+    if (cnt2) atomicAdd(&o.stats[2], (unsigned long long)cnt2);
+    if (cnt3) atomicAdd(&o.stats[3], (unsigned long long)cnt3);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&o.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
+}
+
+// derived protobuf-mirroring fields (row T1; idl/service.proto:22-27, 68-86, 181-223)
+__global__ __launch_bounds__(kBlock) void s2d_world_model_kernel(const float* __restrict__ S, int64_t stride,
+                                                                 int64_t n, S2DWorldModel w) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float px = S[F_PX * stride + i], py = S[F_PY * stride + i], vx = S[F_VX * stride + i], vy = S[F_VY * stride + i];
+  float body = S[F_BODY * stride + i];
+  float bx = S[F_BX * stride + i], by = S[F_BY * stride + i], bvx = S[F_BVX * stride + i], bvy = S[F_BVY * stride + i];
+  float dx = bx - px, dy = by - py;
+  float dist = hypot2(dx, dy), ang = atan2_deg(dy, dx);
+  if (w.ball_dist_from_self) w.ball_dist_from_self[i] = dist;
+  if (w.ball_angle_from_self) w.ball_angle_from_self[i] = ang;
+  if (w.ball_relative_x) w.ball_relative_x[i] = dx;
+  if (w.ball_relative_y) w.ball_relative_y[i] = dy;
+  if (w.ball_pos_dist) w.ball_pos_dist[i] = hypot2(bx, by);
+  if (w.ball_pos_angle) w.ball_pos_angle[i] = atan2_deg(by, bx);
+  if (w.ball_vel_dist) w.ball_vel_dist[i] = hypot2(bvx, bvy);
+  if (w.ball_vel_angle) w.ball_vel_angle[i] = atan2_deg(bvy, bvx);
+  if (w.self_pos_dist) w.self_pos_dist[i] = hypot2(px, py);
+  if (w.self_pos_angle) w.self_pos_angle[i] = atan2_deg(py, px);
+  if (w.self_vel_dist) w.self_vel_dist[i] = hypot2(vx, vy);
+  if (w.self_vel_angle) w.self_vel_angle[i] = atan2_deg(vy, vx);
+  if (w.self_dist_from_ball) w.self_dist_from_ball[i] = dist;
+  if (w.self_angle_from_ball) w.self_angle_from_ball[i] = atan2_deg(-dy, -dx);
+  (void)body;
+}
+
+// diagnostic: evaluate the math spec / Philox on the device (tests compare with the oracle)
+__global__ void s2d_debug_eval_kernel(int op, const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (op) {
+    case 0: { float s, c; sincos_deg(in[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break; }
+    case 1: out[i] = atan2_deg(in[2 * i], in[2 * i + 1]); break;
+    case 2: out[i] = exp_spec(in[i]); break;
+    case 3: out[i] = norm_deg(in[i]); break;
+    case 4: {
+      const uint32_t* u = reinterpret_cast<const uint32_t*>(in) + 6 * i;
+      U4 r = philox4x32_10(u[0], u[1], u[2], u[3], u[4], u[5]);
+      uint32_t* q = reinterpret_cast<uint32_t*>(out) + 4 * i;
+      q[0] = r.x; q[1] = r.y; q[2] = r.z; q[3] = r.w;
+      break;
+    }
+    case 5: out[i] = hypot2(in[2 * i], in[2 * i + 1]); break;
+    default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: engine object + C ABI
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return fail(S2D_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+  } while (0)
+
+struct S2DEngine {
+  S2DConfig cfg;
+  S2DDevParams dp;
+  int64_t n, stride;
+  int device;
+  char* arena;
+  size_t arena_bytes;
+  bool owns_arena;
+  S2DBuffers buf;
+  StepOut out;
+  const char* last_kernel;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static int64_t stride_for(int64_t n) { return (int64_t)align_up((size_t)n, 256); }
+
+struct ArenaLayout {
+  size_t state, obs, reward, done, result, terminal_obs, action_dir, action_cmd, stats, total;
+};
+static ArenaLayout layout_for(int64_t n) {
+  ArenaLayout L;
+  size_t s = (size_t)stride_for(n), off = 0;
+  L.state = off; off += align_up((size_t)F_COUNT * s * 4, 256);
+  L.obs = off; off += align_up(s * S2D_OBS_DIM * 4, 256);
+  L.reward = off; off += align_up(s * 4, 256);
+  L.done = off; off += align_up(s, 256);
+  L.result = off; off += align_up(s, 256);
+  L.terminal_obs = off; off += align_up(s * S2D_OBS_DIM * 4, 256);
+  L.action_dir = off; off += align_up(s * 4, 256);
+  L.action_cmd = off; off += align_up(s, 256);
+  L.stats = off; off += 256;
+  L.total = off;
+  return L;
+}
+
+S2D_API const char* s2d_version(void) { return "s2d-hip 0.1 (gfx950, abi 1)"; }
+S2D_API const char* s2d_last_error(void) { return g_err.c_str(); }
+
+S2D_API void s2d_default_config(S2DConfig* c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof *c);
+  c->abi_version = S2D_ABI_VERSION;
+  c->struct_bytes = (uint32_t)sizeof(S2DConfig);
+  S2DServerParams& s = c->sp;  // rcssserver stock values (EXT)
+  s.pitch_half_length = 52.5; s.pitch_half_width = 34.0;
+  s.player_size = 0.3; s.player_decay = 0.4; s.player_rand = 0.1; s.player_speed_max = 1.05;
+  s.player_accel_max = 1.0; s.inertia_moment = 5.0;
+  s.stamina_max = 8000.0; s.stamina_inc_max = 45.0; s.stamina_capacity = 130600.0; s.extra_stamina = 50.0;
+  s.recover_init = 1.0; s.recover_dec_thr = 0.3; s.recover_min = 0.5; s.recover_dec = 0.002;
+  s.effort_init = 1.0; s.effort_dec_thr = 0.3; s.effort_min = 0.6; s.effort_dec = 0.005;
+  s.effort_inc_thr = 0.6; s.effort_inc = 0.01;
+  s.dash_power_rate = 0.006; s.max_dash_power = 100.0; s.min_dash_power = 0.0;
+  s.max_dash_angle = 180.0; s.min_dash_angle = -180.0; s.dash_angle_step = 1.0;
+  s.side_dash_rate = 0.4; s.back_dash_rate = 0.6;
+  s.max_moment = 180.0; s.min_moment = -180.0;
+  s.ball_size = 0.085; s.ball_decay = 0.94; s.ball_rand = 0.05; s.ball_speed_max = 3.0; s.ball_accel_max = 2.7;
+  s.collision_vel_rate = -0.1;
+  S2DReachBallParams& t = c->task;  // reach_ball_env.py:26-36
+  t.change_ball_position = 1; t.change_ball_velocity = 0;
+  t.ball_position_x = 0; t.ball_position_y = 0; t.ball_speed = 0; t.ball_direction = 0;
+  t.min_distance_to_ball = 5.0; t.max_steps = 200;
+  t.use_continuous_action = 1; t.action_space_size = 16; t.use_turning = 0;
+  t.reset_ball_decay = 0.96;   // reach_ball_env.py:207
+  c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
+}
+
+S2D_API int s2d_validate_config(const S2DConfig* c) {
+  if (!c) return fail(S2D_EINVAL, "config is NULL");
+  if (c->abi_version != S2D_ABI_VERSION) return fail(S2D_EINVAL, "config.abi_version mismatch");
+  if (c->struct_bytes != sizeof(S2DConfig)) return fail(S2D_EINVAL, "config.struct_bytes != sizeof(S2DConfig)");
+  const S2DServerParams& s = c->sp;
+  const S2DReachBallParams& t = c->task;
+  if (!(s.pitch_half_length > 0) || !(s.pitch_half_width > 0)) return fail(S2D_EINVAL, "pitch extents must be > 0");
+  if (!(s.player_decay >= 0 && s.player_decay <= 1) || !(s.ball_decay >= 0 && s.ball_decay <= 1))
+    return fail(S2D_EINVAL, "decay must be in [0,1]");
+  if (!(s.stamina_max > 0)) return fail(S2D_EINVAL, "stamina_max must be > 0");
+  if (!(s.dash_angle_step >= 0)) return fail(S2D_EINVAL, "dash_angle_step must be >= 0");
+  if (!t.use_continuous_action && (t.action_space_size < 1 || t.action_space_size > (1 << 20)))
+    return fail(S2D_EINVAL, "action_space_size must be in [1, 2^20]");
+  if (t.max_steps < 0) return fail(S2D_EINVAL, "max_steps must be >= 0");
+  if (!(t.reset_ball_decay > 0 && t.reset_ball_decay < 1)) return fail(S2D_EINVAL, "reset_ball_decay must be in (0,1)");
+  if (c->env_id_offset < 0) return fail(S2D_EINVAL, "env_id_offset must be >= 0");
+  return S2D_OK;
+}
+
+static void dev_params_from_config(const S2DConfig& c, S2DDevParams& p) {
+  const S2DServerParams& s = c.sp;
+  const S2DReachBallParams& t = c.task;
+  std::memset(&p, 0, sizeof p);
+  p.half_l = (float)s.pitch_half_length; p.half_w = (float)s.pitch_half_width;
+  p.player_size = (float)s.player_size; p.player_decay = (float)s.player_decay;
+  p.player_rand = (float)s.player_rand; p.player_speed_max = (float)s.player_speed_max;
+  p.player_accel_max = (float)s.player_accel_max; p.inertia_moment = (float)s.inertia_moment;
+  p.stamina_max = (float)s.stamina_max; p.stamina_inc_max = (float)s.stamina_inc_max;
+  p.stamina_capacity = (float)s.stamina_capacity; p.extra_stamina = (float)s.extra_stamina;
+  p.recover_init = (float)s.recover_init;
+  p.recover_dec_thr_value = (float)(s.recover_dec_thr * s.stamina_max);
+  p.recover_min = (float)s.recover_min; p.recover_dec = (float)s.recover_dec;
+  p.effort_init = (float)s.effort_init;
+  p.effort_dec_thr_value = (float)(s.effort_dec_thr * s.stamina_max);
+  p.effort_min = (float)s.effort_min; p.effort_dec = (float)s.effort_dec;
+  p.effort_inc_thr_value = (float)(s.effort_inc_thr * s.stamina_max);
+  p.effort_inc = (float)s.effort_inc;
+  p.dash_power_rate = (float)s.dash_power_rate; p.max_dash_power = (float)s.max_dash_power;
+  p.min_dash_power = (float)s.min_dash_power; p.max_dash_angle = (float)s.max_dash_angle;
+  p.min_dash_angle = (float)s.min_dash_angle; p.dash_angle_step = (float)s.dash_angle_step;
+  p.side_dash_rate = (float)s.side_dash_rate; p.back_dash_rate = (float)s.back_dash_rate;
+  p.max_moment = (float)s.max_moment; p.min_moment = (float)s.min_moment;
+  p.ball_size = (float)s.ball_size; p.ball_decay = (float)s.ball_decay;
+  p.ball_rand = (float)s.ball_rand; p.ball_speed_max = (float)s.ball_speed_max;
+  p.collision_vel_rate = (float)s.collision_vel_rate;
+  p.ball_position_x = (float)t.ball_position_x; p.ball_position_y = (float)t.ball_position_y;
+  p.ball_speed = (float)t.ball_speed; p.ball_direction = (float)t.ball_direction;
+  p.min_distance_to_ball = (float)t.min_distance_to_ball;
+  p.travel_factor = (float)((1.0 - std::pow(t.reset_ball_decay, (double)t.max_steps)) / (1.0 - t.reset_ball_decay));
+  p.change_ball_position = t.change_ball_position; p.change_ball_velocity = t.change_ball_velocity;
+  p.max_steps = t.max_steps; p.use_continuous = t.use_continuous_action;
+  p.n_actions = t.action_space_size; p.use_turning = t.use_turning;
+  p.auto_reset = c.auto_reset; p.noise = c.noise;
+  p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
+  p.gid_lo = (uint32_t)(uint64_t)c.env_id_offset; p.gid_hi = (uint32_t)((uint64_t)c.env_id_offset >> 32);
+}
+
+S2D_API size_t s2d_arena_bytes(const S2DConfig* cfg, int64_t n_envs) {
+  if (!cfg || n_envs <= 0) return 0;
+  return layout_for(n_envs).total;
+}
+
+struct DeviceGuard {
+  int prev = -1; bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess) { ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess); }
+  }
+  ~DeviceGuard() { if (ok && prev >= 0) (void)hipSetDevice(prev); }
+};
+
+static int grid_for(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+S2D_API int s2d_create(const S2DConfig* cfg, int64_t n_envs, int device, void* arena_dev, size_t arena_bytes,
+                       void* stream, S2DHandle* out) {
+  if (!out) return fail(S2D_EINVAL, "out handle is NULL");
+  *out = nullptr;
+  int rc = s2d_validate_config(cfg);
+  if (rc != S2D_OK) return rc;
+  if (n_envs <= 0 || n_envs > (int64_t)1 << 31) return fail(S2D_EINVAL, "n_envs must be in [1, 2^31]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(S2D_ENODEV, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(S2D_EINVAL, "device index out of range");
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(S2D_EHIP, "hipSetDevice failed");
+  ArenaLayout L = layout_for(n_envs);
+  S2DEngine* h = new (std::nothrow) S2DEngine();
+  if (!h) return fail(S2D_ENOMEM, "host allocation failed");
+  h->cfg = *cfg; h->n = n_envs; h->stride = stride_for(n_envs); h->device = device;
+  h->last_kernel = "";
+  dev_params_from_config(*cfg, h->dp);
+  if (arena_dev) {
+    if (arena_bytes < L.total) { delete h; return fail(S2D_ENOMEM, "arena smaller than s2d_arena_bytes()"); }
+    if (reinterpret_cast<uintptr_t>(arena_dev) & 255u) { delete h; return fail(S2D_EINVAL, "arena must be 256-byte aligned"); }
+    h->arena = static_cast<char*>(arena_dev); h->owns_arena = false;
+  } else {
+    void* p = nullptr;
+    if (hipMalloc(&p, L.total) != hipSuccess) { delete h; return fail(S2D_ENOMEM, "hipMalloc of the arena failed"); }
+    h->arena = static_cast<char*>(p); h->owns_arena = true;
+  }
+  h->arena_bytes = L.total;
+  S2DBuffers& b = h->buf;
+  b.n_envs = n_envs;
+  float* S = reinterpret_cast<float*>(h->arena + L.state);
+  float** planes[15] = {&b.player_x, &b.player_y, &b.player_vx, &b.player_vy, &b.player_body, &b.stamina,
+                        &b.effort, &b.recovery, &b.stamina_capacity, &b.ball_x, &b.ball_y, &b.ball_vx,
+                        &b.ball_vy, &b.prev_dist, &b.prev_angle};
+  for (int f = 0; f < 15; ++f) *planes[f] = S + (size_t)f * h->stride;
+  b.step_number = reinterpret_cast<int32_t*>(S + (size_t)F_STEP * h->stride);
+  b.cycle = reinterpret_cast<int32_t*>(S + (size_t)F_CYCLE * h->stride);
+  b.obs = reinterpret_cast<float*>(h->arena + L.obs);
+  b.reward = reinterpret_cast<float*>(h->arena + L.reward);
+  b.done = reinterpret_cast<uint8_t*>(h->arena + L.done);
+  b.result = reinterpret_cast<uint8_t*>(h->arena + L.result);
+  b.terminal_obs = reinterpret_cast<float*>(h->arena + L.terminal_obs);
+  b.action_dir = reinterpret_cast<float*>(h->arena + L.action_dir);
+  b.action_cmd = reinterpret_cast<uint8_t*>(h->arena + L.action_cmd);
+  b.stats = reinterpret_cast<unsigned long long*>(h->arena + L.stats);
+  h->out = StepOut{b.obs, b.reward, b.done, b.result, b.terminal_obs, b.action_dir, b.action_cmd, b.stats};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(h->arena, 0, L.total, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(s2d_init_kernel, dim3(grid_for(n_envs)), dim3(kBlock), 0, st, h->dp, S, h->stride, h->n);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) {
+    std::string m = std::string("arena initialisation: ") + hipGetErrorString(e);
+    if (h->owns_arena) (void)hipFree(h->arena);
+    delete h;
+    return fail(S2D_EHIP, m);
+  }
+  *out = h;
+  return S2D_OK;
+}
+
+S2D_API void s2d_destroy(S2DHandle h) {
+  if (!h) return;
+  if (h->owns_arena && h->arena) {
+    DeviceGuard guard(h->device);
+    (void)hipFree(h->arena);
+  }
+  delete h;
+}
+
+S2D_API int s2d_buffers(S2DHandle h, S2DBuffers* out) {
+  if (!h || !out) return fail(S2D_EINVAL, "NULL argument");
+  *out = h->buf;
+  return S2D_OK;
+}
+
+S2D_API int s2d_buffer_offsets(S2DHandle h, int64_t* offsets, int n_offsets) {
+  if (!h || !offsets) return fail(S2D_EINVAL, "NULL argument");
+  const void* ptrs[] = {h->buf.player_x, h->buf.player_y, h->buf.player_vx, h->buf.player_vy, h->buf.player_body,
+                        h->buf.stamina, h->buf.effort, h->buf.recovery, h->buf.stamina_capacity, h->buf.ball_x,
+                        h->buf.ball_y, h->buf.ball_vx, h->buf.ball_vy, h->buf.prev_dist, h->buf.prev_angle,
+                        h->buf.step_number, h->buf.cycle, h->buf.obs, h->buf.reward, h->buf.done, h->buf.result,
+                        h->buf.terminal_obs, h->buf.action_dir, h->buf.action_cmd, h->buf.stats};
+  const int count = 1 + (int)(sizeof ptrs / sizeof ptrs[0]);
+  if (n_offsets < count) return fail(S2D_EINVAL, "offsets array too small (need 26)");
+  offsets[0] = (int64_t)h->arena_bytes;
+  for (int k = 1; k < count; ++k) offsets[k] = (int64_t)(static_cast<const char*>(ptrs[k - 1]) - h->arena);
+  return S2D_OK;
+}
+
+static int check_action_kind(const S2DEngine* h, const void* actions, int kind) {
+  const S2DReachBallParams& t = h->cfg.task;
+  switch (kind) {
+    case S2D_ACT_DISCRETE_I32:
+    case S2D_ACT_DISCRETE_I64:
+      if (t.use_continuous_action) return fail(S2D_EINVAL, "discrete actions given to a continuous-action env");
+      break;
+    case S2D_ACT_CONTINUOUS:
+      if (!t.use_continuous_action || t.use_turning) return fail(S2D_EINVAL, "float[N][1] actions need use_continuous_action && !use_turning");
+      break;
+    case S2D_ACT_TURNING:
+      if (!t.use_continuous_action || !t.use_turning) return fail(S2D_EINVAL, "float[N][4] actions need use_continuous_action && use_turning");
+      if (reinterpret_cast<uintptr_t>(actions) & 15u) return fail(S2D_EINVAL, "float[N][4] actions must be 16-byte aligned");
+      break;
+    case S2D_ACT_RANDOM:
+      return S2D_OK;
+    default:
+      return fail(S2D_EINVAL, "unknown action_kind");
+  }
+  if (!actions) return fail(S2D_EINVAL, "actions pointer is NULL");
+  return S2D_OK;
+}
+
+S2D_API int s2d_reset(S2DHandle h, const uint8_t* mask_dev, void* stream) {
+  if (!h) return fail(S2D_EINVAL, "NULL handle");
+  DeviceGuard guard(h->device);
+  hipLaunchKernelGGL(s2d_reach_reset_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     h->dp, reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, mask_dev, h->out);
+  HIP_TRY(hipGetLastError());
+  h->last_kernel = "s2d_reach_reset_kernel";
+  return S2D_OK;
+}
+
+S2D_API int s2d_step(S2DHandle h, const void* actions_dev, int action_kind, void* stream) {
+  if (!h) return fail(S2D_EINVAL, "NULL handle");
+  int rc = check_action_kind(h, actions_dev, action_kind);
+  if (rc != S2D_OK) return rc;
+  DeviceGuard guard(h->device);
+  hipLaunchKernelGGL(s2d_reach_step_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     h->dp, reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, actions_dev, action_kind,
+                     h->out);
+  HIP_TRY(hipGetLastError());
+  h->last_kernel = "s2d_reach_step_kernel";
+  return S2D_OK;
+}
+
+S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int action_kind, const S2DRollout* out,
+                        void* stream) {
+  if (!h) return fail(S2D_EINVAL, "NULL handle");
+  if (n_steps < 0) return fail(S2D_EINVAL, "n_steps must be >= 0");
+  int rc = check_action_kind(h, actions_dev, action_kind);
+  if (rc != S2D_OK) return rc;
+  if (n_steps == 0) return S2D_OK;
+  RolloutOut ro{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (out) {
+    ro = RolloutOut{out->obs, out->action, out->reward, out->done, out->result};
+    if (h->cfg.task.use_continuous_action && h->cfg.task.use_turning && (reinterpret_cast<uintptr_t>(out->action) & 15u))
+      return fail(S2D_EINVAL, "rollout action buffer float[T][N][4] must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(out->obs) & 3u) return fail(S2D_EINVAL, "rollout obs buffer must be 4-byte aligned");
+  }
+  DeviceGuard guard(h->device);
+  hipLaunchKernelGGL(s2d_reach_rollout_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), h->dp, reinterpret_cast<float*>(h->buf.player_x), h->stride,
+                     h->n, n_steps, actions_dev, action_kind, ro, h->out);
+  HIP_TRY(hipGetLastError());
+  h->last_kernel = "s2d_reach_rollout_kernel";
+  return S2D_OK;
+}
+
+S2D_API int s2d_world_model(S2DHandle h, const S2DWorldModel* out, void* stream) {
+  if (!h || !out) return fail(S2D_EINVAL, "NULL argument");
+  DeviceGuard guard(h->device);
+  hipLaunchKernelGGL(s2d_world_model_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float*>(h->buf.player_x), h->stride, h->n, *out);
+  HIP_TRY(hipGetLastError());
+  h->last_kernel = "s2d_world_model_kernel";
+  return S2D_OK;
+}
+
+S2D_API int s2d_stats_reset(S2DHandle h, void* stream) {
+  if (!h) return fail(S2D_EINVAL, "NULL handle");
+  DeviceGuard guard(h->device);
+  HIP_TRY(hipMemsetAsync(h->buf.stats, 0, 8 * sizeof(unsigned long long), static_cast<hipStream_t>(stream)));
+  return S2D_OK;
+}
+
+S2D_API const char* s2d_kernel_name(S2DHandle h) { return h ? h->last_kernel : ""; }
+
+S2D_API int s2d_debug_eval(int op, const void* in_dev, void* out_dev, int64_t n, void* stream) {
+  if (!in_dev || !out_dev || n <= 0 || op < 0 || op > 5) return fail(S2D_EINVAL, "bad s2d_debug_eval argument");
+  hipLaunchKernelGGL(s2d_debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), op, static_cast<const float*>(in_dev),
+                     static_cast<float*>(out_dev), n);
+  HIP_TRY(hipGetLastError());
+  return S2D_OK;
+}

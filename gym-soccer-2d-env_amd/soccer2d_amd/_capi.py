@@ -125,6 +125,7 @@ PROTOTYPES = (
     ('s2d_world_model', C.c_int, (C.c_void_p, C.POINTER(S2DWorldModel), C.c_void_p)),
     ('s2d_stats_reset', C.c_int, (C.c_void_p, C.c_void_p)),
     ('s2d_kernel_name', C.c_char_p, (C.c_void_p,)),
+    ('s2d_debug_eval', C.c_int, (C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)),
 )
 
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

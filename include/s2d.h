@@ -203,6 +203,11 @@ int s2d_world_model(S2DHandle h, const S2DWorldModel *out, void *stream);
 int s2d_stats_reset(S2DHandle h, void *stream);
 /* name of the most recently launched kernel variant (for profiling reports) */
 const char *s2d_kernel_name(S2DHandle h);
+/* diagnostic: evaluate one primitive of the fp32 math spec / Philox on the device so that
+ * tests can compare it bit for bit with the CPU oracle.  op: 0 sincos_deg (in[n] -> out[n][2]),
+ * 1 atan2_deg (in[n][2]=y,x -> out[n]), 2 exp, 3 norm_deg, 4 philox4x32-10 (in = uint32[n][6]
+ * ctr+key -> out = uint32[n][4]), 5 hypot (in[n][2] -> out[n]). */
+int s2d_debug_eval(int op, const void *in_dev, void *out_dev, int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

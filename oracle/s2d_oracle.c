@@ -161,6 +161,7 @@ static REAL norm_deg(REAL d) {
 API void s2do_sincos_deg(double deg, double *s, double *c) { REAL a, b; sincos_deg((REAL)deg, &a, &b); *s = a; *c = b; }
 API double s2do_atan2_deg(double y, double x) { return atan2_deg((REAL)y, (REAL)x); }
 API double s2do_exp(double x) { return exp_r((REAL)x); }
+API double s2do_hypot(double x, double y) { return hypot2((REAL)x, (REAL)y); }
 API double s2do_norm_deg(double d) { return norm_deg((REAL)d); }
 API int s2do_real_bytes(void) { return (int)sizeof(REAL); }
 

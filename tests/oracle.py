@@ -91,7 +91,7 @@ def lib(precision='f32'):
     L.s2do_philox4x32_10.restype = None
     L.s2do_sincos_deg.argtypes = [C.c_double, dp, dp]
     L.s2do_sincos_deg.restype = None
-    for n in ('s2do_atan2_deg',):
+    for n in ('s2do_atan2_deg', 's2do_hypot'):
         getattr(L, n).argtypes = [C.c_double, C.c_double]
         getattr(L, n).restype = C.c_double
     for n in ('s2do_exp', 's2do_norm_deg'):
@@ -152,6 +152,10 @@ def sincos_deg(deg, precision='f32'):
 
 def atan2_deg(y, x, precision='f32'):
     return lib(precision).s2do_atan2_deg(float(y), float(x))
+
+
+def hypot(x, y, precision='f32'):
+    return lib(precision).s2do_hypot(float(x), float(y))
 
 
 def exp(x, precision='f32'):

@@ -1,0 +1,279 @@
+"""Parity tests proper: the HIP engine (through the C ABI of libs2d_hip.so) against the CPU
+oracle on the same seeded inputs.  Bar: BIT-EXACT for every integer AND every fp32 word
+(the engine and the fp32 oracle implement the same deterministic math spec), plus
+size-independent properties at the BASELINE.json sizes.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+def _engine(n, **kw):
+    from soccer2d_amd.engine import Engine, make_config
+    server = kw.pop('server', None)
+    cfg = make_config(server_params=server, **kw)
+    return Engine(n, 'cuda:0', cfg=cfg)
+
+
+def _oracle(n, **kw):
+    server = kw.pop('server', None)
+    cfg = O.make_config(seed=kw.pop('seed', 0x5EED), env_id_offset=kw.pop('env_id_offset', 0),
+                        auto_reset=int(kw.pop('auto_reset', True)), noise=int(kw.pop('noise', False)),
+                        server=server, **kw)
+    return O.OracleEngine(cfg, n, 'f32')
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float32:
+        return a.view(np.int32)
+    return a
+
+
+def assert_same(gpu_t, cpu_a, what):
+    g = gpu_t.detach().cpu().numpy()
+    assert g.shape == cpu_a.shape, (what, g.shape, cpu_a.shape)
+    if not np.array_equal(bits(g), bits(cpu_a)):
+        bad = np.argwhere(bits(g) != bits(cpu_a))
+        i = tuple(bad[0])
+        raise AssertionError(f"{what}: {len(bad)} of {g.size} words differ; first at {i}: gpu={g[i]!r} cpu={cpu_a[i]!r}")
+
+
+def assert_state_same(eng, orc, tag=''):
+    for f in O.STATE_FIELDS:
+        assert_same(getattr(eng, f), orc.state(f), f'{tag} state.{f}')
+
+
+def test_default_config_matches_test_table():
+    import ctypes as C
+    from soccer2d_amd import _capi
+    lib = _capi.load_library()
+    cfg = _capi.S2DConfig()
+    lib.s2d_default_config(C.byref(cfg))
+    ref = O.make_config()
+    assert bytes(memoryview(cfg)) == bytes(memoryview(ref))
+
+
+def test_device_math_bit_exact():
+    """sincos/atan2/exp/norm/hypot/philox evaluated on the GPU == the oracle's fp32 spec."""
+    import ctypes as C
+    from soccer2d_amd import _capi
+    lib = _capi.load_library()
+    rs = np.random.RandomState(0)
+    dev = 'cuda:0'
+
+    def run(op, inp, out_shape, out_dtype=torch.float32):
+        x = torch.as_tensor(inp, device=dev).contiguous()
+        y = torch.zeros(out_shape, dtype=out_dtype, device=dev)
+        n = out_shape[0]
+        _capi.check(lib, lib.s2d_debug_eval(op, x.data_ptr(), y.data_ptr(), n, None), 's2d_debug_eval')
+        torch.cuda.synchronize()
+        return y.cpu().numpy()
+
+    deg = np.concatenate([rs.uniform(-720, 720, 20000), np.arange(-720, 721, 0.5), 22.5 * np.arange(-32, 33)]).astype(np.float32)
+    got = run(0, deg, (len(deg), 2))
+    exp = np.array([O.sincos_deg(float(d)) for d in deg], dtype=np.float32)
+    assert np.array_equal(bits(got), bits(exp))
+    yx = rs.uniform(-110, 110, (20000, 2)).astype(np.float32)
+    yx[:50] = np.round(yx[:50])
+    yx[50:60] = 0
+    got = run(1, yx, (len(yx),))
+    exp = np.array([O.atan2_deg(float(y), float(x)) for y, x in yx], dtype=np.float32)
+    assert np.array_equal(bits(got), bits(exp))
+    x = rs.uniform(-3, 3, 5000).astype(np.float32)
+    assert np.array_equal(bits(run(2, x, (len(x),))), bits(np.array([O.exp(float(v)) for v in x], dtype=np.float32)))
+    x = rs.uniform(-1000, 1000, 5000).astype(np.float32)
+    assert np.array_equal(bits(run(3, x, (len(x),))),
+                          bits(np.array([O.lib('f32').s2do_norm_deg(float(v)) for v in x], dtype=np.float32)))
+    got = run(5, yx, (len(yx),))
+    exp = np.array([O.hypot(float(a), float(b)) for a, b in yx], dtype=np.float32)
+    assert np.array_equal(bits(got), bits(exp))   # hypot spec = sqrtf(fmaf(x,x,y*y))
+    true = np.sqrt(yx[:, 0].astype(np.float64) ** 2 + yx[:, 1].astype(np.float64) ** 2)
+    assert (np.abs(got - true) <= 1.2e-7 * np.maximum(true, 1e-30)).all()
+    ck = rs.randint(0, 2 ** 32, (512, 6), dtype=np.uint64).astype(np.uint32)
+    ck[0] = 0
+    ck[1] = 0xffffffff
+    ck[2] = [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0]
+    got = run(4, ck.view(np.int32), (512, 4), torch.int32).view(np.uint32)
+    exp = np.array([O.philox(list(map(int, r[:4])), list(map(int, r[4:]))) for r in ck], dtype=np.uint32)
+    assert np.array_equal(got, exp)
+    assert list(got[0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+
+
+@pytest.mark.parametrize('n', [1, 63, 1000, 4096])
+def test_reset_parity(n):
+    kw = dict(use_continuous_action=False, change_ball_velocity=True)
+    eng, orc = _engine(n, **kw), _oracle(n, **kw)
+    obs = eng.reset()
+    torch.cuda.synchronize()
+    orc.reset()
+    assert_same(obs, orc.obs(), 'reset obs')
+    assert_state_same(eng, orc, 'reset')
+    assert int(eng.cycle.min()) == 1 and int(eng.step_number.max()) == 0
+
+
+CONFIGS = {
+    'dqn-discrete16': dict(use_continuous_action=False, action_space_size=16, change_ball_velocity=True),
+    'discrete7-fixed-ball': dict(use_continuous_action=False, action_space_size=7, change_ball_position=False,
+                                 ball_position_x=10, ball_position_y=-5, ball_speed=1.5, ball_direction=30, max_steps=40),
+    'continuous1': dict(use_continuous_action=True, use_turning=False, change_ball_velocity=True, max_steps=60),
+    'turning4': dict(use_continuous_action=True, use_turning=True, change_ball_velocity=True, max_steps=60),
+    'noise-on': dict(use_continuous_action=False, change_ball_velocity=True, noise=True, max_steps=50),
+    'no-autoreset-collide': dict(use_continuous_action=False, auto_reset=False, min_distance_to_ball=0.0, max_steps=30,
+                                 change_ball_velocity=True),
+    'free-dash-angle': dict(use_continuous_action=True, use_turning=False, server=dict(dash_angle_step=0.0), max_steps=80),
+}
+
+
+def _random_actions(rs, cfg_kw, n):
+    if not cfg_kw.get('use_continuous_action', True):
+        return rs.randint(0, cfg_kw.get('action_space_size', 16), n).astype(np.int64)
+    w = 4 if cfg_kw.get('use_turning', False) else 1
+    return rs.uniform(-1.3, 1.3, (n, w)).astype(np.float32)
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_step_parity(name):
+    """Per-step API, 250 steps with caller actions: every output and every state word equal."""
+    kw = CONFIGS[name]
+    n = 777
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    rs = np.random.RandomState(42)
+    dones = 0
+    for t in range(250):
+        a = _random_actions(rs, kw, n)
+        obs, rew, done, res = eng.step(torch.as_tensor(a, device='cuda:0'))
+        o_obs, o_rew, o_done, o_res = orc.step(a)
+        torch.cuda.synchronize()
+        assert_same(done, o_done, f'{name} t={t} done')
+        assert_same(res, o_res, f'{name} t={t} result')
+        assert_same(rew, o_rew, f'{name} t={t} reward')
+        assert_same(obs, o_obs, f'{name} t={t} obs')
+        assert_same(eng.action_dir, orc.action_dir(), f'{name} t={t} action_dir')
+        assert_same(eng.action_cmd, orc.action_cmd(), f'{name} t={t} action_cmd')
+        if o_done.any() and kw.get('auto_reset', True):
+            m = o_done.astype(bool)
+            assert_same(eng.terminal_obs[torch.as_tensor(m, device='cuda:0')], orc.terminal_obs()[m], 'terminal_obs')
+        dones += int(o_done.sum())
+        if t % 50 == 49:
+            assert_state_same(eng, orc, f'{name} t={t}')
+    assert_state_same(eng, orc, name)
+    assert dones > 0
+    st = eng.stats.cpu().numpy()
+    assert list(st[:4]) == list(orc.stats()[:4].astype(np.int64))
+    assert st[0] == 250 * n and st[1:4].sum() == dones
+
+
+@pytest.mark.parametrize('name', ['dqn-discrete16', 'turning4', 'noise-on'])
+def test_random_policy_and_rollout_parity(name):
+    """In-kernel Philox policy (S2D_ACT_RANDOM): per-step launches == one fused rollout launch
+    == the oracle, bit for bit, including the emitted actions."""
+    kw = CONFIGS[name]
+    n, T = 1000, 130
+    a, b, orc = _engine(n, **dict(kw)), _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    a.reset(); b.reset(); orc.reset()
+    ref = orc.rollout(T)
+    out = b.rollout(T)
+    torch.cuda.synchronize()
+    for k in ('obs', 'action', 'reward', 'done', 'result'):
+        assert_same(out[k], ref[k], f'{name} rollout.{k}')
+    assert_state_same(b, orc, f'{name} rollout')
+    assert_same(b.obs, orc.obs(), 'rollout last obs')
+    for t in range(T):
+        obs, rew, done, res = a.step(None)
+        assert_same(obs, ref['obs'][t], f'{name} step t={t} obs')
+        assert_same(done, ref['done'][t], f'{name} step t={t} done')
+    assert_state_same(a, orc, f'{name} stepwise')
+    assert (a.stats.cpu().numpy() == b.stats.cpu().numpy()).all()
+
+
+def test_rollout_with_caller_actions_and_odd_n():
+    """[T][N] caller actions; odd N exercises the unaligned observation-store path."""
+    kw = CONFIGS['dqn-discrete16']
+    n, T = 333, 64
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    rs = np.random.RandomState(9)
+    acts = rs.randint(0, 16, (T, n)).astype(np.int32)
+    ref = orc.rollout(T, acts)
+    out = eng.rollout(T, torch.as_tensor(acts, device='cuda:0'))
+    torch.cuda.synchronize()
+    for k in ('obs', 'action', 'reward', 'done', 'result'):
+        assert_same(out[k], ref[k], f'rollout.{k}')
+    assert_state_same(eng, orc, 'rollout caller actions')
+
+
+def test_masked_reset_parity():
+    kw = CONFIGS['dqn-discrete16']
+    n = 500
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    rs = np.random.RandomState(1)
+    for t in range(20):
+        eng.step(None); orc.step(None)
+        m = (rs.rand(n) < 0.2).astype(np.uint8)
+        obs = eng.reset(torch.as_tensor(m, device='cuda:0'))
+        o = orc.reset(m)
+        assert_same(obs, o, f'masked reset t={t}')
+    assert_state_same(eng, orc, 'masked reset')
+
+
+def test_shard_invariance_on_device():
+    """Two engines over [0,600) and [600,1000) == one engine over [0,1000) (global env ids)."""
+    kw = dict(CONFIGS['noise-on'])
+    whole = _engine(1000, **dict(kw))
+    lo, hi = _engine(600, env_id_offset=0, **dict(kw)), _engine(400, env_id_offset=600, **dict(kw))
+    for e in (whole, lo, hi):
+        e.reset()
+        e.rollout(90, with_obs=False)
+    torch.cuda.synchronize()
+    for f in O.STATE_FIELDS:
+        assert torch.equal(torch.cat([getattr(lo, f), getattr(hi, f)]), getattr(whole, f)), f
+    assert torch.equal(torch.cat([lo.obs, hi.obs]), whole.obs)
+
+
+def test_full_size_parity_and_properties():
+    """BASELINE.json sizes: 65 536 envs, dqn kwargs, 256 random-policy steps (> one full episode).
+    Full bit-exact comparison with the oracle plus size-independent invariants."""
+    kw = CONFIGS['dqn-discrete16']
+    n, T = 65536, 256
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    out = eng.rollout(T)
+    ref = orc.rollout(T)
+    torch.cuda.synchronize()
+    for k in ('action', 'reward', 'done', 'result', 'obs'):
+        assert_same(out[k], ref[k], f'full-size rollout.{k}')
+    assert_state_same(eng, orc, 'full-size')
+    done, res = out['done'].cpu().numpy(), out['result'].cpu().numpy()
+    assert ((res != 0) == (done != 0)).all()
+    # cycle bookkeeping (A7): one cycle per step, plus one per reset (initial + each auto-reset)
+    cyc = eng.cycle.cpu().numpy()
+    assert (cyc == T + 1 + done.sum(axis=0)).all()
+    # an episode never exceeds max_steps + 1 steps
+    assert int(eng.step_number.max()) <= 201
+    st = eng.stats.cpu().numpy()
+    assert st[0] == n * T and st[1] == (res == 1).sum() and st[2] == (res == 2).sum() and st[3] == (res == 3).sum()
+    assert st[3] > 0 and st[1] > 0
+    obs = out['obs']
+    assert bool(torch.isfinite(obs).all())
+    assert float(obs[..., 0].abs().max()) <= 1.0 and float(obs[..., 7].abs().max()) <= 0.5
+
+
+def test_errors_are_loud():
+    from soccer2d_amd.engine import Engine, make_config
+    with pytest.raises(ValueError):
+        make_config(no_such_kwarg=1)
+    with pytest.raises(ValueError):
+        make_config(use_continuous_action=False, action_space_size=0)
+    eng = _engine(8, use_continuous_action=False)
+    with pytest.raises(ValueError):
+        eng.step(torch.zeros(9, dtype=torch.int64, device='cuda:0'))
+    with pytest.raises(ValueError):
+        Engine(0, 'cuda:0')
