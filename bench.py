@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the reach_ball hot path on N MI355X (BASELINE.json metric).
+
+A "step" is one simulator cycle for every env of the batch (action decode -> dash/turn ->
+stamina -> integrate -> collide -> decay -> observation -> reward/done/result -> auto-reset),
+with the rollout record of that step (obs[10], action, reward, done, result per env) written
+to HBM.  Workload = BASELINE.json configs[2]: 65 536 reach_ball envs per GPU, kwargs of
+dqn_stable_baselines3.py:18-31, uniform random policy drawn in-kernel (Philox), synthetic
+reset distribution of reach_ball_env.py:170-218.  Inputs are resident in HBM before the
+timed region; nothing is copied to the host inside it.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode rollout|step|graph] [--fuse T]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Modes (all run the same arithmetic, bit-identical trajectories):
+  rollout  (default) T cycles fused per launch (s2d_rollout): state stays in registers
+  step     one launch per cycle (s2d_step), eager
+  graph    one launch per cycle, T of them captured in a hipGraph and replayed
+Multi-GPU: one process per GPU, contiguous global env-id ranges, NO data-path collective
+(envs are independent) -> weak scaling; only the timing max is all-reduced.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, 'gym-soccer-2d-env_amd'), os.path.join(ROOT, 'tests'), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+STATE_BYTES = 68               # 17 words per env
+RECORD_BYTES = 50              # obs 40 + action 4 + reward 4 + done 1 + result 1 per env-step
+DQN_KWARGS = dict(change_ball_position=True, change_ball_velocity=True, min_distance_to_ball=5.0,
+                  max_steps=200, use_continuous_action=False, action_space_size=16, use_turning=False)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4096)
+    ap.add_argument('--warmup', type=int, default=256)
+    ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
+    ap.add_argument('--mode', choices=('rollout', 'step', 'graph'), default='rollout')
+    ap.add_argument('--fuse', type=int, default=64, help='cycles per launch (rollout) / per graph (graph)')
+    ap.add_argument('--noise', action='store_true', help='player_rand/ball_rand Philox noise on')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-steps', type=int, default=0, help='0 = auto (about 10-20 s of CPU work)')
+    return ap.parse_args()
+
+
+def cpu_baseline(n_envs, sample_steps):
+    """Time the CPU oracle (plain-C scalar port of the same algorithm, fp32 build) on the
+    host cores of this box, on a bounded sample of the same workload.  kind = "port"."""
+    import ctypes as C
+    import numpy as np  # noqa: F401
+    import oracle as O
+    cores_avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    threads = max(1, min(cores_avail, 16))
+    try:
+        gomp = C.CDLL('libgomp.so.1')
+    except OSError:
+        gomp, threads = None, 1
+    cfg = O.make_config(**DQN_KWARGS)
+    eng = O.OracleEngine(cfg, n_envs, 'f32')
+
+    def run(nthreads, steps):
+        if gomp is not None:
+            gomp.omp_set_num_threads(int(nthreads))
+        eng.reset()
+        eng.L.s2do_rollout(eng.h, 2, None, 4, None, None, None, None, None)   # touch memory
+        t0 = time.perf_counter()
+        eng.L.s2do_rollout(eng.h, steps, None, 4, None, None, None, None, None)
+        return time.perf_counter() - t0
+
+    probe = run(1, 4)
+    per_step_1t = probe / 4
+    s1 = sample_steps or max(8, min(256, int(6.0 / per_step_1t)))
+    t1 = run(1, s1)
+    v1 = n_envs * s1 / t1
+    sN = sample_steps or max(8, min(2048, int(8.0 / (per_step_1t / threads))))
+    tN = run(threads, sN) if threads > 1 else t1
+    vN = n_envs * sN / tN if threads > 1 else v1
+    return {'value': vN, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+            'value_1thread': v1,
+            'sample': f'{n_envs} envs x {sN} steps ({threads} OpenMP threads, {tN:.2f} s) and x {s1} steps '
+                      f'(1 thread, {t1:.2f} s); oracle/s2d_oracle.c fp32 build, gcc -O2, same kwargs/seed; '
+                      f'reference rcssserver+proxy+gRPC chain not measurable (binaries absent offline)'}
+
+
+def load_traffic(mode, fuse, n_envs):
+    """HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/traffic_*.json)."""
+    best = None
+    pdir = os.path.join(ROOT, 'profiles')
+    if not os.path.isdir(pdir):
+        return None
+    for f in sorted(os.listdir(pdir)):
+        if f.startswith('traffic_') and f.endswith('.json'):
+            try:
+                d = json.load(open(os.path.join(pdir, f)))
+            except Exception:
+                continue
+            for row in d.get('rows', []):
+                if row.get('mode') == mode and row.get('fuse') == fuse and row.get('envs') == n_envs:
+                    best = row.get('hbm_bytes_per_launch')
+    return best
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)')
+        args.gpus = world
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from soccer2d_amd.engine import Engine, make_config
+    n = args.envs
+    cfg = make_config(seed=0x5EED, env_id_offset=rank * n, auto_reset=True, noise=args.noise, **DQN_KWARGS)
+    eng = Engine(n, dev, cfg=cfg)
+    eng.reset()
+    T = max(1, args.fuse)
+    K, W = args.steps, args.warmup
+    ro = eng.alloc_rollout(T) if args.mode == 'rollout' else None
+    stream = torch.cuda.current_stream(dev)
+
+    graph = None
+    if args.mode == 'graph':
+        side = torch.cuda.Stream(dev)
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eng.step(None)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(T):
+                eng.step(None)
+
+    def launch(k):
+        """run k cycles; returns number of launches issued"""
+        if args.mode == 'rollout':
+            full, rem = divmod(k, T)
+            for _ in range(full):
+                eng.rollout(T, out=ro)
+            if rem:
+                eng.rollout(rem, out=ro)
+            return full + (1 if rem else 0)
+        if args.mode == 'graph':
+            full, rem = divmod(k, T)
+            for _ in range(full):
+                graph.replay()
+            for _ in range(rem):
+                eng.step(None)
+            return full * T + rem
+        for _ in range(k):
+            eng.step(None)
+        return k
+
+    launch(W)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    # ---- timed region: EXACTLY K cycles ----
+    per_launch_events = []
+    t0 = time.perf_counter()
+    if args.mode == 'rollout':
+        full, rem = divmod(K, T)
+        for i in range(full + (1 if rem else 0)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            eng.rollout(T if i < full else rem, out=ro)
+            e1.record(stream)
+            if i < full:
+                per_launch_events.append((e0, e1))
+        n_launches = full + (1 if rem else 0)
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        n_launches = launch(K)
+        e1.record(stream)
+        per_launch_events.append((e0, e1))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant-kernel launch duration from HIP events on the launch stream
+    if args.mode == 'rollout' and per_launch_events:
+        durs = sorted(a.elapsed_time(b) * 1e-3 for a, b in per_launch_events)
+        launch_s = sum(durs) / len(durs)
+        steps_per_launch = T
+    else:
+        a, b = per_launch_events[0]
+        launch_s = a.elapsed_time(b) * 1e-3 / K
+        steps_per_launch = 1
+    if args.mode == 'rollout':
+        alg_bytes_launch = n * (2 * STATE_BYTES + steps_per_launch * RECORD_BYTES)
+        kernel = 's2d_reach_rollout_kernel'
+    else:
+        alg_bytes_launch = n * (2 * STATE_BYTES + 4 + RECORD_BYTES - 4)      # 186 B per env-step
+        kernel = 's2d_reach_step_kernel'
+    achieved = alg_bytes_launch / launch_s / 1e9
+
+    total_steps = world * n * K
+    stats = eng.stats.cpu().tolist()
+    if rank == 0:
+        line = {
+            'metric': 'env-steps/sec at 65 536 parallel reach_ball envs per MI355X',
+            'value': total_steps / elapsed,
+            'unit': 'env-steps/s',
+            'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': elapsed / K * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'reach_ball_env, {n} envs per GPU, random-policy rollouts '
+                                   f'(BASELINE.json configs[2]; kwargs of dqn_stable_baselines3.py:18-31)',
+                       'envs_per_gpu': n, 'global_envs': world * n, 'mode': args.mode,
+                       'cycles_per_launch': steps_per_launch if args.mode != 'graph' else f'1 ({T} per graph replay)',
+                       'noise': bool(args.noise), 'parallelism': f'env-shard x{world} (no collective)',
+                       'launches': n_launches},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(args.mode, T, n),
+                         'kernel': kernel, 'launch_us': launch_s * 1e6,
+                         'algorithmic_bytes_per_launch': alg_bytes_launch,
+                         'algorithmic_bytes_per_env_step': alg_bytes_launch / (n * steps_per_launch)},
+            'episodes': {'goal': stats[1], 'out': stats[2], 'timeout': stats[3]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = cpu_baseline(n, args.cpu_sample_steps)
+            except Exception as ex:     # the baseline is a report, never the product
+                line['cpu_baseline'] = {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port',
+                                        'sample': f'failed: {ex!r}'}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

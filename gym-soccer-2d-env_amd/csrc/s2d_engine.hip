@@ -83,54 +83,49 @@ S2D_DEV void wave_count_results(int res, bool active, int lane, unsigned long lo
   }
 }
 
-struct Action4 { float a0, a1, a2, a3; };
-
 // caller-provided action of env i at rollout step t (layouts of include/s2d.h), or the
 // in-kernel uniform random policy (Philox POLICY stream at (gid, cycle))
-S2D_DEV Action4 fetch_action(const S2DDevParams& p, const void* __restrict__ actions, int kind, int64_t idx,
+template <int MODE>
+S2D_DEV Action4 fetch_action(const S2DHot& p, const void* __restrict__ actions, int kind, int64_t idx,
                              uint32_t gid_lo, uint32_t gid_hi, uint32_t cycle) {
   Action4 a{0.0f, 0.0f, 0.0f, 0.0f};
-  switch (kind) {
-    case S2D_ACT_DISCRETE_I32: a.a0 = (float)static_cast<const int32_t*>(actions)[idx]; break;
-    case S2D_ACT_DISCRETE_I64: a.a0 = (float)static_cast<const long long*>(actions)[idx]; break;
-    case S2D_ACT_CONTINUOUS: a.a0 = static_cast<const float*>(actions)[idx]; break;
-    case S2D_ACT_TURNING: {
-      float4 v = static_cast<const float4*>(actions)[idx];
-      a.a0 = v.x; a.a1 = v.y; a.a2 = v.z; a.a3 = v.w;
-      break;
+  if (kind == S2D_ACT_RANDOM) {
+    U4 w = s2d_draw(p, gid_lo, gid_hi, cycle, S2D_ST_POLICY, 0);
+    if (MODE == S2D_MODE_DISCRETE) a.a0 = (float)rnd_below(w.x, (uint32_t)p.n_actions);
+    else if (MODE == S2D_MODE_CONT1) a.a0 = rnd_u01(w.x) * 2.0f - 1.0f;
+    else {
+      a.a0 = rnd_u01(w.x) * 2.0f - 1.0f; a.a1 = rnd_u01(w.y) * 2.0f - 1.0f;
+      a.a2 = rnd_u01(w.z) * 2.0f - 1.0f; a.a3 = rnd_u01(w.w) * 2.0f - 1.0f;
     }
-    default: {
-      U4 w = s2d_draw(p, gid_lo, gid_hi, cycle, S2D_ST_POLICY, 0);
-      if (!p.use_continuous) a.a0 = (float)rnd_below(w.x, (uint32_t)p.n_actions);
-      else if (!p.use_turning) a.a0 = rnd_u01(w.x) * 2.0f - 1.0f;
-      else {
-        a.a0 = rnd_u01(w.x) * 2.0f - 1.0f; a.a1 = rnd_u01(w.y) * 2.0f - 1.0f;
-        a.a2 = rnd_u01(w.z) * 2.0f - 1.0f; a.a3 = rnd_u01(w.w) * 2.0f - 1.0f;
-      }
-    }
+  } else if (MODE == S2D_MODE_DISCRETE) {
+    a.a0 = (kind == S2D_ACT_DISCRETE_I64) ? (float)static_cast<const long long*>(actions)[idx]
+                                          : (float)static_cast<const int32_t*>(actions)[idx];
+  } else if (MODE == S2D_MODE_CONT1) {
+    a.a0 = static_cast<const float*>(actions)[idx];
+  } else {
+    float4 v = static_cast<const float4*>(actions)[idx];
+    a.a0 = v.x; a.a1 = v.y; a.a2 = v.z; a.a3 = v.w;
   }
   return a;
 }
 
 // A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269) for the env held in registers.
 // Returns the observation to hand back (post auto-reset), reward/done/result of the step.
-S2D_DEV void step_env(const S2DDevParams& p, Env& e, uint32_t gid_lo, uint32_t gid_hi, const Action4& a,
-                      ObsOut& ob, float& reward, int& done, int& result, int& cmd, float& dir,
+template <int MODE, bool NOISE>
+S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
+                      const Action4& a, ObsOut& ob, float& reward, int& done, int& result, int& cmd, float& dir,
                       float* __restrict__ terminal_row) {
   e.step_number += 1;                                    // reach_ball_env.py:55
   float u = 0.0f;
-  if (p.use_continuous && p.use_turning)
-    u = rnd_u01(s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_SELECT, 0).x);
+  if (MODE == S2D_MODE_TURN4) u = rnd_u01(s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_SELECT, 0).x);
   float power;
-  action_map(p, a.a0, a.a1, a.a2, a.a3, u, cmd, power, dir);
-  sim_cycle(p, e, gid_lo, gid_hi, cmd, power, dir);      // trainer forces PlayOn each cycle (:242)
+  action_map<MODE>(p, a, u, cmd, power, dir);
+  sim_cycle<NOISE, true>(p, rp, e, gid_lo, gid_hi, cmd, power, dir);   // trainer forces PlayOn each cycle (:242)
   observe_and_check(p, e, ob, done, reward, result);
-  if (done && p.auto_reset) {                            // SB3 VecEnv convention
-    if (terminal_row) {
+  if (done && p.auto_reset) {                            // rare: SB3 VecEnv convention
 #pragma unroll
-      for (int k = 0; k < S2D_OBS_DIM; ++k) terminal_row[k] = ob.o[k];
-    }
-    env_reset(p, e, gid_lo, gid_hi);
+    for (int k = 0; k < S2D_OBS_DIM; ++k) terminal_row[k] = ob.o[k];
+    env_reset<NOISE>(p, rp, e, gid_lo, gid_hi);
     int d2, r2; float w2;
     observe_and_check(p, e, ob, d2, w2, r2);             // reach_ball_env.py:166: carry seeded, outputs dropped
   }
@@ -139,18 +134,19 @@ S2D_DEV void step_env(const S2DDevParams& p, Env& e, uint32_t gid_lo, uint32_t g
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void s2d_init_kernel(S2DDevParams p, float* __restrict__ S, int64_t stride,
-                                                          int64_t n) {
+__global__ __launch_bounds__(kBlock) void s2d_init_kernel(S2DHot p, const S2DRare* __restrict__ rp,
+                                                          float* __restrict__ S, int64_t stride, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   S[F_STAMINA * stride + i] = p.stamina_max;             // state after a trainer (recover)
-  S[F_RECOVERY * stride + i] = p.recover_init;
+  S[F_RECOVERY * stride + i] = rp->recover_init;
   S[F_EFFORT * stride + i] = p.effort_init;
   S[F_CAPACITY * stride + i] = p.stamina_capacity;
 }
 
-__global__ __launch_bounds__(kBlock) void s2d_reach_reset_kernel(S2DDevParams p, float* __restrict__ S,
-                                                                 int64_t stride, int64_t n,
+template <bool NOISE>
+__global__ __launch_bounds__(kBlock) void s2d_reach_reset_kernel(S2DHot p, const S2DRare* __restrict__ rp,
+                                                                 float* __restrict__ S, int64_t stride, int64_t n,
                                                                  const uint8_t* __restrict__ mask, StepOut o) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
@@ -166,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_reset_kernel(S2DDevParams p,
     env_load(e, S, stride, i);
     if (active) {
       uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
-      env_reset(p, e, (uint32_t)gid, (uint32_t)(gid >> 32));
+      env_reset<NOISE>(p, rp, e, (uint32_t)gid, (uint32_t)(gid >> 32));
       int d, r; float w;
       observe_and_check(p, e, ob, d, w, r);
       env_store(e, S, stride, i);
@@ -180,8 +176,9 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_reset_kernel(S2DDevParams p,
   store_obs_tile(lds[wv], ob, lane, in_range, o.obs + wave_first * S2D_OBS_DIM, (int)rows * S2D_OBS_DIM);
 }
 
-__global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DDevParams p, float* __restrict__ S,
-                                                                int64_t stride, int64_t n,
+template <int MODE, bool NOISE>
+__global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const S2DRare* __restrict__ rp,
+                                                                float* __restrict__ S, int64_t stride, int64_t n,
                                                                 const void* __restrict__ actions, int kind,
                                                                 StepOut o) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
@@ -197,9 +194,9 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DDevParams p, 
     env_load(e, S, stride, i);
     uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
     uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
-    Action4 a = fetch_action(p, actions, kind, i, gl, gh, (uint32_t)e.cycle);
+    Action4 a = fetch_action<MODE>(p, actions, kind, i, gl, gh, (uint32_t)e.cycle);
     float reward, dir; int done, cmd;
-    step_env(p, e, gl, gh, a, ob, reward, done, res, cmd, dir, o.terminal_obs + i * S2D_OBS_DIM);
+    step_env<MODE, NOISE>(p, rp, e, gl, gh, a, ob, reward, done, res, cmd, dir, o.terminal_obs + i * S2D_OBS_DIM);
     env_store(e, S, stride, i);
     o.reward[i] = reward;
     o.done[i] = (uint8_t)done;
@@ -219,10 +216,11 @@ struct RolloutOut {
   float* obs; void* action; float* reward; uint8_t* done; uint8_t* result;
 };
 
-__global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DDevParams p, float* __restrict__ S,
-                                                                   int64_t stride, int64_t n, int n_steps,
-                                                                   const void* __restrict__ actions, int kind,
-                                                                   RolloutOut ro, StepOut o) {
+template <int MODE, bool NOISE>
+__global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p, const S2DRare* __restrict__ rp,
+                                                                   float* __restrict__ S, int64_t stride, int64_t n,
+                                                                   int n_steps, const void* __restrict__ actions,
+                                                                   int kind, RolloutOut ro, StepOut o) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -241,17 +239,18 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DDevParams 
   ObsOut ob;
   float reward = 0.0f, dir = 0.0f; int done = 0, res = 0, cmd = 0;
   unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
+  float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
   for (int t = 0; t < n_steps; ++t) {
     const int64_t row = (int64_t)t * n;
     res = 0;
     if (active) {
-      Action4 a = fetch_action(p, actions, kind, row + i, gl, gh, (uint32_t)e.cycle);
+      Action4 a = fetch_action<MODE>(p, actions, kind, row + i, gl, gh, (uint32_t)e.cycle);
       if (ro.action) {
-        if (!p.use_continuous) static_cast<int32_t*>(ro.action)[row + i] = (int32_t)a.a0;
-        else if (!p.use_turning) static_cast<float*>(ro.action)[row + i] = a.a0;
+        if (MODE == S2D_MODE_DISCRETE) static_cast<int32_t*>(ro.action)[row + i] = (int32_t)a.a0;
+        else if (MODE == S2D_MODE_CONT1) static_cast<float*>(ro.action)[row + i] = a.a0;
         else static_cast<float4*>(ro.action)[row + i] = make_float4(a.a0, a.a1, a.a2, a.a3);
       }
-      step_env(p, e, gl, gh, a, ob, reward, done, res, cmd, dir, o.terminal_obs + i * S2D_OBS_DIM);
+      step_env<MODE, NOISE>(p, rp, e, gl, gh, a, ob, reward, done, res, cmd, dir, term_row);
       if (ro.reward) ro.reward[row + i] = reward;
       if (ro.done) ro.done[row + i] = (uint8_t)done;
       if (ro.result) ro.result[row + i] = (uint8_t)res;
@@ -285,7 +284,6 @@ __global__ __launch_bounds__(kBlock) void s2d_world_model_kernel(const float* __
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   float px = S[F_PX * stride + i], py = S[F_PY * stride + i], vx = S[F_VX * stride + i], vy = S[F_VY * stride + i];
-  float body = S[F_BODY * stride + i];
   float bx = S[F_BX * stride + i], by = S[F_BY * stride + i], bvx = S[F_BVX * stride + i], bvy = S[F_BVY * stride + i];
   float dx = bx - px, dy = by - py;
   float dist = hypot2(dx, dy), ang = atan2_deg(dy, dx);
@@ -303,7 +301,6 @@ __global__ __launch_bounds__(kBlock) void s2d_world_model_kernel(const float* __
   if (w.self_vel_angle) w.self_vel_angle[i] = atan2_deg(vy, vx);
   if (w.self_dist_from_ball) w.self_dist_from_ball[i] = dist;
   if (w.self_angle_from_ball) w.self_angle_from_ball[i] = atan2_deg(-dy, -dx);
-  (void)body;
 }
 
 // diagnostic: evaluate the math spec / Philox on the device (tests compare with the oracle)
@@ -314,7 +311,7 @@ __global__ void s2d_debug_eval_kernel(int op, const float* __restrict__ in, floa
     case 0: { float s, c; sincos_deg(in[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break; }
     case 1: out[i] = atan2_deg(in[2 * i], in[2 * i + 1]); break;
     case 2: out[i] = exp_spec(in[i]); break;
-    case 3: out[i] = norm_deg(in[i]); break;
+    case 3: out[i] = norm_deg_any(in[i]); break;
     case 4: {
       const uint32_t* u = reinterpret_cast<const uint32_t*>(in) + 6 * i;
       U4 r = philox4x32_10(u[0], u[1], u[2], u[3], u[4], u[5]);
@@ -341,7 +338,11 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct S2DEngine {
   S2DConfig cfg;
-  S2DDevParams dp;
+  S2DHot hot;
+  S2DRare rare;
+  const S2DRare* rare_dev;
+  int mode;      // S2D_MODE_*
+  bool noise;
   int64_t n, stride;
   int device;
   char* arena;
@@ -356,7 +357,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static int64_t stride_for(int64_t n) { return (int64_t)align_up((size_t)n, 256); }
 
 struct ArenaLayout {
-  size_t state, obs, reward, done, result, terminal_obs, action_dir, action_cmd, stats, total;
+  size_t state, obs, reward, done, result, terminal_obs, action_dir, action_cmd, stats, rare, total;
 };
 static ArenaLayout layout_for(int64_t n) {
   ArenaLayout L;
@@ -370,6 +371,7 @@ static ArenaLayout layout_for(int64_t n) {
   L.action_dir = off; off += align_up(s * 4, 256);
   L.action_cmd = off; off += align_up(s, 256);
   L.stats = off; off += 256;
+  L.rare = off; off += align_up(sizeof(S2DRare), 256);
   L.total = off;
   return L;
 }
@@ -424,42 +426,47 @@ S2D_API int s2d_validate_config(const S2DConfig* c) {
   return S2D_OK;
 }
 
-static void dev_params_from_config(const S2DConfig& c, S2DDevParams& p) {
+static void dev_params_from_config(const S2DConfig& c, S2DHot& h, S2DRare& r) {
   const S2DServerParams& s = c.sp;
   const S2DReachBallParams& t = c.task;
-  std::memset(&p, 0, sizeof p);
-  p.half_l = (float)s.pitch_half_length; p.half_w = (float)s.pitch_half_width;
-  p.player_size = (float)s.player_size; p.player_decay = (float)s.player_decay;
-  p.player_rand = (float)s.player_rand; p.player_speed_max = (float)s.player_speed_max;
-  p.player_accel_max = (float)s.player_accel_max; p.inertia_moment = (float)s.inertia_moment;
-  p.stamina_max = (float)s.stamina_max; p.stamina_inc_max = (float)s.stamina_inc_max;
-  p.stamina_capacity = (float)s.stamina_capacity; p.extra_stamina = (float)s.extra_stamina;
-  p.recover_init = (float)s.recover_init;
-  p.recover_dec_thr_value = (float)(s.recover_dec_thr * s.stamina_max);
-  p.recover_min = (float)s.recover_min; p.recover_dec = (float)s.recover_dec;
-  p.effort_init = (float)s.effort_init;
-  p.effort_dec_thr_value = (float)(s.effort_dec_thr * s.stamina_max);
-  p.effort_min = (float)s.effort_min; p.effort_dec = (float)s.effort_dec;
-  p.effort_inc_thr_value = (float)(s.effort_inc_thr * s.stamina_max);
-  p.effort_inc = (float)s.effort_inc;
-  p.dash_power_rate = (float)s.dash_power_rate; p.max_dash_power = (float)s.max_dash_power;
-  p.min_dash_power = (float)s.min_dash_power; p.max_dash_angle = (float)s.max_dash_angle;
-  p.min_dash_angle = (float)s.min_dash_angle; p.dash_angle_step = (float)s.dash_angle_step;
-  p.side_dash_rate = (float)s.side_dash_rate; p.back_dash_rate = (float)s.back_dash_rate;
-  p.max_moment = (float)s.max_moment; p.min_moment = (float)s.min_moment;
-  p.ball_size = (float)s.ball_size; p.ball_decay = (float)s.ball_decay;
-  p.ball_rand = (float)s.ball_rand; p.ball_speed_max = (float)s.ball_speed_max;
-  p.collision_vel_rate = (float)s.collision_vel_rate;
-  p.ball_position_x = (float)t.ball_position_x; p.ball_position_y = (float)t.ball_position_y;
-  p.ball_speed = (float)t.ball_speed; p.ball_direction = (float)t.ball_direction;
-  p.min_distance_to_ball = (float)t.min_distance_to_ball;
-  p.travel_factor = (float)((1.0 - std::pow(t.reset_ball_decay, (double)t.max_steps)) / (1.0 - t.reset_ball_decay));
-  p.change_ball_position = t.change_ball_position; p.change_ball_velocity = t.change_ball_velocity;
-  p.max_steps = t.max_steps; p.use_continuous = t.use_continuous_action;
-  p.n_actions = t.action_space_size; p.use_turning = t.use_turning;
-  p.auto_reset = c.auto_reset; p.noise = c.noise;
-  p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
-  p.gid_lo = (uint32_t)(uint64_t)c.env_id_offset; p.gid_hi = (uint32_t)((uint64_t)c.env_id_offset >> 32);
+  std::memset(&h, 0, sizeof h);
+  std::memset(&r, 0, sizeof r);
+  const float accel_max = (float)s.player_accel_max, pspeed_max = (float)s.player_speed_max;
+  const float bspeed_max = (float)s.ball_speed_max;
+  const float rsum = (float)s.player_size + (float)s.ball_size;
+  h.inv_half_l = (float)(1.0 / s.pitch_half_length); h.inv_half_w = (float)(1.0 / s.pitch_half_width);
+  h.half_l = (float)s.pitch_half_length; h.half_w = (float)s.pitch_half_width;
+  h.player_decay = (float)s.player_decay; h.ball_decay = (float)s.ball_decay;
+  h.player_accel_max2 = accel_max * accel_max; h.player_speed_max2 = pspeed_max * pspeed_max;
+  h.ball_speed_max2 = bspeed_max * bspeed_max; h.rsum2 = rsum * rsum;
+  h.stamina_max = (float)s.stamina_max; h.stamina_inc_max = (float)s.stamina_inc_max;
+  h.extra_stamina = (float)s.extra_stamina; h.stamina_capacity = (float)s.stamina_capacity;
+  h.recover_dec_thr_value = (float)(s.recover_dec_thr * s.stamina_max);
+  h.recover_min = (float)s.recover_min; h.recover_dec = (float)s.recover_dec;
+  h.effort_init = (float)s.effort_init;
+  h.effort_dec_thr_value = (float)(s.effort_dec_thr * s.stamina_max);
+  h.effort_min = (float)s.effort_min; h.effort_dec = (float)s.effort_dec;
+  h.effort_inc_thr_value = (float)(s.effort_inc_thr * s.stamina_max);
+  h.effort_inc = (float)s.effort_inc;
+  h.dash_power_rate = (float)s.dash_power_rate; h.max_dash_power = (float)s.max_dash_power;
+  h.min_dash_power = (float)s.min_dash_power; h.max_dash_angle = (float)s.max_dash_angle;
+  h.min_dash_angle = (float)s.min_dash_angle; h.dash_angle_step = (float)s.dash_angle_step;
+  h.inv_dash_angle_step = s.dash_angle_step > 0 ? (float)(1.0 / s.dash_angle_step) : 0.0f;
+  h.side_dash_rate = (float)s.side_dash_rate; h.back_dash_rate = (float)s.back_dash_rate;
+  h.min_distance_to_ball = (float)t.min_distance_to_ball;
+  h.act_scale = (float)(360.0 / (double)(t.action_space_size > 0 ? t.action_space_size : 1));
+  h.max_steps = t.max_steps; h.n_actions = t.action_space_size; h.auto_reset = c.auto_reset;
+  h.seed_lo = (uint32_t)c.seed; h.seed_hi = (uint32_t)(c.seed >> 32);
+  h.gid_lo = (uint32_t)(uint64_t)c.env_id_offset; h.gid_hi = (uint32_t)((uint64_t)c.env_id_offset >> 32);
+  h.max_moment = (float)s.max_moment; h.min_moment = (float)s.min_moment;
+  h.inertia_moment = (float)s.inertia_moment; h.player_rand = (float)s.player_rand; h.ball_rand = (float)s.ball_rand;
+  r.player_accel_max = accel_max; r.player_speed_max = pspeed_max; r.ball_speed_max = bspeed_max;
+  r.rsum = rsum; r.collision_vel_rate = (float)s.collision_vel_rate;
+  r.recover_init = (float)s.recover_init;
+  r.ball_position_x = (float)t.ball_position_x; r.ball_position_y = (float)t.ball_position_y;
+  r.ball_speed = (float)t.ball_speed; r.ball_direction = (float)t.ball_direction;
+  r.travel_factor = (float)((1.0 - std::pow(t.reset_ball_decay, (double)t.max_steps)) / (1.0 - t.reset_ball_decay));
+  r.change_ball_position = t.change_ball_position; r.change_ball_velocity = t.change_ball_velocity;
 }
 
 S2D_API size_t s2d_arena_bytes(const S2DConfig* cfg, int64_t n_envs) {
@@ -494,7 +501,10 @@ S2D_API int s2d_create(const S2DConfig* cfg, int64_t n_envs, int device, void* a
   if (!h) return fail(S2D_ENOMEM, "host allocation failed");
   h->cfg = *cfg; h->n = n_envs; h->stride = stride_for(n_envs); h->device = device;
   h->last_kernel = "";
-  dev_params_from_config(*cfg, h->dp);
+  dev_params_from_config(*cfg, h->hot, h->rare);
+  h->mode = !cfg->task.use_continuous_action ? S2D_MODE_DISCRETE
+                                             : (cfg->task.use_turning ? S2D_MODE_TURN4 : S2D_MODE_CONT1);
+  h->noise = cfg->noise != 0;
   if (arena_dev) {
     if (arena_bytes < L.total) { delete h; return fail(S2D_ENOMEM, "arena smaller than s2d_arena_bytes()"); }
     if (reinterpret_cast<uintptr_t>(arena_dev) & 255u) { delete h; return fail(S2D_EINVAL, "arena must be 256-byte aligned"); }
@@ -523,10 +533,14 @@ S2D_API int s2d_create(const S2DConfig* cfg, int64_t n_envs, int device, void* a
   b.action_cmd = reinterpret_cast<uint8_t*>(h->arena + L.action_cmd);
   b.stats = reinterpret_cast<unsigned long long*>(h->arena + L.stats);
   h->out = StepOut{b.obs, b.reward, b.done, b.result, b.terminal_obs, b.action_dir, b.action_cmd, b.stats};
+  h->rare_dev = reinterpret_cast<const S2DRare*>(h->arena + L.rare);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipError_t e = hipMemsetAsync(h->arena, 0, L.total, st);
+  // h->rare lives as long as the handle, so the (possibly staged) copy may complete later
+  if (e == hipSuccess) e = hipMemcpyAsync(h->arena + L.rare, &h->rare, sizeof(S2DRare), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(s2d_init_kernel, dim3(grid_for(n_envs)), dim3(kBlock), 0, st, h->dp, S, h->stride, h->n);
+    hipLaunchKernelGGL(s2d_init_kernel, dim3(grid_for(n_envs)), dim3(kBlock), 0, st, h->hot, h->rare_dev, S,
+                       h->stride, h->n);
     e = hipGetLastError();
   }
   if (e != hipSuccess) {
@@ -594,8 +608,9 @@ static int check_action_kind(const S2DEngine* h, const void* actions, int kind) 
 S2D_API int s2d_reset(S2DHandle h, const uint8_t* mask_dev, void* stream) {
   if (!h) return fail(S2D_EINVAL, "NULL handle");
   DeviceGuard guard(h->device);
-  hipLaunchKernelGGL(s2d_reach_reset_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                     h->dp, reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, mask_dev, h->out);
+  auto k = h->noise ? s2d_reach_reset_kernel<true> : s2d_reach_reset_kernel<false>;
+  hipLaunchKernelGGL(k, dim3(grid_for(h->n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->hot,
+                     h->rare_dev, reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, mask_dev, h->out);
   HIP_TRY(hipGetLastError());
   h->last_kernel = "s2d_reach_reset_kernel";
   return S2D_OK;
@@ -606,9 +621,14 @@ S2D_API int s2d_step(S2DHandle h, const void* actions_dev, int action_kind, void
   int rc = check_action_kind(h, actions_dev, action_kind);
   if (rc != S2D_OK) return rc;
   DeviceGuard guard(h->device);
-  hipLaunchKernelGGL(s2d_reach_step_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                     h->dp, reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, actions_dev, action_kind,
-                     h->out);
+  using StepK = void (*)(S2DHot, const S2DRare*, float*, int64_t, int64_t, const void*, int, StepOut);
+  static const StepK table[3][2] = {
+      {s2d_reach_step_kernel<S2D_MODE_DISCRETE, false>, s2d_reach_step_kernel<S2D_MODE_DISCRETE, true>},
+      {s2d_reach_step_kernel<S2D_MODE_CONT1, false>, s2d_reach_step_kernel<S2D_MODE_CONT1, true>},
+      {s2d_reach_step_kernel<S2D_MODE_TURN4, false>, s2d_reach_step_kernel<S2D_MODE_TURN4, true>}};
+  hipLaunchKernelGGL(table[h->mode][h->noise ? 1 : 0], dim3(grid_for(h->n)), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), h->hot, h->rare_dev,
+                     reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, actions_dev, action_kind, h->out);
   HIP_TRY(hipGetLastError());
   h->last_kernel = "s2d_reach_step_kernel";
   return S2D_OK;
@@ -629,9 +649,15 @@ S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int a
     if (reinterpret_cast<uintptr_t>(out->obs) & 3u) return fail(S2D_EINVAL, "rollout obs buffer must be 4-byte aligned");
   }
   DeviceGuard guard(h->device);
-  hipLaunchKernelGGL(s2d_reach_rollout_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0,
-                     static_cast<hipStream_t>(stream), h->dp, reinterpret_cast<float*>(h->buf.player_x), h->stride,
-                     h->n, n_steps, actions_dev, action_kind, ro, h->out);
+  using RollK = void (*)(S2DHot, const S2DRare*, float*, int64_t, int64_t, int, const void*, int, RolloutOut, StepOut);
+  static const RollK table[3][2] = {
+      {s2d_reach_rollout_kernel<S2D_MODE_DISCRETE, false>, s2d_reach_rollout_kernel<S2D_MODE_DISCRETE, true>},
+      {s2d_reach_rollout_kernel<S2D_MODE_CONT1, false>, s2d_reach_rollout_kernel<S2D_MODE_CONT1, true>},
+      {s2d_reach_rollout_kernel<S2D_MODE_TURN4, false>, s2d_reach_rollout_kernel<S2D_MODE_TURN4, true>}};
+  hipLaunchKernelGGL(table[h->mode][h->noise ? 1 : 0], dim3(grid_for(h->n)), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), h->hot, h->rare_dev,
+                     reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, n_steps, actions_dev, action_kind,
+                     ro, h->out);
   HIP_TRY(hipGetLastError());
   h->last_kernel = "s2d_reach_rollout_kernel";
   return S2D_OK;

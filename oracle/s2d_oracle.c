@@ -42,6 +42,14 @@ typedef float REAL;
 
 #define API __attribute__((visibility("default")))
 
+/* x / c for a constant c.  F64 (reference semantics): a true division.  F32 spec: one
+ * multiplication by the correctly rounded reciprocal `ic`. */
+#ifdef S2DO_F64
+#define DIVC(x, c, ic) ((x) / (c))
+#else
+#define DIVC(x, c, ic) ((x) * (ic))
+#endif
+
 /* ======================================================================================
  * Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11).
  * Counter layout of this project:
@@ -91,6 +99,7 @@ static REAL atan2_deg(REAL y, REAL x) {
   if (x == 0.0 && y == 0.0) return 0.0;
   return atan2(y, x) * RAD2DEG;
 }
+static REAL sq2(REAL x, REAL y) { return x * x + y * y; }
 static REAL hypot2(REAL x, REAL y) { return sqrt(x * x + y * y); }
 static REAL exp_r(REAL x) { return exp(x); }
 #else
@@ -116,12 +125,12 @@ static REAL atan2_deg(REAL y, REAL x) {
   float ax = fabsf(x), ay = fabsf(y);
   float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
   if (mx == 0.0f) return 0.0f;
-  float t = mn / mx;
-  float base = 0.0f;
-  if (t > 0.41421356237f) {
-    t = (t - 1.0f) / (t + 1.0f);
-    base = 45.0f;
-  }
+  /* one division: atan(mn/mx) = 45deg + atan((mn-mx)/(mn+mx)) above tan(pi/8) */
+  int hi = mn > 0.41421356237f * mx;
+  float num = hi ? mn - mx : mn;
+  float den = hi ? mn + mx : mx;
+  float base = hi ? 45.0f : 0.0f;
+  float t = num / den;
   float z = t * t;
   float p = fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f);
   p = fmaf(z, p, 1.99777106478e-1f);
@@ -133,6 +142,7 @@ static REAL atan2_deg(REAL y, REAL x) {
   if (y < 0.0f) a = -a;
   return a;
 }
+static REAL sq2(REAL x, REAL y) { return fmaf(x, x, y * y); }
 static REAL hypot2(REAL x, REAL y) { return sqrtf(fmaf(x, x, y * y)); }
 static REAL exp_r(REAL x) {
   float k = rintf(x * 1.44269504088896341f);
@@ -178,6 +188,9 @@ typedef struct P {
   REAL dash_angle_step, side_dash_rate, back_dash_rate, max_moment, min_moment;
   REAL ball_size, ball_decay, ball_rand, ball_speed_max;
   REAL collision_vel_rate;
+  /* derived once (host, double -> REAL) */
+  REAL inv_half_l, inv_half_w, inv_dash_angle_step, player_accel_max2, player_speed_max2, ball_speed_max2;
+  REAL rsum, rsum2, act_scale;
   /* task */
   int change_ball_position, change_ball_velocity, max_steps, use_continuous, n_actions, use_turning;
   REAL ball_position_x, ball_position_y, ball_speed, ball_direction, min_distance_to_ball;
@@ -212,6 +225,13 @@ static void params_from_config(const S2DConfig *c, P *p) {
   p->ball_size = (REAL)s->ball_size; p->ball_decay = (REAL)s->ball_decay;
   p->ball_rand = (REAL)s->ball_rand; p->ball_speed_max = (REAL)s->ball_speed_max;
   p->collision_vel_rate = (REAL)s->collision_vel_rate;
+  p->inv_half_l = (REAL)(1.0 / s->pitch_half_length); p->inv_half_w = (REAL)(1.0 / s->pitch_half_width);
+  p->inv_dash_angle_step = s->dash_angle_step > 0 ? (REAL)(1.0 / s->dash_angle_step) : R(0.0);
+  p->player_accel_max2 = p->player_accel_max * p->player_accel_max;
+  p->player_speed_max2 = p->player_speed_max * p->player_speed_max;
+  p->ball_speed_max2 = p->ball_speed_max * p->ball_speed_max;
+  p->rsum = p->player_size + p->ball_size; p->rsum2 = p->rsum * p->rsum;
+  p->act_scale = (REAL)(360.0 / (double)(t->action_space_size > 0 ? t->action_space_size : 1));
   p->change_ball_position = t->change_ball_position; p->change_ball_velocity = t->change_ball_velocity;
   p->max_steps = t->max_steps; p->use_continuous = t->use_continuous_action;
   p->n_actions = t->action_space_size; p->use_turning = t->use_turning;
@@ -245,9 +265,14 @@ static void action_map(const P *p, const REAL *a, REAL u, int *cmd, REAL *power,
       *cmd = S2D_CMD_DASH; *power = R(100.0); *dir = a[0] * R(180.0);
     }
   } else {                     /* :84-85  Python float modulo: result has the sign of the divisor */
+#ifdef S2DO_F64
     REAL t = a[0] * R(360.0) / (REAL)p->n_actions;
     REAL m = R(fmod)(t, R(360.0));
     if (m < R(0.0)) m += R(360.0);
+#else
+    REAL t = a[0] * p->act_scale;                                 /* act_scale = 360 / n */
+    REAL m = t - R(360.0) * floorf(t * 0.002777777777777778f);   /* floor-mod; identity for 0 <= a < n */
+#endif
     *cmd = S2D_CMD_DASH; *power = R(100.0); *dir = m - R(180.0);
   }
 }
@@ -271,16 +296,16 @@ static void observation(const P *p, REAL bx, REAL by, REAL bvx, REAL bvy, REAL p
   REAL player_body = norm_deg(body);                       /* :94 */
   REAL player_to_ball = atan2_deg(by - py, bx - px);       /* :95 */
   REAL rel = norm_deg(player_to_ball - player_body);       /* :96 */
-  obs[0] = rel / R(180.0);                                 /* :98 */
-  obs[1] = player_body / R(180.0);
-  obs[2] = px / p->half_l;                                 /* 52.5 */
-  obs[3] = py / p->half_w;                                 /* 34.0 */
-  obs[4] = bx / p->half_l;
-  obs[5] = by / p->half_w;
-  obs[6] = ball_speed / R(3.0);
-  obs[7] = ball_direction / R(360.0);
-  obs[8] = bvx / R(3.0);
-  obs[9] = bvy / R(3.0);                                   /* :107 */
+  obs[0] = DIVC(rel, R(180.0), 0.005555555555555556f);           /* :98 */
+  obs[1] = DIVC(player_body, R(180.0), 0.005555555555555556f);
+  obs[2] = DIVC(px, p->half_l, p->inv_half_l);                    /* 52.5 */
+  obs[3] = DIVC(py, p->half_w, p->inv_half_w);                    /* 34.0 */
+  obs[4] = DIVC(bx, p->half_l, p->inv_half_l);
+  obs[5] = DIVC(by, p->half_w, p->inv_half_w);
+  obs[6] = DIVC(ball_speed, R(3.0), 0.3333333333333333f);
+  obs[7] = DIVC(ball_direction, R(360.0), 0.002777777777777778f);
+  obs[8] = DIVC(bvx, R(3.0), 0.3333333333333333f);
+  obs[9] = DIVC(bvy, R(3.0), 0.3333333333333333f);               /* :107 */
 }
 
 API void s2do_observation(const S2DConfig *cfg, const double *in7, double *obs10) {
@@ -301,10 +326,9 @@ static void check_trainer(const P *p, REAL bx, REAL by, REAL px, REAL py, REAL b
   REAL ball_direction = atan2_deg(dy, dx);                              /* :123 */
   REAL diff = norm_deg(ball_direction - player_body);                   /* :124 */
   int d = 0, res = S2D_RESULT_NONE;
-  REAL r = R(0.0);
   REAL distance_reward = *carry_dist - distance_to_ball;                /* :130 */
-  r += distance_reward;
-  REAL angle_reward = (R(fabs)(norm_deg(*carry_angle)) - R(fabs)(diff)) / R(180.0); /* :133 */
+  REAL r = distance_reward;                                             /* :128,131  0.0 + x */
+  REAL angle_reward = DIVC(R(fabs)(norm_deg(*carry_angle)) - R(fabs)(diff), R(180.0), 0.005555555555555556f); /* :133 */
   r += angle_reward;
   if (distance_to_ball < p->min_distance_to_ball) { d = 1; r += R(10.0); res = S2D_RESULT_GOAL; }   /* :137-140 */
   if (R(fabs)(px) > p->half_l || R(fabs)(py) > p->half_w) { d = 1; r -= R(-10.0); res = S2D_RESULT_OUT; } /* :142-145 (+10, quirk) */
@@ -421,7 +445,7 @@ static REAL clampr(REAL v, REAL lo, REAL hi) { return v < lo ? lo : (v > hi ? hi
 static void cmd_dash(const P *p, Env *e, REAL power, REAL dir, REAL *ax, REAL *ay) {
   power = clampr(power, p->min_dash_power, p->max_dash_power);
   dir = clampr(dir, p->min_dash_angle, p->max_dash_angle);
-  if (p->dash_angle_step > R(0.0)) dir = p->dash_angle_step * R(rint)(dir / p->dash_angle_step);
+  if (p->dash_angle_step > R(0.0)) dir = p->dash_angle_step * R(rint)(DIVC(dir, p->dash_angle_step, p->inv_dash_angle_step));
   int back = power < R(0.0);
   REAL need = back ? power * R(-2.0) : power;
   REAL avail = e->stamina + p->extra_stamina;
@@ -431,15 +455,15 @@ static void cmd_dash(const P *p, Env *e, REAL power, REAL dir, REAL *ax, REAL *a
   power = back ? need / R(-2.0) : need;
   REAL ad = R(fabs)(dir);
   REAL dir_rate = ad > R(90.0)
-      ? p->back_dash_rate - ((p->back_dash_rate - p->side_dash_rate) * (R(1.0) - (ad - R(90.0)) / R(90.0)))
-      : p->side_dash_rate + ((R(1.0) - p->side_dash_rate) * (R(1.0) - ad / R(90.0)));
+      ? p->back_dash_rate - ((p->back_dash_rate - p->side_dash_rate) * (R(1.0) - DIVC(ad - R(90.0), R(90.0), 0.011111111111111112f)))
+      : p->side_dash_rate + ((R(1.0) - p->side_dash_rate) * (R(1.0) - DIVC(ad, R(90.0), 0.011111111111111112f)));
   dir_rate = clampr(dir_rate, R(0.0), R(1.0));
   REAL acc = R(fabs)(e->effort * power * dir_rate * p->dash_power_rate);
   if (back) dir += R(180.0);
   REAL sn, cs;
   sincos_deg(norm_deg(e->body + dir), &sn, &cs);
-  *ax += acc * cs;
-  *ay += acc * sn;
+  *ax = acc * cs;
+  *ay = acc * sn;
 }
 
 /* Player::turn -- appendix A "Turn(moment)"; `noise_u` in [0,1) or 0.5 for none */
@@ -451,18 +475,17 @@ static void cmd_turn(const P *p, Env *e, REAL moment, REAL noise_u) {
   e->body = norm_deg(e->body + f * moment / (R(1.0) + p->inertia_moment * speed));
 }
 
-/* MPObject::_inc for one object (accel clamp, vel += accel, speed clamp, noise, pos += vel) */
-static void obj_inc(REAL *x, REAL *y, REAL *vx, REAL *vy, REAL ax, REAL ay, REAL accel_max, REAL speed_max,
-                    int noise, REAL rnd, REAL u_mag, REAL u_ang) {
-  if (ax != R(0.0) || ay != R(0.0)) {
-    REAL a = hypot2(ax, ay);
-    if (a > accel_max) { REAL k = accel_max / a; ax *= k; ay *= k; }
+/* MPObject::_inc for one object (accel clamp, vel += accel, speed clamp, noise, pos += vel).
+ * The magnitude tests compare squares (|a|^2 > max^2), the sqrt is taken only when clamping. */
+static void obj_inc(REAL *x, REAL *y, REAL *vx, REAL *vy, int has_accel, REAL ax, REAL ay, REAL accel_max,
+                    REAL accel_max2, REAL speed_max, REAL speed_max2, int noise, REAL rnd, REAL u_mag, REAL u_ang) {
+  if (has_accel) {
+    REAL a2 = sq2(ax, ay);
+    if (a2 > accel_max2) { REAL k = accel_max / R(sqrt)(a2); ax *= k; ay *= k; }
     *vx += ax; *vy += ay;
   }
-  if (*vx != R(0.0) || *vy != R(0.0)) {
-    REAL s = hypot2(*vx, *vy);
-    if (s > speed_max) { REAL k = speed_max / s; *vx *= k; *vy *= k; }
-  }
+  REAL s2 = sq2(*vx, *vy);
+  if (s2 > speed_max2) { REAL k = speed_max / R(sqrt)(s2); *vx *= k; *vy *= k; }
   if (noise) {
     REAL s = hypot2(*vx, *vy);
     REAL mag = u_mag * (rnd * s);
@@ -477,9 +500,10 @@ static void obj_inc(REAL *x, REAL *y, REAL *vx, REAL *vy, REAL ax, REAL ay, REAL
  * midpoint to exact contact, both velocities *= collision_vel_rate (-0.1). */
 static void collide(const P *p, Env *e) {
   REAL dx = e->bx - e->px, dy = e->by - e->py;
-  REAL d = hypot2(dx, dy);
-  REAL rsum = p->player_size + p->ball_size;
-  if (d < rsum) {
+  REAL d2 = sq2(dx, dy);
+  REAL rsum = p->rsum;
+  if (d2 < p->rsum2) {
+    REAL d = R(sqrt)(d2);
     REAL ux, uy;
     if (d > R(0.0)) { ux = dx / d; uy = dy / d; } else { ux = R(1.0); uy = R(0.0); }
     REAL mx = (e->px + e->bx) * R(0.5), my = (e->py + e->by) * R(0.5);
@@ -522,10 +546,10 @@ static void sim_cycle(const P *p, Env *e, uint64_t gid, int cmd, REAL power, REA
   REAL ax = R(0.0), ay = R(0.0);
   if (cmd == S2D_CMD_DASH) cmd_dash(p, e, power, dir, &ax, &ay);
   else if (cmd == S2D_CMD_TURN) cmd_turn(p, e, dir, rnd_u01(nz2[0]));
-  obj_inc(&e->px, &e->py, &e->vx, &e->vy, ax, ay, p->player_accel_max, p->player_speed_max,
-          p->noise, p->player_rand, rnd_u01(nz[0]), rnd_u01(nz[1]));
-  obj_inc(&e->bx, &e->by, &e->bvx, &e->bvy, R(0.0), R(0.0), R(0.0), p->ball_speed_max,
-          p->noise, p->ball_rand, rnd_u01(nz[2]), rnd_u01(nz[3]));
+  obj_inc(&e->px, &e->py, &e->vx, &e->vy, cmd == S2D_CMD_DASH, ax, ay, p->player_accel_max, p->player_accel_max2,
+          p->player_speed_max, p->player_speed_max2, p->noise, p->player_rand, rnd_u01(nz[0]), rnd_u01(nz[1]));
+  obj_inc(&e->bx, &e->by, &e->bvx, &e->bvy, 0, R(0.0), R(0.0), R(0.0), R(0.0),
+          p->ball_speed_max, p->ball_speed_max2, p->noise, p->ball_rand, rnd_u01(nz[2]), rnd_u01(nz[3]));
   collide(p, e);
   e->cycle += 1;                                        /* referee: time += 1 */
   e->vx *= p->player_decay; e->vy *= p->player_decay;   /* _turn */

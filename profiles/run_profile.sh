@@ -1,0 +1,18 @@
+#!/bin/bash
+# Usage (on the GPU box, from the repo root): bash profiles/run_profile.sh <tag>
+# Produces gpurun_out/<tag>/ : bench lines for the three modes and rocprofv3 kernel stats
+# of the SAME bench command as the default (rollout) line.
+set -e
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py --steps 4096 --warmup 256 > $OUT/bench_rollout.json 2> $OUT/bench_rollout.err
+python bench.py --steps 2048 --warmup 128 --mode step --no-cpu-baseline > $OUT/bench_step.json 2> $OUT/bench_step.err
+python bench.py --steps 2048 --warmup 128 --mode graph --no-cpu-baseline > $OUT/bench_graph.json 2> $OUT/bench_graph.err
+python bench.py --steps 4096 --warmup 256 --envs 1048576 --no-cpu-baseline > $OUT/bench_rollout_1M.json 2> $OUT/bench_rollout_1M.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rollout -- python3 bench.py --steps 4096 --warmup 256 --no-cpu-baseline > $OUT/prof_rollout.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step -- python3 bench.py --steps 2048 --warmup 128 --mode step --no-cpu-baseline > $OUT/prof_step.log 2>&1
+find $OUT -name "*kernel_stats.csv" | while read f; do echo "== $f"; head -8 "$f"; done > $OUT/kernel_stats_summary.txt
+cat $OUT/bench_*.json
+cat $OUT/kernel_stats_summary.txt
