@@ -1,0 +1,166 @@
+"""Drop-in boundary on the GPU: the reference's own call patterns (dqn_stable_baselines3.py:
+36-56, reach_ball_env.py) against the HIP engine, checked with the oracle."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+KW = dict(O.DQN_KWARGS)      # kwargs of dqn_stable_baselines3.py:18-31
+
+
+def test_factory_single_env_flow_like_reference_script():
+    """env = EnvironmentFactory().create(...); obs = env.reset(); obs, r, done, info = env.step(a);
+    if done: env.reset()  -- types and values as the reference returns them."""
+    from sample_environments.environment_factory import EnvironmentFactory
+    env = EnvironmentFactory().create('reachball', render_mode=False, logger=None, log_dir='logs', **KW)
+    assert env.action_space.n == 16 and env.observation_space.shape == (10,)
+    assert env.max_steps == 200 and env.min_distance_to_ball == 5.0 and env.change_ball_velocity is True
+    orc = O.OracleEngine(O.make_config(auto_reset=0, **KW), 1, 'f32')
+    obs = env.reset()
+    o_obs = orc.reset()
+    assert isinstance(obs, np.ndarray) and obs.dtype == np.float64 and obs.shape == (10,)
+    assert np.array_equal(obs.astype(np.float32), o_obs[0])
+    rs = np.random.RandomState(0)
+    results = {'Goal': 0, 'Out': 0, 'Timeout': 0}
+    episodes = 0
+    for t in range(700):
+        a = int(rs.randint(16))
+        arg = (np.array(a), None) if t % 3 == 0 else a            # script passes model.predict()'s tuple (:48-49)
+        obs, reward, done, info = env.step(arg)
+        oo, orw, od, ores = orc.step(np.array([a], dtype=np.int32))
+        assert isinstance(reward, float) and isinstance(done, bool) and set(info) == {'result'}
+        assert np.array_equal(obs.astype(np.float32), oo[0]) and np.float32(reward) == orw[0] and done == bool(od[0])
+        assert info['result'] == (None, 'Goal', 'Out', 'Timeout')[int(ores[0])]
+        assert env.step_number == int(orc.state('step_number')[0])
+        if done:
+            assert info['result']
+            results[info['result']] += 1
+            episodes += 1
+            obs = env.reset()
+            assert np.array_equal(obs.astype(np.float32), orc.reset()[0])
+    assert episodes >= 3 and results['Timeout'] >= 1
+    st = env.latest_player_state
+    assert st.world_model.cycle == int(orc.state('cycle')[0])
+    assert st.world_model.self.stamina == float(orc.state('stamina')[0])
+    assert st.world_model.teammates[0].position.x == st.world_model.self.position.x
+    assert st.world_model.game_mode_type == 2 and st.world_model.stoped_cycle == 0      # PlayOn, bit-exact ints
+    env.close()
+
+
+def test_vec_env_tensor_surface_and_infos():
+    from sample_environments.environment_factory import EnvironmentFactory
+    n = 4096                                                     # BASELINE.json configs[1]
+    env = EnvironmentFactory().create_vec('reachball', n, device='cuda:0', **KW)
+    orc = O.OracleEngine(O.make_config(**KW), n, 'f32')
+    obs = env.reset(); orc.reset()
+    assert obs.shape == (n, 10) and obs.dtype == torch.float32 and obs.is_cuda
+    g = torch.Generator(device='cuda:0'); g.manual_seed(1)
+    fin = 0
+    for t in range(230):
+        a = torch.randint(0, 16, (n,), device='cuda:0', generator=g)          # int64, torch's default
+        obs, rew, done, info = env.step(a)
+        oo, orw, od, ores = orc.step(a.cpu().numpy())
+        assert torch.equal(obs.cpu(), torch.from_numpy(oo)) and torch.equal(rew.cpu(), torch.from_numpy(orw))
+        assert torch.equal(info['result'].cpu(), torch.from_numpy(ores))
+        m = od.astype(bool)
+        fin += int(m.sum())
+        if m.any():
+            assert np.array_equal(info['terminal_observation'].cpu().numpy()[m], orc.terminal_obs()[m])
+    assert fin > n // 2
+    infos = env.infos()
+    assert len(infos) == n and all(set(d) == {'result'} for d in infos[:5])
+    assert env.stats['env_steps'] == 230 * n and env.stats['Goal'] + env.stats['Out'] + env.stats['Timeout'] == fin
+    env.close()
+
+
+def test_world_model_tensor_dict():
+    from soccer2d_amd.vec_env import Soccer2DVecEnv
+    env = Soccer2DVecEnv(512, **KW)
+    env.reset(); env.rollout(25, with_obs=False)
+    wm = env.world_model()
+    torch.cuda.synchronize()
+    bx, by = wm['world_model.ball.position.x'].cpu().numpy(), wm['world_model.ball.position.y'].cpu().numpy()
+    px, py = wm['world_model.self.position.x'].cpu().numpy(), wm['world_model.self.position.y'].cpu().numpy()
+    assert wm['world_model.cycle'].dtype == torch.int32 and int(wm['world_model.cycle'].min()) >= 26
+    d = np.hypot(bx - px, by - py)
+    assert np.allclose(wm['world_model.ball.dist_from_self'].cpu().numpy(), d, rtol=3e-7)
+    ang = np.degrees(np.arctan2(by - py, bx - px))
+    got = wm['world_model.ball.angle_from_self'].cpu().numpy()
+    assert np.abs(((got - ang) + 180) % 360 - 180).max() < 5e-5
+    assert np.allclose(wm['world_model.ball.relative_position.x'].cpu().numpy(), bx - px)
+    assert np.allclose(wm['world_model.self.position.dist'].cpu().numpy(), np.hypot(px, py), rtol=3e-7)
+    assert wm['world_model.teammates.position.x'].shape == (512, 1)
+    assert wm['world_model.ball.position.x'].data_ptr() == env.engine.ball_x.data_ptr()      # zero-copy view
+    assert int(wm['world_model.game_mode_type'][0]) == 2
+    env.close()
+
+
+def test_sb3_vecenv_adapter_contract():
+    from soccer2d_amd.sb3_vec_env import S2DSB3VecEnv
+    from utils.info_collector_callback import InfoCollectorCallback
+    n = 256
+    venv = S2DSB3VecEnv(n, max_steps=20, **{k: v for k, v in KW.items() if k != 'max_steps'})
+    orc = O.OracleEngine(O.make_config(**dict(KW, max_steps=20)), n, 'f32')
+    obs = venv.reset(); orc.reset()
+    assert isinstance(obs, np.ndarray) and obs.shape == (n, 10) and obs.dtype == np.float32
+    cb = InfoCollectorCallback()
+    rs = np.random.RandomState(2)
+    total = 0
+    for t in range(60):
+        a = rs.randint(0, 16, n)
+        venv.step_async(a)
+        obs, rews, dones, infos = venv.step_wait()
+        oo, orw, od, ores = orc.step(a.astype(np.int64))
+        assert obs.dtype == np.float32 and rews.dtype == np.float32 and dones.dtype == bool and len(infos) == n
+        assert np.array_equal(obs, oo) and np.array_equal(rews, orw) and np.array_equal(dones, od.astype(bool))
+        for i in np.nonzero(dones)[0][:8]:
+            assert infos[i]['result'] in ('Goal', 'Out', 'Timeout')
+            assert np.array_equal(infos[i]['terminal_observation'], orc.terminal_obs()[i])
+            assert infos[i]['TimeLimit.truncated'] == (infos[i]['result'] == 'Timeout')
+        assert all(infos[i]['result'] is None for i in np.nonzero(~dones)[0][:8])
+        cb.locals = {'infos': infos}
+        cb._on_step()
+        total += int(dones.sum())
+    assert len(cb.infos) == total > n
+    g, o, tmo = cb.plot_print_results(None)
+    assert abs(np.mean(g) + np.mean(o) + np.mean(tmo) - 100) < 1e-6
+    venv.close()
+
+
+def test_state_dict_resume_is_exact():
+    from soccer2d_amd.vec_env import Soccer2DVecEnv
+    a = Soccer2DVecEnv(1000, noise=True, **KW)
+    a.reset(); a.rollout(40, with_obs=False)
+    sd = a.state_dict()
+    b = Soccer2DVecEnv(1000, noise=True, **KW)
+    b.load_state_dict(sd)
+    ra, rb = a.rollout(50), b.rollout(50)
+    torch.cuda.synchronize()
+    for k in ra:
+        assert torch.equal(ra[k], rb[k]), k
+
+
+def test_hipgraph_capture_of_step():
+    """s2d_step is capturable (no allocation / sync inside): a captured graph of 8 steps replays
+    to the same trajectory as 8 eager steps."""
+    from soccer2d_amd.vec_env import Soccer2DVecEnv
+    a, b = Soccer2DVecEnv(2048, **KW), Soccer2DVecEnv(2048, **KW)
+    a.reset(); b.reset()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        a.step(None)
+    torch.cuda.synchronize()
+    b.step(None)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(8):
+            a.step(None)
+    for _ in range(3):
+        g.replay()
+    for _ in range(24):
+        b.step(None)
+    torch.cuda.synchronize()
+    assert torch.equal(a.engine.arena[:a.engine.arena.numel() - 512], b.engine.arena[:b.engine.arena.numel() - 512])

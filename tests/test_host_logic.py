@@ -1,0 +1,120 @@
+"""CPU tests of the host-side logic around the C ABI: spaces, factory error behaviour, lazy
+infos, the InfoCollectorCallback mirror, shard arithmetic, and the N>1 path (world_size-2
+gloo): shard invariance + the rollout all-gather, with the oracle standing in for the GPU
+engine (the collective plumbing is what is under test here)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_spaces_match_reference_shapes():
+    from soccer2d_amd.spaces import reach_ball_spaces
+    act, obs = reach_ball_spaces(False, False, 16)
+    assert act.n == 16 and obs.shape == (10,) and obs.dtype == np.float32
+    act, _ = reach_ball_spaces(True, False)
+    assert act.shape == (1,) and float(act.low.min()) == -1 and float(act.high.max()) == 1
+    act, _ = reach_ball_spaces(True, True)
+    assert act.shape == (4,)
+
+
+def test_factory_errors_like_reference():
+    from sample_environments.environment_factory import EnvironmentFactory
+    with pytest.raises(ValueError, match='not found'):
+        EnvironmentFactory().create('no-such-env', None, None, None)
+    with pytest.raises(ValueError, match='not found'):
+        EnvironmentFactory().create_vec('no-such-env', 4)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            EnvironmentFactory().create('ReachBall', None, None, None)
+
+
+def test_lazy_infos_and_callback():
+    from soccer2d_amd.sb3_vec_env import LazyInfos
+    from utils.info_collector_callback import InfoCollectorCallback
+    codes = np.array([0, 1, 0, 3, 2, 0], dtype=np.uint8)
+    term = np.arange(60, dtype=np.float32).reshape(6, 10)
+    infos = LazyInfos(codes, term)
+    assert len(infos) == 6 and infos[0] == {'result': None}
+    assert infos[1]['result'] == 'Goal' and infos[3]['TimeLimit.truncated'] is True and infos[4]['TimeLimit.truncated'] is False
+    assert (infos[3]['terminal_observation'] == term[3]).all()
+    assert [d['result'] for d in infos] == [None, 'Goal', None, 'Timeout', 'Out', None]
+    cb = InfoCollectorCallback()
+    cb.locals = {'infos': list(infos)}
+    assert cb._on_step() is True                        # reference contract: info['result'] falsy -> skipped
+    assert [i['result'] for i in cb.infos] == ['Goal', 'Timeout', 'Out']
+    cb.on_infos(infos)                                  # lazy path: only finished envs are touched
+    cb.on_result_codes(torch.tensor([[0, 1], [1, 3]], dtype=torch.uint8))
+    res = cb.update_results_dict()
+    assert res['Goal'] == [pytest.approx(4 / 9 * 100)] and res['Timeout'] == [pytest.approx(3 / 9 * 100)]
+    cb.reset()
+    assert cb.infos == []
+
+
+def test_shard_range():
+    from soccer2d_amd.dist import shard_range
+    for n, w in ((65536 * 8, 8), (10, 3), (7, 7)):
+        parts = [shard_range(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+        for (o0, c0), (o1, _c1) in zip(parts, parts[1:]):
+            assert o0 + c0 == o1
+        assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 4, 4)
+
+
+def _worker(rank, world, port, n_global, T, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'gym-soccer-2d-env_amd'))
+    import oracle as O2
+    from soccer2d_amd.dist import all_gather_rollout, all_reduce_stats, shard_range
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    off, cnt = shard_range(n_global, rank, world)
+    cfg = O2.make_config(env_id_offset=off, noise=1, **O2.DQN_KWARGS)
+    eng = O2.OracleEngine(cfg, cnt, 'f32')
+    eng.reset()
+    ro = eng.rollout(T)
+    local = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ro.items()}
+    full = all_gather_rollout(local, time_major=True)
+    raw = all_gather_rollout(local, time_major=False)
+    stats = all_reduce_stats(torch.from_numpy(eng.stats().astype(np.int64)))
+    if rank == 0:
+        q.put(({k: v.numpy() for k, v in full.items()}, {k: tuple(v.shape) for k, v in raw.items()}, stats.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shards_and_all_gather():
+    """world_size 2: each rank simulates its shard, rollouts are all-gathered; the result is
+    identical to one process simulating the whole env range (no data-path collective needed
+    for the simulation itself)."""
+    import torch.multiprocessing as mp
+    n_global, T, world = 64, 40, 2
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, raw_shapes, stats = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = O.make_config(noise=1, **O.DQN_KWARGS)
+    whole = O.OracleEngine(cfg, n_global, 'f32')
+    whole.reset()
+    ref = whole.rollout(T)
+    for k in ('obs', 'action', 'reward', 'done', 'result'):
+        assert full[k].shape == ref[k].shape
+        assert np.array_equal(full[k].view(np.uint8), np.ascontiguousarray(ref[k]).view(np.uint8)), k
+    assert raw_shapes['obs'] == (2, T, n_global // 2, 10)
+    assert list(stats[:4]) == list(whole.stats()[:4].astype(np.int64))
