@@ -358,49 +358,53 @@ S2D_DEV void sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, 
 // ------------------------------------------------------------------ A5 + A6 reset
 // trainer_reset_actions + get_ball_velocity (reach_ball_env.py:170-218), then ONE cycle
 // with no body command (soccer_2d_env.py:186-197).  Philox RESET stream at (gid, cycle):
-// block 0 = {player x, player y, body, ball x}, block 1 = {ball y}, attempt k = block 2+k.
-#define S2D_MAX_VEL_TRIES 256
+// block 0 = {player x, player y, body, ball x}, block 1 = {ball y, speed0, dir0, -}, then two
+// velocity candidates per block.
+#define S2D_MAX_VEL_TRIES 255
 template <bool NOISE>
 S2D_DEV void env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo,
-                                       uint32_t gid_hi) {
+                       uint32_t gid_hi) {
+  const S2DRare r = *rp;                                 // one bulk scalar load for the whole path
   uint32_t cyc = (uint32_t)e.cycle;
   U4 w = s2d_draw(p, gid_lo, gid_hi, cyc, S2D_ST_RESET, 0);
+  U4 w1 = s2d_draw(p, gid_lo, gid_hi, cyc, S2D_ST_RESET, 1);
   float px = (float)(-50 + rnd_below(w.x, 101));         // :173
   float py = (float)(-30 + rnd_below(w.y, 61));          // :174
   float body = (float)rnd_below(w.z, 361);               // :175
-  float bx, by;
-  if (rp->change_ball_position) {                        // :176-181
+  float bx = r.ball_position_x, by = r.ball_position_y;
+  if (r.change_ball_position) {                          // :176-181
     bx = (float)(-50 + rnd_below(w.w, 101));
-    U4 w1 = s2d_draw(p, gid_lo, gid_hi, cyc, S2D_ST_RESET, 1);
     by = (float)(-30 + rnd_below(w1.x, 61));
-  } else {
-    bx = rp->ball_position_x; by = rp->ball_position_y;
   }
   float bvx = 0.0f, bvy = 0.0f;
-  if (rp->change_ball_velocity) {                        // :202-212
-    const float travel_factor = rp->travel_factor;
+  if (r.change_ball_velocity) {                          // :202-212
     bool ok = false;
+    uint32_t ws = w1.y, wd = w1.z;                       // try 0 rides in block 1
+    U4 wb{0, 0, 0, 0};
     for (int k = 0; k < S2D_MAX_VEL_TRIES && !ok; ++k) {  // bounded: every lane leaves the loop
-      U4 wv = s2d_draw(p, gid_lo, gid_hi, cyc, S2D_ST_RESET, 2 + k);
-      float speed = rnd_u01(wv.x) * 3.0f;
-      float dir = (float)rnd_below(wv.y, 361);
+      if (k >= 1) {                                      // two candidates per Philox call
+        if ((k - 1) & 1) { ws = wb.z; wd = wb.w; }
+        else { wb = s2d_draw(p, gid_lo, gid_hi, cyc, S2D_ST_RESET, 2 + ((k - 1) >> 1)); ws = wb.x; wd = wb.y; }
+      }
+      float speed = rnd_u01(ws) * 3.0f;
+      float dir = (float)rnd_below(wd, 361);
       float sn, cs;
       sincos_deg(dir, sn, cs);
       bvx = speed * cs; bvy = speed * sn;
-      float travel = speed * travel_factor;
+      float travel = speed * r.travel_factor;
       float tx = bx + travel * cs, ty = by + travel * sn;
       if (fabsf(tx) <= p.half_l && fabsf(ty) <= p.half_w) ok = true;
     }
     if (!ok) { bvx = 0.0f; bvy = 0.0f; }
   } else {                                               // :213-216
     float sn, cs;
-    sincos_deg(rp->ball_direction, sn, cs);
-    bvx = rp->ball_speed * cs; bvy = rp->ball_speed * sn;
+    sincos_deg(r.ball_direction, sn, cs);
+    bvx = r.ball_speed * cs; bvy = r.ball_speed * sn;
   }
   e.step_number = 0;                                     // :172
   e.bx = bx; e.by = by; e.bvx = bvx; e.bvy = bvy;
   e.px = px; e.py = py; e.body = norm_deg(body); e.vx = 0.0f; e.vy = 0.0f;
-  e.stamina = p.stamina_max; e.recovery = rp->recover_init;
+  e.stamina = p.stamina_max; e.recovery = r.recover_init;
   e.effort = p.effort_init; e.capacity = p.stamina_capacity;
   sim_cycle<NOISE, false>(p, rp, e, gid_lo, gid_hi, S2D_CMD_NONE, 0.0f, 0.0f);
 }

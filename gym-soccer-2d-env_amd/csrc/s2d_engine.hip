@@ -20,7 +20,10 @@
 
 #define S2D_API extern "C" __attribute__((visibility("default")))
 
-static constexpr int kBlock = 256;
+#ifndef S2D_BLOCK
+#define S2D_BLOCK 256
+#endif
+static constexpr int kBlock = S2D_BLOCK;
 static constexpr int kWave = 64;
 static constexpr int kWavesPerBlock = kBlock / kWave;
 static constexpr int kObsTile = kWave * S2D_OBS_DIM;  // 640 floats per wave
@@ -235,13 +238,19 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p, con
     env_load(e, S, stride, i);
     uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
     gl = (uint32_t)gid; gh = (uint32_t)(gid >> 32);
+    // Consume every loaded word once BEFORE the loop: the s_waitcnt for the 17 prologue loads
+    // is then placed here and not inside the loop body, where (vmcnt being in-order) it would
+    // also wait for the previous iteration's stores to be acknowledged.
+    asm volatile("" ::"v"(e.px), "v"(e.py), "v"(e.vx), "v"(e.vy), "v"(e.body), "v"(e.stamina), "v"(e.effort),
+                 "v"(e.recovery), "v"(e.capacity), "v"(e.bx), "v"(e.by), "v"(e.bvx), "v"(e.bvy), "v"(e.prev_dist),
+                 "v"(e.prev_angle), "v"(e.step_number), "v"(e.cycle));
   }
   ObsOut ob;
   float reward = 0.0f, dir = 0.0f; int done = 0, res = 0, cmd = 0;
   unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
   float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
-  for (int t = 0; t < n_steps; ++t) {
-    const int64_t row = (int64_t)t * n;
+  int64_t row = 0;
+  for (int t = 0; t < n_steps; ++t, row += n) {
     res = 0;
     if (active) {
       Action4 a = fetch_action<MODE>(p, actions, kind, row + i, gl, gh, (uint32_t)e.cycle);

@@ -363,7 +363,6 @@ static uint32_t src_word(DrawSrc *s) {
   draw(s->seed, s->gid, s->cycle, ST_RESET, (uint32_t)(s->pos >> 2), w);
   return w[(s->pos++) & 3];
 }
-static void src_skip_to_block(DrawSrc *s, int block) { s->pos = block * 4; }
 /* random.randint(lo, hi), inclusive */
 static int src_randint(DrawSrc *s, int lo, int hi) {
   if (s->rec) { if (s->i_rec >= s->n_rec) { s->underflow = 1; return lo; } return (int)s->rec[s->i_rec++]; }
@@ -375,13 +374,13 @@ static REAL src_random(DrawSrc *s) {
   return rnd_u01(src_word(s));
 }
 
-#define S2DO_MAX_VEL_TRIES 256
+#define S2DO_MAX_VEL_TRIES 255
 
 typedef struct ResetDraw { REAL px, py, body, bx, by, bvx, bvy; int tries; } ResetDraw;
 
 static void reset_sample(const P *p, DrawSrc *s, ResetDraw *o) {
-  /* Philox layout: block 0 = {player x, player y, body, ball x}, block 1 = {ball y},
-   * velocity attempt k = block 2+k {speed, dir}.  Same ORDER as the reference's draws. */
+  /* Philox layout: block 0 = {player x, player y, body, ball x}, block 1 = {ball y, speed0,
+   * dir0, -}, later velocity attempts two per block.  Same ORDER as the reference's draws. */
   o->px = (REAL)src_randint(s, -50, 50);                 /* :173 */
   o->py = (REAL)src_randint(s, -30, 30);                 /* :174 */
   o->body = (REAL)src_randint(s, 0, 360);                /* :175 */
@@ -397,7 +396,9 @@ static void reset_sample(const P *p, DrawSrc *s, ResetDraw *o) {
     REAL vx = R(0.0), vy = R(0.0);
     int ok = 0;
     for (int k = 0; k < S2DO_MAX_VEL_TRIES && !ok; ++k) {
-      if (!s->rec) src_skip_to_block(s, 2 + k);
+      /* Philox word positions: try 0 = block 1 words {1,2}; try k>=1 = block 2+(k-1)/2,
+       * words {0,1} (odd k) or {2,3} (even k): two candidates per Philox call */
+      if (!s->rec) s->pos = k == 0 ? 5 : 4 * (2 + (k - 1) / 2) + 2 * ((k - 1) & 1);
       REAL speed = src_random(s) * R(3.0);               /* :204 */
       REAL dir = (REAL)src_randint(s, 0, 360);           /* :205 */
       if (s->rec && s->underflow) break;
@@ -409,7 +410,7 @@ static void reset_sample(const P *p, DrawSrc *s, ResetDraw *o) {
       o->tries = k + 1;
       if (R(fabs)(tx) <= p->half_l && R(fabs)(ty) <= p->half_w) ok = 1; /* :211 */
     }
-    if (!ok) { vx = R(0.0); vy = R(0.0); }               /* cap reached (p < 1e-18): ball at rest */
+    if (!ok) { vx = R(0.0); vy = R(0.0); }               /* cap reached (p < 1e-70): ball at rest */
     o->bvx = vx; o->bvy = vy;
   } else {                                               /* :213-216 */
     REAL sn, cs;
