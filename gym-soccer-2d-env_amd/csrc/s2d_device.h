@@ -214,38 +214,61 @@ S2D_DEV void action_map(const S2DHot& p, const Action4& a, float u, int& cmd, fl
 // lines 94, 122 and 133 is the identity on them.
 struct ObsOut { float o[S2D_OBS_DIM]; };
 
-S2D_DEV void observe_and_check(const S2DHot& p, Env& e, ObsOut& ob, int& done, float& reward, int& result) {
-  float dx = e.bx - e.px, dy = e.by - e.py;
-  float ball_speed = hypot2(e.bvx, e.bvy);               // :91
-  float ball_direction = atan2_deg(e.bvy, e.bvx);        // :92
-  float player_body = e.body;                            // :94 / :122
+// The three pieces below are the same arithmetic in the same order whether they run in one
+// thread (observe_and_check) or are split between a simulating wave and an observing wave
+// (wave-specialised rollout kernel).
+enum { S2D_FLAG_GOAL = 1, S2D_FLAG_OUT = 2, S2D_FLAG_TIMEOUT = 4 };
+
+// distance + done conditions, reach_ball_env.py:121, 137, 142, 147
+S2D_DEV int judge(const S2DHot& p, float px, float py, float bx, float by, int step_number, float& dist) {
+  dist = hypot2(bx - px, by - py);                       // :121
+  int f = (dist < p.min_distance_to_ball) ? S2D_FLAG_GOAL : 0;                       // :137
+  f |= (fabsf(px) > p.half_l || fabsf(py) > p.half_w) ? S2D_FLAG_OUT : 0;            // :142
+  f |= (step_number > p.max_steps) ? S2D_FLAG_TIMEOUT : 0;                           // :147 strict >
+  return f;
+}
+// state_to_observation, reach_ball_env.py:87-111; returns the body->ball angle difference
+S2D_DEV float observe(const S2DHot& p, float px, float py, float body, float bx, float by, float bvx, float bvy,
+                      ObsOut& ob) {
+  float dx = bx - px, dy = by - py;
+  float ball_speed = hypot2(bvx, bvy);                   // :91
+  float ball_direction = atan2_deg(bvy, bvx);            // :92
   float player_to_ball = atan2_deg(dy, dx);              // :95 / :123
-  float rel = norm_deg(player_to_ball - player_body);    // :96 / :124
+  float rel = norm_deg(player_to_ball - body);           // :96 / :124
   ob.o[0] = rel * 0.005555555555555556f;                 // :98-107  (x/180, x/52.5, x/34, x/3, x/360)
-  ob.o[1] = player_body * 0.005555555555555556f;
-  ob.o[2] = e.px * p.inv_half_l;
-  ob.o[3] = e.py * p.inv_half_w;
-  ob.o[4] = e.bx * p.inv_half_l;
-  ob.o[5] = e.by * p.inv_half_w;
+  ob.o[1] = body * 0.005555555555555556f;
+  ob.o[2] = px * p.inv_half_l;
+  ob.o[3] = py * p.inv_half_w;
+  ob.o[4] = bx * p.inv_half_l;
+  ob.o[5] = by * p.inv_half_w;
   ob.o[6] = ball_speed * 0.3333333333333333f;
   ob.o[7] = ball_direction * 0.002777777777777778f;
-  ob.o[8] = e.bvx * 0.3333333333333333f;
-  ob.o[9] = e.bvy * 0.3333333333333333f;
-  float distance_to_ball = hypot2(dx, dy);               // :121
-  float r = e.prev_dist - distance_to_ball;              // :130-131
-  r += (fabsf(e.prev_angle) - fabsf(rel)) * 0.005555555555555556f;   // :133-134
-  bool goal = distance_to_ball < p.min_distance_to_ball;                  // :137
-  bool out = fabsf(e.px) > p.half_l || fabsf(e.py) > p.half_w;            // :142
-  bool tmo = e.step_number > p.max_steps;                                 // :147 strict >
-  r = goal ? r + 10.0f : r;                              // :139
-  r = out ? r - -10.0f : r;                              // :144 (+10, quirk kept)
-  r = tmo ? r - 5.0f : r;                                // :149
-  int res = goal ? S2D_RESULT_GOAL : S2D_RESULT_NONE;    // later label overwrites earlier
-  res = out ? S2D_RESULT_OUT : res;
-  res = tmo ? S2D_RESULT_TIMEOUT : res;
-  e.prev_dist = distance_to_ball;                        // :158
+  ob.o[8] = bvx * 0.3333333333333333f;
+  ob.o[9] = bvy * 0.3333333333333333f;
+  return rel;
+}
+// reward and label of check_trainer_observation, reach_ball_env.py:128-150
+S2D_DEV float reward_of(float prev_dist, float prev_angle, float dist, float rel, int flags, int& result) {
+  float r = prev_dist - dist;                            // :130-131
+  r += (fabsf(prev_angle) - fabsf(rel)) * 0.005555555555555556f;   // :133-134
+  r = (flags & S2D_FLAG_GOAL) ? r + 10.0f : r;           // :139
+  r = (flags & S2D_FLAG_OUT) ? r - -10.0f : r;           // :144 (+10, quirk kept)
+  r = (flags & S2D_FLAG_TIMEOUT) ? r - 5.0f : r;         // :149
+  int res = (flags & S2D_FLAG_GOAL) ? S2D_RESULT_GOAL : S2D_RESULT_NONE;   // later label overwrites earlier
+  res = (flags & S2D_FLAG_OUT) ? S2D_RESULT_OUT : res;
+  res = (flags & S2D_FLAG_TIMEOUT) ? S2D_RESULT_TIMEOUT : res;
+  result = res;
+  return r;
+}
+
+S2D_DEV void observe_and_check(const S2DHot& p, Env& e, ObsOut& ob, int& done, float& reward, int& result) {
+  float rel = observe(p, e.px, e.py, e.body, e.bx, e.by, e.bvx, e.bvy, ob);
+  float dist;
+  int flags = judge(p, e.px, e.py, e.bx, e.by, e.step_number, dist);
+  reward = reward_of(e.prev_dist, e.prev_angle, dist, rel, flags, result);
+  e.prev_dist = dist;                                    // :158
   e.prev_angle = rel;                                    // :159
-  done = (goal | out | tmo) ? 1 : 0; reward = r; result = res;
+  done = flags ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ S: rcssserver cycle (EXT)

@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -27,6 +28,7 @@ static constexpr int kBlock = S2D_BLOCK;
 static constexpr int kWave = 64;
 static constexpr int kWavesPerBlock = kBlock / kWave;
 static constexpr int kObsTile = kWave * S2D_OBS_DIM;  // 640 floats per wave
+static constexpr int64_t kWsMaxEnvs = 262144;         // <= 1 wave/SIMD-ish batches use the wave-specialised rollout
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -287,6 +289,160 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p, con
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&o.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
 }
 
+// ------------------------------------------------------------------------------------------
+// Wave-specialised rollout (producer / consumer through LDS).
+//
+// At N = 65 536 the unified kernel leaves ONE wave per SIMD and is bound by its own VALU issue
+// (a lone wave issues one VALU per 4 cycles, a SIMD can take two waves' VALUs in that time).
+// Here every group of 64 envs is served by two waves of one workgroup:
+//   S-wave (simulate): action -> dash/turn -> integrate -> stamina -> done test -> reset
+//   O-wave (observe):  observation, reward, labels, LDS transposition, all rollout stores
+// The S-wave publishes a snapshot of step t in LDS (double-buffered) and goes on with step
+// t+1 while the O-wave processes step t: one s_barrier per cycle, no feedback edge (the
+// S-wave evaluates the done conditions itself, the O-wave owns the reward carry).  The
+// arithmetic is the same functions in the same order, so results stay bit-identical.
+// Used for small batches (resident waves double); at >= 4 waves per SIMD the unified kernel
+// is already issue-bound and is kept.
+enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_DIST, WS_FLAGS, WS_WORDS };
+static constexpr int kWsGroups = kBlock / (2 * kWave);   // env groups (of 64) per workgroup
+
+template <int MODE, bool NOISE>
+__global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p, const S2DRare* __restrict__ rp,
+                                                                      float* __restrict__ S, int64_t stride,
+                                                                      int64_t n, int n_steps,
+                                                                      const void* __restrict__ actions, int kind,
+                                                                      RolloutOut ro, StepOut o) {
+  __shared__ float snap[kWsGroups][2][WS_WORDS][kWave];            // step-t snapshot, double-buffered
+  __shared__ float post[kWsGroups][2][WS_DIST][kWave];             // post-reset state of finished envs
+  __shared__ __attribute__((aligned(16))) float tile[kWsGroups][kObsTile];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const bool sim_role = wv < kWsGroups;
+  const int g = sim_role ? wv : wv - kWsGroups;
+  const int64_t wave_first = ((int64_t)blockIdx.x * kWsGroups + g) * kWave;
+  const int64_t i = wave_first + lane;
+  const bool active = i < n;
+  int64_t rows = n - wave_first; rows = rows > kWave ? kWave : (rows < 0 ? 0 : rows);
+  const int valid = (int)rows * S2D_OBS_DIM;
+
+  if (sim_role) {
+    // ------------------------------------------------------------------ S-wave
+    Env e;
+    uint32_t gl = 0, gh = 0;
+    if (active) {
+      env_load(e, S, stride, i);
+      uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
+      gl = (uint32_t)gid; gh = (uint32_t)(gid >> 32);
+      asm volatile("" ::"v"(e.px), "v"(e.py), "v"(e.vx), "v"(e.vy), "v"(e.body), "v"(e.stamina), "v"(e.effort),
+                   "v"(e.recovery), "v"(e.capacity), "v"(e.bx), "v"(e.by), "v"(e.bvx), "v"(e.bvy),
+                   "v"(e.step_number), "v"(e.cycle));
+    }
+    float dir = 0.0f; int cmd = 0;
+    int64_t row = 0;
+    for (int t = 0; t < n_steps; ++t, row += n) {
+      const int b = t & 1;
+      if (active) {
+        Action4 a = fetch_action<MODE>(p, actions, kind, row + i, gl, gh, (uint32_t)e.cycle);
+        if (ro.action) {
+          if (MODE == S2D_MODE_DISCRETE) static_cast<int32_t*>(ro.action)[row + i] = (int32_t)a.a0;
+          else if (MODE == S2D_MODE_CONT1) static_cast<float*>(ro.action)[row + i] = a.a0;
+          else static_cast<float4*>(ro.action)[row + i] = make_float4(a.a0, a.a1, a.a2, a.a3);
+        }
+        e.step_number += 1;                                // reach_ball_env.py:55
+        float u = 0.0f;
+        if (MODE == S2D_MODE_TURN4) u = rnd_u01(s2d_draw(p, gl, gh, (uint32_t)e.cycle, S2D_ST_SELECT, 0).x);
+        float power;
+        action_map<MODE>(p, a, u, cmd, power, dir);
+        sim_cycle<NOISE, true>(p, rp, e, gl, gh, cmd, power, dir);
+        float dist;
+        int flags = judge(p, e.px, e.py, e.bx, e.by, e.step_number, dist);
+        snap[g][b][WS_PX][lane] = e.px; snap[g][b][WS_PY][lane] = e.py; snap[g][b][WS_BODY][lane] = e.body;
+        snap[g][b][WS_BX][lane] = e.bx; snap[g][b][WS_BY][lane] = e.by;
+        snap[g][b][WS_BVX][lane] = e.bvx; snap[g][b][WS_BVY][lane] = e.bvy;
+        snap[g][b][WS_DIST][lane] = dist; snap[g][b][WS_FLAGS][lane] = __int_as_float(flags);
+        if (flags && p.auto_reset) {                       // rare
+          env_reset<NOISE>(p, rp, e, gl, gh);
+          post[g][b][WS_PX][lane] = e.px; post[g][b][WS_PY][lane] = e.py; post[g][b][WS_BODY][lane] = e.body;
+          post[g][b][WS_BX][lane] = e.bx; post[g][b][WS_BY][lane] = e.by;
+          post[g][b][WS_BVX][lane] = e.bvx; post[g][b][WS_BVY][lane] = e.bvy;
+        }
+      }
+      __syncthreads();                                     // snapshot t published
+    }
+    if (active) {                                          // prev_dist / prev_angle belong to the O-wave
+      S[F_PX * stride + i] = e.px; S[F_PY * stride + i] = e.py;
+      S[F_VX * stride + i] = e.vx; S[F_VY * stride + i] = e.vy;
+      S[F_BODY * stride + i] = e.body;
+      S[F_STAMINA * stride + i] = e.stamina; S[F_EFFORT * stride + i] = e.effort;
+      S[F_RECOVERY * stride + i] = e.recovery; S[F_CAPACITY * stride + i] = e.capacity;
+      S[F_BX * stride + i] = e.bx; S[F_BY * stride + i] = e.by;
+      S[F_BVX * stride + i] = e.bvx; S[F_BVY * stride + i] = e.bvy;
+      S[F_STEP * stride + i] = __int_as_float(e.step_number);
+      S[F_CYCLE * stride + i] = __int_as_float(e.cycle);
+      o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
+    }
+  } else {
+    // ------------------------------------------------------------------ O-wave
+    float prev_dist = 0.0f, prev_angle = 0.0f;
+    if (active) {
+      prev_dist = S[F_PREV_DIST * stride + i]; prev_angle = S[F_PREV_ANGLE * stride + i];
+      asm volatile("" ::"v"(prev_dist), "v"(prev_angle));
+    }
+    ObsOut ob;
+    float reward = 0.0f; int res = 0, done = 0;
+    unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
+    int64_t row = 0;
+    for (int t = 0; t < n_steps; ++t, row += n) {
+      const int b = t & 1;
+      __syncthreads();                                     // wait for snapshot t
+      res = 0;
+      if (active) {
+        float px = snap[g][b][WS_PX][lane], py = snap[g][b][WS_PY][lane], body = snap[g][b][WS_BODY][lane];
+        float bx = snap[g][b][WS_BX][lane], by = snap[g][b][WS_BY][lane];
+        float bvx = snap[g][b][WS_BVX][lane], bvy = snap[g][b][WS_BVY][lane];
+        float dist = snap[g][b][WS_DIST][lane];
+        int flags = __float_as_int(snap[g][b][WS_FLAGS][lane]);
+        float rel = observe(p, px, py, body, bx, by, bvx, bvy, ob);
+        reward = reward_of(prev_dist, prev_angle, dist, rel, flags, res);
+        prev_dist = dist; prev_angle = rel;
+        done = flags ? 1 : 0;
+        if (flags && p.auto_reset) {                       // rare: terminal row, then the new episode's first obs
+#pragma unroll
+          for (int k = 0; k < S2D_OBS_DIM; ++k) term_row[k] = ob.o[k];
+          px = post[g][b][WS_PX][lane]; py = post[g][b][WS_PY][lane]; body = post[g][b][WS_BODY][lane];
+          bx = post[g][b][WS_BX][lane]; by = post[g][b][WS_BY][lane];
+          bvx = post[g][b][WS_BVX][lane]; bvy = post[g][b][WS_BVY][lane];
+          prev_angle = observe(p, px, py, body, bx, by, bvx, bvy, ob);    // reach_ball_env.py:166 carry seeded
+          prev_dist = hypot2(bx - px, by - py);
+        }
+        if (ro.reward) ro.reward[row + i] = reward;
+        if (ro.done) ro.done[row + i] = (uint8_t)done;
+        if (ro.result) ro.result[row + i] = (uint8_t)res;
+        cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
+      }
+      if (ro.obs && rows > 0) store_obs_tile(tile[g], ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
+    }
+    if (active) {
+      S[F_PREV_DIST * stride + i] = prev_dist; S[F_PREV_ANGLE * stride + i] = prev_angle;
+      o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
+    }
+    if (rows > 0) store_obs_tile(tile[g], ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, valid);
+    if (!active) { cnt1 = cnt2 = cnt3 = 0; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      cnt1 += __shfl_down(cnt1, off); cnt2 += __shfl_down(cnt2, off); cnt3 += __shfl_down(cnt3, off);
+    }
+    if (lane == 0) {
+      if (cnt1) atomicAdd(&o.stats[1], (unsigned long long)cnt1);
+      if (cnt2) atomicAdd(&o.stats[2], (unsigned long long)cnt2);
+      if (cnt3) atomicAdd(&o.stats[3], (unsigned long long)cnt3);
+    }
+    if (blockIdx.x == 0 && g == 0 && lane == 0)
+      atomicAdd(&o.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
+  }
+}
+
 // derived protobuf-mirroring fields (row T1; idl/service.proto:22-27, 68-86, 181-223)
 __global__ __launch_bounds__(kBlock) void s2d_world_model_kernel(const float* __restrict__ S, int64_t stride,
                                                                  int64_t n, S2DWorldModel w) {
@@ -352,6 +508,7 @@ struct S2DEngine {
   const S2DRare* rare_dev;
   int mode;      // S2D_MODE_*
   bool noise;
+  int rollout_ws;  // -1 auto (by batch size), 0 unified kernel, 1 wave-specialised kernel
   int64_t n, stride;
   int device;
   char* arena;
@@ -514,6 +671,8 @@ S2D_API int s2d_create(const S2DConfig* cfg, int64_t n_envs, int device, void* a
   h->mode = !cfg->task.use_continuous_action ? S2D_MODE_DISCRETE
                                              : (cfg->task.use_turning ? S2D_MODE_TURN4 : S2D_MODE_CONT1);
   h->noise = cfg->noise != 0;
+  h->rollout_ws = -1;
+  if (const char* v = std::getenv("S2D_ROLLOUT_WS")) h->rollout_ws = std::atoi(v) != 0 ? 1 : 0;
   if (arena_dev) {
     if (arena_bytes < L.total) { delete h; return fail(S2D_ENOMEM, "arena smaller than s2d_arena_bytes()"); }
     if (reinterpret_cast<uintptr_t>(arena_dev) & 255u) { delete h; return fail(S2D_EINVAL, "arena must be 256-byte aligned"); }
@@ -663,6 +822,22 @@ S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int a
       {s2d_reach_rollout_kernel<S2D_MODE_DISCRETE, false>, s2d_reach_rollout_kernel<S2D_MODE_DISCRETE, true>},
       {s2d_reach_rollout_kernel<S2D_MODE_CONT1, false>, s2d_reach_rollout_kernel<S2D_MODE_CONT1, true>},
       {s2d_reach_rollout_kernel<S2D_MODE_TURN4, false>, s2d_reach_rollout_kernel<S2D_MODE_TURN4, true>}};
+  static const RollK table_ws[3][2] = {
+      {s2d_reach_rollout_ws_kernel<S2D_MODE_DISCRETE, false>, s2d_reach_rollout_ws_kernel<S2D_MODE_DISCRETE, true>},
+      {s2d_reach_rollout_ws_kernel<S2D_MODE_CONT1, false>, s2d_reach_rollout_ws_kernel<S2D_MODE_CONT1, true>},
+      {s2d_reach_rollout_ws_kernel<S2D_MODE_TURN4, false>, s2d_reach_rollout_ws_kernel<S2D_MODE_TURN4, true>}};
+  // small batches: two waves per env group (simulate || observe) keep every SIMD at >= 2 waves
+  const bool ws = h->rollout_ws < 0 ? (h->n <= kWsMaxEnvs) : (h->rollout_ws != 0);
+  if (ws) {
+    const int per_block = kWsGroups * kWave;
+    hipLaunchKernelGGL(table_ws[h->mode][h->noise ? 1 : 0], dim3((unsigned)((h->n + per_block - 1) / per_block)),
+                       dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->hot, h->rare_dev,
+                       reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, n_steps, actions_dev, action_kind,
+                       ro, h->out);
+    HIP_TRY(hipGetLastError());
+    h->last_kernel = "s2d_reach_rollout_ws_kernel";
+    return S2D_OK;
+  }
   hipLaunchKernelGGL(table[h->mode][h->noise ? 1 : 0], dim3(grid_for(h->n)), dim3(kBlock), 0,
                      static_cast<hipStream_t>(stream), h->hot, h->rare_dev,
                      reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, n_steps, actions_dev, action_kind,

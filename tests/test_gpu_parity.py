@@ -170,10 +170,13 @@ def test_step_parity(name):
     assert st[0] == 250 * n and st[1:4].sum() == dones
 
 
+@pytest.mark.parametrize('ws', ['0', '1'])
 @pytest.mark.parametrize('name', ['dqn-discrete16', 'turning4', 'noise-on'])
-def test_random_policy_and_rollout_parity(name):
+def test_random_policy_and_rollout_parity(name, ws, monkeypatch):
     """In-kernel Philox policy (S2D_ACT_RANDOM): per-step launches == one fused rollout launch
-    == the oracle, bit for bit, including the emitted actions."""
+    (unified kernel ws=0 and wave-specialised kernel ws=1) == the oracle, bit for bit, including
+    the emitted actions."""
+    monkeypatch.setenv('S2D_ROLLOUT_WS', ws)
     kw = CONFIGS[name]
     n, T = 1000, 130
     a, b, orc = _engine(n, **dict(kw)), _engine(n, **dict(kw)), _oracle(n, **dict(kw))
@@ -191,10 +194,13 @@ def test_random_policy_and_rollout_parity(name):
         assert_same(done, ref['done'][t], f'{name} step t={t} done')
     assert_state_same(a, orc, f'{name} stepwise')
     assert (a.stats.cpu().numpy() == b.stats.cpu().numpy()).all()
+    assert b.kernel_name() == ('s2d_reach_rollout_ws_kernel' if ws == '1' else 's2d_reach_rollout_kernel')
 
 
-def test_rollout_with_caller_actions_and_odd_n():
+@pytest.mark.parametrize('ws', ['0', '1'])
+def test_rollout_with_caller_actions_and_odd_n(ws, monkeypatch):
     """[T][N] caller actions; odd N exercises the unaligned observation-store path."""
+    monkeypatch.setenv('S2D_ROLLOUT_WS', ws)
     kw = CONFIGS['dqn-discrete16']
     n, T = 333, 64
     eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
@@ -238,9 +244,11 @@ def test_shard_invariance_on_device():
     assert torch.equal(torch.cat([lo.obs, hi.obs]), whole.obs)
 
 
-def test_full_size_parity_and_properties():
+@pytest.mark.parametrize('ws', ['0', '1'])
+def test_full_size_parity_and_properties(ws, monkeypatch):
     """BASELINE.json sizes: 65 536 envs, dqn kwargs, 256 random-policy steps (> one full episode).
     Full bit-exact comparison with the oracle plus size-independent invariants."""
+    monkeypatch.setenv('S2D_ROLLOUT_WS', ws)
     kw = CONFIGS['dqn-discrete16']
     n, T = 65536, 256
     eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
