@@ -218,10 +218,10 @@ def main():
         steps_per_launch = 1
     if args.mode == 'rollout':
         alg_bytes_launch = n * (2 * STATE_BYTES + steps_per_launch * RECORD_BYTES)
-        kernel = 's2d_reach_rollout_kernel'
+        kernel = eng.kernel_name() or 's2d_reach_rollout_kernel'
     else:
         alg_bytes_launch = n * (2 * STATE_BYTES + 4 + RECORD_BYTES - 4)      # 186 B per env-step
-        kernel = 's2d_reach_step_kernel'
+        kernel = eng.kernel_name() or 's2d_reach_step_kernel'
     achieved = alg_bytes_launch / launch_s / 1e9
 
     total_steps = world * n * K

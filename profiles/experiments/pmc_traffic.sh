@@ -28,8 +28,8 @@ def avg(tag, counter, kern):
                 tot += float(r['Counter_Value']); n += 1
     return (tot / n if n else None), n
 rows = []
-for name, mode, fuse, envs, kern in (('rollout64k', 'rollout', 64, 65536, 'rollout_kernel'),
-                                     ('rollout1m', 'rollout', 64, 1048576, 'rollout_kernel'),
+for name, mode, fuse, envs, kern in (('rollout64k', 'rollout', 64, 65536, 'rollout_'),
+                                     ('rollout1m', 'rollout', 64, 1048576, 'rollout_'),
                                      ('step64k', 'step', 64, 65536, 'step_kernel')):
     f, nf = avg(name + '_fetch', 'FETCH_SIZE', kern)
     w, nw = avg(name + '_write', 'WRITE_SIZE', kern)
