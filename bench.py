@@ -47,6 +47,8 @@ def parse():
     ap.add_argument('--mode', choices=('rollout', 'step', 'graph'), default='rollout')
     ap.add_argument('--fuse', type=int, default=64, help='cycles per launch (rollout) / per graph (graph)')
     ap.add_argument('--noise', action='store_true', help='player_rand/ball_rand Philox noise on')
+    ap.add_argument('--variant', choices=('dqn', 'no-auto-reset', 'never-done'), default='dqn',
+                    help='experiments only: dqn = the benchmark workload; the others switch episode ends off')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-steps', type=int, default=0, help='0 = auto (about 10-20 s of CPU work)')
     return ap.parse_args()
@@ -131,7 +133,13 @@ def main():
 
     from soccer2d_amd.engine import Engine, make_config
     n = args.envs
-    cfg = make_config(seed=0x5EED, env_id_offset=rank * n, auto_reset=True, noise=args.noise, **DQN_KWARGS)
+    kw, sp, auto = dict(DQN_KWARGS), None, True
+    if args.variant == 'no-auto-reset':
+        auto = False
+    elif args.variant == 'never-done':
+        kw.update(max_steps=1000000, min_distance_to_ball=0.0)
+        sp = dict(pitch_half_length=1e6, pitch_half_width=1e6)
+    cfg = make_config(seed=0x5EED, env_id_offset=rank * n, auto_reset=auto, noise=args.noise, server_params=sp, **kw)
     eng = Engine(n, dev, cfg=cfg)
     eng.reset()
     T = max(1, args.fuse)
@@ -240,7 +248,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'reach_ball_env, {n} envs per GPU, random-policy rollouts '
                                    f'(BASELINE.json configs[2]; kwargs of dqn_stable_baselines3.py:18-31)',
-                       'envs_per_gpu': n, 'global_envs': world * n, 'mode': args.mode,
+                       'envs_per_gpu': n, 'global_envs': world * n, 'mode': args.mode, 'variant': args.variant,
                        'cycles_per_launch': steps_per_launch if args.mode != 'graph' else f'1 ({T} per graph replay)',
                        'noise': bool(args.noise), 'parallelism': f'env-shard x{world} (no collective)',
                        'launches': n_launches},

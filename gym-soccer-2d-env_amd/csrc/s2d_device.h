@@ -36,7 +36,7 @@ struct S2DHot {  // by value (kernarg -> SGPRs): everything the always-taken pat
   float player_decay, ball_decay;
   float player_accel_max2, player_speed_max2, ball_speed_max2, rsum2;
   float stamina_max, stamina_inc_max, extra_stamina, stamina_capacity;
-  float recover_dec_thr_value, recover_min, recover_dec;
+  float recover_init, recover_dec_thr_value, recover_min, recover_dec;
   float effort_init, effort_dec_thr_value, effort_min, effort_dec, effort_inc_thr_value, effort_inc;
   float dash_power_rate, max_dash_power, min_dash_power, max_dash_angle, min_dash_angle;
   float dash_angle_step, inv_dash_angle_step, side_dash_rate, back_dash_rate;
@@ -53,6 +53,39 @@ struct S2DRare {  // device memory, read inside rare branches only
   int change_ball_position, change_ball_velocity;
   int pad[3];
 };
+
+// The loop-invariant float parameters arrive in SGPRs (kernarg).  A rollout loop keeps ~45 of
+// them live next to pointers, exec masks and loop state, which exceeds the 102 SGPRs of a wave:
+// the compiler then spills to VGPR lanes or re-loads kernargs inside the loop (s_load +
+// s_waitcnt, ~200 cycles each).  VGPRs are plentiful here (60 of 512), so the floats are moved
+// into VGPRs once, behind an opaque v_mov the compiler cannot fold back into scalar form.
+S2D_DEV float to_vgpr(float x) {
+  float y;
+  asm("v_mov_b32 %0, %1" : "=v"(y) : "s"(x));
+  return y;
+}
+S2D_DEV S2DHot hot_in_vgprs(const S2DHot& p) {
+  S2DHot v = p;   // ints / seeds stay scalar (they feed scalar branches and Philox keys)
+  v.inv_half_l = to_vgpr(p.inv_half_l); v.inv_half_w = to_vgpr(p.inv_half_w);
+  v.half_l = to_vgpr(p.half_l); v.half_w = to_vgpr(p.half_w);
+  v.player_decay = to_vgpr(p.player_decay); v.ball_decay = to_vgpr(p.ball_decay);
+  v.player_accel_max2 = to_vgpr(p.player_accel_max2); v.player_speed_max2 = to_vgpr(p.player_speed_max2);
+  v.ball_speed_max2 = to_vgpr(p.ball_speed_max2); v.rsum2 = to_vgpr(p.rsum2);
+  v.stamina_max = to_vgpr(p.stamina_max); v.stamina_inc_max = to_vgpr(p.stamina_inc_max);
+  v.extra_stamina = to_vgpr(p.extra_stamina);
+  v.recover_dec_thr_value = to_vgpr(p.recover_dec_thr_value); v.recover_min = to_vgpr(p.recover_min);
+  v.recover_dec = to_vgpr(p.recover_dec);
+  v.effort_init = to_vgpr(p.effort_init); v.effort_dec_thr_value = to_vgpr(p.effort_dec_thr_value);
+  v.effort_min = to_vgpr(p.effort_min); v.effort_dec = to_vgpr(p.effort_dec);
+  v.effort_inc_thr_value = to_vgpr(p.effort_inc_thr_value); v.effort_inc = to_vgpr(p.effort_inc);
+  v.dash_power_rate = to_vgpr(p.dash_power_rate); v.max_dash_power = to_vgpr(p.max_dash_power);
+  v.min_dash_power = to_vgpr(p.min_dash_power); v.max_dash_angle = to_vgpr(p.max_dash_angle);
+  v.min_dash_angle = to_vgpr(p.min_dash_angle);
+  v.inv_dash_angle_step = to_vgpr(p.inv_dash_angle_step);
+  v.side_dash_rate = to_vgpr(p.side_dash_rate); v.back_dash_rate = to_vgpr(p.back_dash_rate);
+  v.min_distance_to_ball = to_vgpr(p.min_distance_to_ball); v.act_scale = to_vgpr(p.act_scale);
+  return v;
+}
 
 // ------------------------------------------------------------------ Philox4x32-10
 enum { S2D_ST_RESET = 0, S2D_ST_POLICY = 1, S2D_ST_SELECT = 2, S2D_ST_NOISE = 3 };
@@ -384,16 +417,21 @@ S2D_DEV void sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, 
 // block 0 = {player x, player y, body, ball x}, block 1 = {ball y, speed0, dir0, -}, then two
 // velocity candidates per block.
 #define S2D_MAX_VEL_TRIES 255
-template <bool NOISE>
-S2D_DEV void env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo,
-                       uint32_t gid_hi) {
-  const S2DRare r = *rp;                                 // one bulk scalar load for the whole path
-  uint32_t cyc = (uint32_t)e.cycle;
-  U4 w = s2d_draw(p, gid_lo, gid_hi, cyc, S2D_ST_RESET, 0);
-  U4 w1 = s2d_draw(p, gid_lo, gid_hi, cyc, S2D_ST_RESET, 1);
-  float px = (float)(-50 + rnd_below(w.x, 101));         // :173
-  float py = (float)(-30 + rnd_below(w.y, 61));          // :174
-  float body = (float)rnd_below(w.z, 361);               // :175
+struct ResetSample { float px, py, body, bx, by, bvx, bvy; };
+
+// RESET stream counter word = the cycle at which the CURRENT episode began
+// (cycle - step_number - 1: constant during an episode, unique per episode).  The sample of the
+// NEXT episode is therefore computable at any time during the current one, which lets the
+// rollout kernels prepare samples for many lanes at once instead of one lane at a time.
+S2D_DEV uint32_t reset_key(const Env& e) { return (uint32_t)(e.cycle - e.step_number - 1); }
+
+S2D_DEV ResetSample reset_sample(const S2DHot& p, const S2DRare& r, uint32_t gid_lo, uint32_t gid_hi, uint32_t c0) {
+  U4 w = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 0);
+  U4 w1 = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 1);
+  ResetSample o;
+  o.px = (float)(-50 + rnd_below(w.x, 101));             // :173
+  o.py = (float)(-30 + rnd_below(w.y, 61));              // :174
+  o.body = norm_deg((float)rnd_below(w.z, 361));         // :175 (move normalises the angle)
   float bx = r.ball_position_x, by = r.ball_position_y;
   if (r.change_ball_position) {                          // :176-181
     bx = (float)(-50 + rnd_below(w.w, 101));
@@ -407,7 +445,7 @@ S2D_DEV void env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, 
     for (int k = 0; k < S2D_MAX_VEL_TRIES && !ok; ++k) {  // bounded: every lane leaves the loop
       if (k >= 1) {                                      // two candidates per Philox call
         if ((k - 1) & 1) { ws = wb.z; wd = wb.w; }
-        else { wb = s2d_draw(p, gid_lo, gid_hi, cyc, S2D_ST_RESET, 2 + ((k - 1) >> 1)); ws = wb.x; wd = wb.y; }
+        else { wb = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 2 + ((k - 1) >> 1)); ws = wb.x; wd = wb.y; }
       }
       float speed = rnd_u01(ws) * 3.0f;
       float dir = (float)rnd_below(wd, 361);
@@ -424,10 +462,24 @@ S2D_DEV void env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, 
     sincos_deg(r.ball_direction, sn, cs);
     bvx = r.ball_speed * cs; bvy = r.ball_speed * sn;
   }
+  o.bx = bx; o.by = by; o.bvx = bvx; o.bvy = bvy;
+  return o;
+}
+// trainer (move ball) (move player) (recover), then the command-less cycle (soccer_2d_env.py:186-197)
+template <bool NOISE>
+S2D_DEV void reset_apply(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
+                         const ResetSample& o, float recover_init) {
   e.step_number = 0;                                     // :172
-  e.bx = bx; e.by = by; e.bvx = bvx; e.bvy = bvy;
-  e.px = px; e.py = py; e.body = norm_deg(body); e.vx = 0.0f; e.vy = 0.0f;
-  e.stamina = p.stamina_max; e.recovery = r.recover_init;
+  e.bx = o.bx; e.by = o.by; e.bvx = o.bvx; e.bvy = o.bvy;
+  e.px = o.px; e.py = o.py; e.body = o.body; e.vx = 0.0f; e.vy = 0.0f;
+  e.stamina = p.stamina_max; e.recovery = recover_init;
   e.effort = p.effort_init; e.capacity = p.stamina_capacity;
   sim_cycle<NOISE, false>(p, rp, e, gid_lo, gid_hi, S2D_CMD_NONE, 0.0f, 0.0f);
+}
+template <bool NOISE>
+S2D_DEV void env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo,
+                       uint32_t gid_hi) {
+  const S2DRare r = *rp;                                 // one bulk scalar load for the whole path
+  ResetSample o = reset_sample(p, r, gid_lo, gid_hi, reset_key(e));
+  reset_apply<NOISE>(p, rp, e, gid_lo, gid_hi, o, r.recover_init);
 }

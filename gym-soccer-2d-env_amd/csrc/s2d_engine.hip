@@ -21,6 +21,9 @@
 
 #define S2D_API extern "C" __attribute__((visibility("default")))
 
+#ifndef S2D_HACK
+#define S2D_HACK 0   // timing-only ablation builds (profiles/experiments); 0 in the product
+#endif
 #ifndef S2D_BLOCK
 #define S2D_BLOCK 256
 #endif
@@ -114,12 +117,33 @@ S2D_DEV Action4 fetch_action(const S2DHot& p, const void* __restrict__ actions, 
   return a;
 }
 
+// Prepared reset samples of one wave (LDS, struct-of-arrays over the 64 lanes).  The sample of
+// an env's NEXT episode depends only on (gid, cycle at which the current episode began), so a
+// rollout kernel draws them for many lanes at once -- a full wave at launch, then whenever
+// kRefillMin lanes have used theirs -- instead of running the Philox + rejection loop with one
+// or two active lanes each time an episode ends.
+struct PrepTile { float v[7][kWave]; };
+static constexpr int kRefillMin = 8;
+
+S2D_DEV void prep_fill(const S2DHot& p, const S2DRare* __restrict__ rp, PrepTile& t, int lane, const Env& e,
+                       uint32_t gid_lo, uint32_t gid_hi) {
+  const S2DRare r = *rp;
+  ResetSample o = reset_sample(p, r, gid_lo, gid_hi, reset_key(e));
+  t.v[0][lane] = o.px; t.v[1][lane] = o.py; t.v[2][lane] = o.body; t.v[3][lane] = o.bx;
+  t.v[4][lane] = o.by; t.v[5][lane] = o.bvx; t.v[6][lane] = o.bvy;
+}
+S2D_DEV ResetSample prep_take(const PrepTile& t, int lane) {
+  return ResetSample{t.v[0][lane], t.v[1][lane], t.v[2][lane], t.v[3][lane], t.v[4][lane], t.v[5][lane],
+                     t.v[6][lane]};
+}
+
 // A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269) for the env held in registers.
 // Returns the observation to hand back (post auto-reset), reward/done/result of the step.
+// prep == nullptr: the reset sample is drawn on the spot (per-step API).
 template <int MODE, bool NOISE>
 S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
                       const Action4& a, ObsOut& ob, float& reward, int& done, int& result, int& cmd, float& dir,
-                      float* __restrict__ terminal_row) {
+                      float* __restrict__ terminal_row, PrepTile* prep, int lane, bool& have_prep) {
   e.step_number += 1;                                    // reach_ball_env.py:55
   float u = 0.0f;
   if (MODE == S2D_MODE_TURN4) u = rnd_u01(s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_SELECT, 0).x);
@@ -130,7 +154,13 @@ S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, u
   if (done && p.auto_reset) {                            // rare: SB3 VecEnv convention
 #pragma unroll
     for (int k = 0; k < S2D_OBS_DIM; ++k) terminal_row[k] = ob.o[k];
-    env_reset<NOISE>(p, rp, e, gid_lo, gid_hi);
+    if (prep) {
+      if (!have_prep) prep_fill(p, rp, *prep, lane, e, gid_lo, gid_hi);   // episode shorter than the refill cadence
+      reset_apply<NOISE>(p, rp, e, gid_lo, gid_hi, prep_take(*prep, lane), p.recover_init);
+      have_prep = false;
+    } else {
+      env_reset<NOISE>(p, rp, e, gid_lo, gid_hi);
+    }
     int d2, r2; float w2;
     observe_and_check(p, e, ob, d2, w2, r2);             // reach_ball_env.py:166: carry seeded, outputs dropped
   }
@@ -201,7 +231,9 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
     uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
     Action4 a = fetch_action<MODE>(p, actions, kind, i, gl, gh, (uint32_t)e.cycle);
     float reward, dir; int done, cmd;
-    step_env<MODE, NOISE>(p, rp, e, gl, gh, a, ob, reward, done, res, cmd, dir, o.terminal_obs + i * S2D_OBS_DIM);
+    bool no_prep = false;
+    step_env<MODE, NOISE>(p, rp, e, gl, gh, a, ob, reward, done, res, cmd, dir, o.terminal_obs + i * S2D_OBS_DIM,
+                          nullptr, lane, no_prep);
     env_store(e, S, stride, i);
     o.reward[i] = reward;
     o.done[i] = (uint8_t)done;
@@ -222,11 +254,13 @@ struct RolloutOut {
 };
 
 template <int MODE, bool NOISE>
-__global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p, const S2DRare* __restrict__ rp,
+__global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
                                                                    float* __restrict__ S, int64_t stride, int64_t n,
                                                                    int n_steps, const void* __restrict__ actions,
                                                                    int kind, RolloutOut ro, StepOut o) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
+  __shared__ PrepTile prep[kWavesPerBlock];
+  const S2DHot p = hot_in_vgprs(p_sgpr);
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t wave_first = i - lane;
@@ -251,9 +285,14 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p, con
   float reward = 0.0f, dir = 0.0f; int done = 0, res = 0, cmd = 0;
   unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
   float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
+  bool have_prep = false;
+  if (active && p.auto_reset) { prep_fill(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }   // full wave
   int64_t row = 0;
   for (int t = 0; t < n_steps; ++t, row += n) {
     res = 0;
+    if (p.auto_reset && __popcll(__ballot(active && !have_prep)) >= kRefillMin) {   // batched refill
+      if (active && !have_prep) { prep_fill(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }
+    }
     if (active) {
       Action4 a = fetch_action<MODE>(p, actions, kind, row + i, gl, gh, (uint32_t)e.cycle);
       if (ro.action) {
@@ -261,7 +300,8 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p, con
         else if (MODE == S2D_MODE_CONT1) static_cast<float*>(ro.action)[row + i] = a.a0;
         else static_cast<float4*>(ro.action)[row + i] = make_float4(a.a0, a.a1, a.a2, a.a3);
       }
-      step_env<MODE, NOISE>(p, rp, e, gl, gh, a, ob, reward, done, res, cmd, dir, term_row);
+      step_env<MODE, NOISE>(p, rp, e, gl, gh, a, ob, reward, done, res, cmd, dir, term_row, &prep[wv], lane,
+                            have_prep);
       if (ro.reward) ro.reward[row + i] = reward;
       if (ro.done) ro.done[row + i] = (uint8_t)done;
       if (ro.result) ro.result[row + i] = (uint8_t)res;
@@ -307,7 +347,7 @@ enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_DIST, WS_FLAGS, W
 static constexpr int kWsGroups = kBlock / (2 * kWave);   // env groups (of 64) per workgroup
 
 template <int MODE, bool NOISE>
-__global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p, const S2DRare* __restrict__ rp,
+__global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
                                                                       float* __restrict__ S, int64_t stride,
                                                                       int64_t n, int n_steps,
                                                                       const void* __restrict__ actions, int kind,
@@ -315,6 +355,8 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p, 
   __shared__ float snap[kWsGroups][2][WS_WORDS][kWave];            // step-t snapshot, double-buffered
   __shared__ float post[kWsGroups][2][WS_DIST][kWave];             // post-reset state of finished envs
   __shared__ __attribute__((aligned(16))) float tile[kWsGroups][kObsTile];
+  __shared__ PrepTile prep[kWsGroups];
+  const S2DHot p = hot_in_vgprs(p_sgpr);
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const bool sim_role = wv < kWsGroups;
@@ -327,6 +369,9 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p, 
 
   if (sim_role) {
     // ------------------------------------------------------------------ S-wave
+#ifdef S2D_WS_PRIO
+    __builtin_amdgcn_s_setprio(S2D_WS_PRIO);               // the simulate wave is the critical path
+#endif
     Env e;
     uint32_t gl = 0, gh = 0;
     if (active) {
@@ -338,9 +383,17 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p, 
                    "v"(e.step_number), "v"(e.cycle));
     }
     float dir = 0.0f; int cmd = 0;
+    bool have_prep = false;
+    if (active && p.auto_reset) { prep_fill(p, rp, prep[g], lane, e, gl, gh); have_prep = true; }   // full wave
     int64_t row = 0;
     for (int t = 0; t < n_steps; ++t, row += n) {
       const int b = t & 1;
+      if (p.auto_reset && __popcll(__ballot(active && !have_prep)) >= kRefillMin) {   // batched refill
+#if S2D_HACK == 5
+        if (lane == 0) atomicAdd(&o.stats[4], 1ull);
+#endif
+        if (active && !have_prep) { prep_fill(p, rp, prep[g], lane, e, gl, gh); have_prep = true; }
+      }
       if (active) {
         Action4 a = fetch_action<MODE>(p, actions, kind, row + i, gl, gh, (uint32_t)e.cycle);
         if (ro.action) {
@@ -361,7 +414,15 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p, 
         snap[g][b][WS_BVX][lane] = e.bvx; snap[g][b][WS_BVY][lane] = e.bvy;
         snap[g][b][WS_DIST][lane] = dist; snap[g][b][WS_FLAGS][lane] = __int_as_float(flags);
         if (flags && p.auto_reset) {                       // rare
-          env_reset<NOISE>(p, rp, e, gl, gh);
+#if S2D_HACK == 5
+          if (!have_prep) atomicAdd(&o.stats[5], 1ull);
+          atomicAdd(&o.stats[6], 1ull);
+#endif
+#if S2D_HACK != 2
+          if (!have_prep) prep_fill(p, rp, prep[g], lane, e, gl, gh);
+          reset_apply<NOISE>(p, rp, e, gl, gh, prep_take(prep[g], lane), p.recover_init);
+#endif
+          have_prep = false;
           post[g][b][WS_PX][lane] = e.px; post[g][b][WS_PY][lane] = e.py; post[g][b][WS_BODY][lane] = e.body;
           post[g][b][WS_BX][lane] = e.bx; post[g][b][WS_BY][lane] = e.by;
           post[g][b][WS_BVX][lane] = e.bvx; post[g][b][WS_BVY][lane] = e.bvy;
@@ -407,9 +468,15 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p, 
         reward = reward_of(prev_dist, prev_angle, dist, rel, flags, res);
         prev_dist = dist; prev_angle = rel;
         done = flags ? 1 : 0;
+#if S2D_HACK == 1
+        if (false) {
+#else
         if (flags && p.auto_reset) {                       // rare: terminal row, then the new episode's first obs
+#endif
+#if S2D_HACK != 3
 #pragma unroll
           for (int k = 0; k < S2D_OBS_DIM; ++k) term_row[k] = ob.o[k];
+#endif
           px = post[g][b][WS_PX][lane]; py = post[g][b][WS_PY][lane]; body = post[g][b][WS_BODY][lane];
           bx = post[g][b][WS_BX][lane]; by = post[g][b][WS_BY][lane];
           bvx = post[g][b][WS_BVX][lane]; bvy = post[g][b][WS_BVY][lane];
@@ -607,6 +674,7 @@ static void dev_params_from_config(const S2DConfig& c, S2DHot& h, S2DRare& r) {
   h.ball_speed_max2 = bspeed_max * bspeed_max; h.rsum2 = rsum * rsum;
   h.stamina_max = (float)s.stamina_max; h.stamina_inc_max = (float)s.stamina_inc_max;
   h.extra_stamina = (float)s.extra_stamina; h.stamina_capacity = (float)s.stamina_capacity;
+  h.recover_init = (float)s.recover_init;
   h.recover_dec_thr_value = (float)(s.recover_dec_thr * s.stamina_max);
   h.recover_min = (float)s.recover_min; h.recover_dec = (float)s.recover_dec;
   h.effort_init = (float)s.effort_init;

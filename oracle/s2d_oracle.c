@@ -562,7 +562,10 @@ static void sim_cycle(const P *p, Env *e, uint64_t gid, int cmd, REAL power, REA
  * no body command (soccer_2d_env.py:186-197); carry is seeded (reach_ball_env.py:166). */
 static void env_reset(const P *p, Env *e, uint64_t gid, REAL *obs) {
   DrawSrc s; memset(&s, 0, sizeof s);
-  s.seed = p->seed; s.gid = gid; s.cycle = (uint32_t)e->cycle;
+  /* RESET stream counter word: the cycle at which the CURRENT episode began
+   * (= cycle - step_number - 1, constant during an episode, unique per episode), so the next
+   * episode's initial state is a function of data known from the episode's first cycle on. */
+  s.seed = p->seed; s.gid = gid; s.cycle = (uint32_t)(e->cycle - e->step_number - 1);
   ResetDraw o;
   reset_sample(p, &s, &o);
   e->step_number = 0;                                    /* :172 */

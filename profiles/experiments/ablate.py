@@ -37,6 +37,8 @@ def main():
         eng2 = Engine(n, 'cuda:0', cfg=make_config(server_params=dict(pitch_half_length=1e6, pitch_half_width=1e6), **kw)); eng2.reset()
         rows.append(('never done (no reset path taken)', timeit(eng2, T, reps)))
         rows.append(('never done + caller actions', timeit(eng2, T, reps, actions=acts)))
+        eng4 = Engine(n, 'cuda:0', cfg=make_config(auto_reset=False, **KW)); eng4.reset()
+        rows.append(('auto_reset off (dones flagged, no reset work)', timeit(eng4, T, reps)))
         eng3 = Engine(n, 'cuda:0', cfg=make_config(noise=True, **KW)); eng3.reset()
         rows.append(('noise on', timeit(eng3, T, reps)))
         for name, us in rows:
