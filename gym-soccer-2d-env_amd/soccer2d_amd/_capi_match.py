@@ -1,0 +1,69 @@
+"""ctypes mirror of include/s2d_match.h (11v11 match engine entry points of libs2d_hip.so)."""
+import ctypes as C
+
+from . import _capi
+
+MATCH_PLAYERS, MATCH_SLOTS, MATCH_BALL, MATCH_OBJ_WORDS = 22, 24, 22, 5
+MCMD_NONE, MCMD_DASH, MCMD_TURN, MCMD_KICK, MCMD_TACKLE = 0, 1, 2, 3, 4
+GM_TIME_OVER, GM_PLAY_ON, GM_KICK_OFF, GM_KICK_IN, GM_FREE_KICK, GM_CORNER_KICK, GM_GOAL_KICK, GM_OFF_SIDE = 1, 2, 3, 4, 5, 6, 7, 9
+GM_NAMES = {1: 'TimeOver', 2: 'PlayOn', 3: 'KickOff_', 4: 'KickIn_', 5: 'FreeKick_', 6: 'CornerKick_', 7: 'GoalKick_', 9: 'OffSide_'}
+
+
+class S2DMatchParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        'kick_power_rate', 'kickable_margin', 'kick_rand', 'max_power', 'min_power',
+        'tackle_dist', 'tackle_back_dist', 'tackle_width', 'tackle_power_rate',
+        'max_tackle_power', 'max_back_tackle_power',
+        'goal_width', 'offside_active_area_size', 'free_kick_distance')] + [(n, C.c_int32) for n in (
+            'tackle_cycles', 'half_time_cycles', 'nr_normal_halfs', 'drop_ball_time', 'use_offside', 'reserved0')]
+
+
+class S2DMatchConfig(C.Structure):
+    _fields_ = [('abi_version', C.c_uint32), ('struct_bytes', C.c_uint32),
+                ('sp', _capi.S2DServerParams), ('mp', S2DMatchParams),
+                ('seed', C.c_uint64), ('env_id_offset', C.c_int64),
+                ('auto_reset', C.c_int32), ('noise', C.c_int32), ('reserved', C.c_int32 * 4)]
+
+
+_F, _I, _U8 = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+# (name, ctypes type, torch dtype, per-env trailing shape; None = stats[8])
+MATCH_BUFFER_FIELDS = tuple(
+    [(n, _F, 'float32', (MATCH_SLOTS,)) for n in ('x', 'y', 'vx', 'vy', 'body', 'stamina', 'effort', 'recovery', 'stamina_capacity')]
+    + [('tackle_cycles', _I, 'int32', (MATCH_SLOTS,))]
+    + [(n, _I, 'int32', ()) for n in ('cycle', 'mode', 'mode_side', 'score_left', 'score_right', 'last_touch_side',
+                                      'setplay_timer', 'offside_mask')]
+    + [('reward_left', _F, 'float32', ()), ('done', _U8, 'uint8', ()),
+       ('nearest_left', _I, 'int32', ()), ('nearest_right', _I, 'int32', ()),
+       ('stats', C.POINTER(C.c_ulonglong), 'int64', None)])
+
+
+class S2DMatchBuffers(C.Structure):
+    _fields_ = [('n_envs', C.c_int64)] + [(n, t) for (n, t, _, _) in MATCH_BUFFER_FIELDS]
+
+
+class S2DMatchRollout(C.Structure):
+    _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('mode', C.c_void_p), ('done', C.c_void_p)]
+
+
+MATCH_PROTOTYPES = (
+    ('s2d_match_default_config', None, (C.POINTER(S2DMatchConfig),)),
+    ('s2d_match_validate_config', C.c_int, (C.POINTER(S2DMatchConfig),)),
+    ('s2d_match_arena_bytes', C.c_size_t, (C.POINTER(S2DMatchConfig), C.c_int64)),
+    ('s2d_match_create', C.c_int, (C.POINTER(S2DMatchConfig), C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                   C.POINTER(C.c_void_p))),
+    ('s2d_match_destroy', None, (C.c_void_p,)),
+    ('s2d_match_buffers', C.c_int, (C.c_void_p, C.POINTER(S2DMatchBuffers))),
+    ('s2d_match_buffer_offsets', C.c_int, (C.c_void_p, C.POINTER(C.c_int64), C.c_int)),
+    ('s2d_match_reset', C.c_int, (C.c_void_p, C.c_void_p, C.c_void_p)),
+    ('s2d_match_step', C.c_int, (C.c_void_p, C.c_void_p, C.c_void_p)),
+    ('s2d_match_rollout', C.c_int, (C.c_void_p, C.c_int, C.c_void_p, C.POINTER(S2DMatchRollout), C.c_void_p)),
+)
+
+
+def bind(lib):
+    """Attach restype/argtypes of the match entry points (idempotent)."""
+    for name, res, args in MATCH_PROTOTYPES:
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+    return lib

@@ -1,0 +1,105 @@
+/*
+ * s2d_match.h -- C ABI of the 11v11 full-match engine (BASELINE.json
+ * configs[3]: 22 players, kick / tackle / offside / stamina, thousands of lockstep matches).
+ * Same library (libs2d_hip.so), same conventions as s2d.h: plain C, device pointers,
+ * hipStream_t as void*, stream-ordered asynchronous launches, 0 / negative error codes.
+ *
+ * What it replaces in the reference: the rcssserver match itself behind Soccer2DEnv
+ * (soccer_2d_env.py:356-383 starts it; every State read at server.py:49-103 comes from it).
+ * The reference holds NO Python for an 11v11 task; the boundary mirrored here is therefore the
+ * protobuf schema: commands = PlayerAction {Dash, Turn, Kick, Tackle} (idl/service.proto:380-402),
+ * observations = WorldModel {ball, teammates[11], opponents[11], game_mode_type, scores, cycle}
+ * (idl/service.proto:144-175, 306-349), play modes = GameModeType (267-301).
+ * All match rules are rcssserver's (EXT): parity-unpinned.
+ */
+#ifndef S2D_MATCH_H_
+#define S2D_MATCH_H_
+
+#include "s2d.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2D_MATCH_PLAYERS 22      /* 0..10 left team (attacks +x), 11..21 right team */
+#define S2D_MATCH_SLOTS 24        /* per-env object slots in memory: 22 players, slot 22 = ball, 23 = pad */
+#define S2D_MATCH_BALL 22
+#define S2D_MATCH_OBJ_WORDS 5     /* observation row of one object: x, y, vx, vy, body */
+
+/* body commands, PlayerAction oneof members idl/service.proto:380-402 (catch/move: later) */
+enum { S2D_MCMD_NONE = 0, S2D_MCMD_DASH = 1, S2D_MCMD_TURN = 2, S2D_MCMD_KICK = 3, S2D_MCMD_TACKLE = 4 };
+/* GameModeType values used (idl/service.proto:267-301); the taking side is in mode_side */
+enum {
+  S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4, S2D_GM_FREE_KICK = 5,
+  S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_OFF_SIDE = 9
+};
+
+/* ServerParam fields the match needs beyond S2DServerParams (same names as idl/service.proto:
+ * 1435-1662); defaults = rcssserver stock values. */
+typedef struct S2DMatchParams {
+  double kick_power_rate, kickable_margin, kick_rand, max_power, min_power;        /* .027 .7 .1 100 -100 */
+  double tackle_dist, tackle_back_dist, tackle_width, tackle_power_rate;           /* 2 0 1.25 .027 */
+  double max_tackle_power, max_back_tackle_power;                                  /* 100 0 */
+  double goal_width, offside_active_area_size, free_kick_distance;                 /* 14.02 2.5 9.15 */
+  int32_t tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time;        /* 10 3000 2 100 */
+  int32_t use_offside, reserved0;                                                  /* 1 */
+} S2DMatchParams;
+
+typedef struct S2DMatchConfig {
+  uint32_t abi_version;   /* S2D_ABI_VERSION */
+  uint32_t struct_bytes;  /* sizeof(S2DMatchConfig) */
+  S2DServerParams sp;
+  S2DMatchParams mp;
+  uint64_t seed;
+  int64_t env_id_offset;
+  int32_t auto_reset;     /* 1: a finished match (TimeOver) restarts inside the same step */
+  int32_t noise;          /* 0: player_rand/ball_rand/kick_rand off; tackle success is always drawn */
+  int32_t reserved[4];
+} S2DMatchConfig;
+
+/* Device buffers.  Per-object planes are [N][24] (slot = lane of the env's half-wave);
+ * per-env arrays are [N]. */
+typedef struct S2DMatchBuffers {
+  int64_t n_envs;
+  float *x, *y, *vx, *vy, *body;                      /* players + ball (ball: body unused) */
+  float *stamina, *effort, *recovery, *stamina_capacity;
+  int32_t *tackle_cycles;                             /* >0: player frozen after a tackle */
+  int32_t *cycle, *mode, *mode_side, *score_left, *score_right;
+  int32_t *last_touch_side, *setplay_timer, *offside_mask;     /* bit i = player i flagged */
+  float *reward_left;      /* [N] +1 left goal, -1 right goal this cycle */
+  uint8_t *done;           /* [N] 1 when the match reached TimeOver this cycle */
+  int32_t *nearest_left, *nearest_right;              /* [N] index of the player closest to the ball, per team */
+  unsigned long long *stats;  /* [0] env-steps [1] goals left [2] goals right [3] matches finished
+                                 [4] kicks [5] tackles [6] offsides [7] ball-outs */
+} S2DMatchBuffers;
+
+typedef struct S2DMatchRollout {
+  float *obs;        /* [T][N][24][5] x,y,vx,vy,body after each cycle (slot 22 = ball) or NULL */
+  float *reward;     /* [T][N] or NULL */
+  int32_t *mode;     /* [T][N] or NULL */
+  uint8_t *done;     /* [T][N] or NULL */
+} S2DMatchRollout;
+
+typedef struct S2DMatchEngine *S2DMatchHandle;
+
+void s2d_match_default_config(S2DMatchConfig *cfg);
+int s2d_match_validate_config(const S2DMatchConfig *cfg);
+size_t s2d_match_arena_bytes(const S2DMatchConfig *cfg, int64_t n_envs);
+int s2d_match_create(const S2DMatchConfig *cfg, int64_t n_envs, int device, void *arena_dev, size_t arena_bytes,
+                     void *stream, S2DMatchHandle *out);
+void s2d_match_destroy(S2DMatchHandle h);
+int s2d_match_buffers(S2DMatchHandle h, S2DMatchBuffers *out);
+/* byte offsets of every S2DMatchBuffers pointer from the arena base (slot 0 = arena size) */
+int s2d_match_buffer_offsets(S2DMatchHandle h, int64_t *offsets, int n_offsets);
+/* kick-off formation, full stamina, score 0-0, cycle 0, KickOff for the left side */
+int s2d_match_reset(S2DMatchHandle h, const uint8_t *mask_dev, void *stream);
+/* actions_dev: float[N][22][3] = {command, a, b}: Dash(power=a, dir=b) Turn(moment=a)
+ * Kick(power=a, dir=b) Tackle(dir=a); NULL = uniform random policy drawn in-kernel */
+int s2d_match_step(S2DMatchHandle h, const float *actions_dev, void *stream);
+int s2d_match_rollout(S2DMatchHandle h, int n_steps, const float *actions_dev /* [T][N][22][3] or NULL */,
+                      const S2DMatchRollout *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2D_MATCH_H_ */

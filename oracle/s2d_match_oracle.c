@@ -1,0 +1,552 @@
+/*
+ * s2d_match_oracle.c -- CPU ORACLE of the 11v11 match engine.  TEST INFRASTRUCTURE ONLY
+ * (same rules as s2d_oracle.c: only tests/, smoke() and bench.py's cpu_baseline may load it).
+ *
+ * The reference holds no Python for an 11v11 task: everything here restates rcssserver's
+ * published match model (EXT) -- dash / turn / kick / tackle, stamina,
+ * movement, player-player and player-ball collisions, goals, ball-out restarts (kick-in,
+ * corner, goal kick), a basic offside rule, kick-off, half time, time over -- in the
+ * simplified form documented in DESIGN.md section 11.  PARITY UNPINNED against a real
+ * rcssserver; pinned by the hand-derived scenarios of tests/test_match_oracle.py.
+ *
+ * One source of truth for the HIP kernels: gym-soccer-2d-env_amd/csrc/s2d_match.hip must
+ * reproduce every fp32 word and integer of this file bit for bit (same deterministic math
+ * spec as the reach_ball path).
+ */
+#include "s2d_oracle_common.h"
+#include "../include/s2d_match.h"
+
+#define API __attribute__((visibility("default")))
+#define NP S2D_MATCH_PLAYERS
+#define NOBJ (NP + 1)
+#define BALL S2D_MATCH_BALL
+
+enum { ST_TACKLE = 4 };
+enum { SIDE_NONE = 0, SIDE_LEFT = 1, SIDE_RIGHT = 2 };
+
+typedef struct MP {
+  REAL half_l, half_w, player_size, ball_size, player_decay, ball_decay, player_rand, ball_rand;
+  REAL player_speed_max, player_speed_max2, player_accel_max, player_accel_max2, ball_speed_max, ball_speed_max2;
+  REAL ball_accel_max, ball_accel_max2, inertia_moment;
+  REAL stamina_max, stamina_inc_max, stamina_capacity, extra_stamina;
+  REAL recover_init, recover_dec_thr_value, recover_min, recover_dec;
+  REAL effort_init, effort_dec_thr_value, effort_min, effort_dec, effort_inc_thr_value, effort_inc;
+  REAL dash_power_rate, max_dash_power, min_dash_power, max_dash_angle, min_dash_angle;
+  REAL dash_angle_step, inv_dash_angle_step, side_dash_rate, back_dash_rate, max_moment, min_moment;
+  REAL collision_vel_rate;
+  REAL kick_power_rate, kickable_area, kickable_margin, inv_kickable_margin, kick_rand, max_power, min_power, inv_max_power;
+  REAL tackle_dist, tackle_back_dist, tackle_width, tackle_power_rate, max_tackle_power, max_back_tackle_power;
+  REAL goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
+  int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside;
+  uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
+} MP;
+
+static void mp_from_config(const S2DMatchConfig *c, MP *p) {
+  const S2DServerParams *s = &c->sp; const S2DMatchParams *m = &c->mp;
+  p->half_l = (REAL)s->pitch_half_length; p->half_w = (REAL)s->pitch_half_width;
+  p->player_size = (REAL)s->player_size; p->ball_size = (REAL)s->ball_size;
+  p->player_decay = (REAL)s->player_decay; p->ball_decay = (REAL)s->ball_decay;
+  p->player_rand = (REAL)s->player_rand; p->ball_rand = (REAL)s->ball_rand;
+  p->player_speed_max = (REAL)s->player_speed_max; p->player_speed_max2 = p->player_speed_max * p->player_speed_max;
+  p->player_accel_max = (REAL)s->player_accel_max; p->player_accel_max2 = p->player_accel_max * p->player_accel_max;
+  p->ball_speed_max = (REAL)s->ball_speed_max; p->ball_speed_max2 = p->ball_speed_max * p->ball_speed_max;
+  p->ball_accel_max = (REAL)s->ball_accel_max; p->ball_accel_max2 = p->ball_accel_max * p->ball_accel_max;
+  p->inertia_moment = (REAL)s->inertia_moment;
+  p->stamina_max = (REAL)s->stamina_max; p->stamina_inc_max = (REAL)s->stamina_inc_max;
+  p->stamina_capacity = (REAL)s->stamina_capacity; p->extra_stamina = (REAL)s->extra_stamina;
+  p->recover_init = (REAL)s->recover_init; p->recover_dec_thr_value = (REAL)(s->recover_dec_thr * s->stamina_max);
+  p->recover_min = (REAL)s->recover_min; p->recover_dec = (REAL)s->recover_dec;
+  p->effort_init = (REAL)s->effort_init; p->effort_dec_thr_value = (REAL)(s->effort_dec_thr * s->stamina_max);
+  p->effort_min = (REAL)s->effort_min; p->effort_dec = (REAL)s->effort_dec;
+  p->effort_inc_thr_value = (REAL)(s->effort_inc_thr * s->stamina_max); p->effort_inc = (REAL)s->effort_inc;
+  p->dash_power_rate = (REAL)s->dash_power_rate; p->max_dash_power = (REAL)s->max_dash_power;
+  p->min_dash_power = (REAL)s->min_dash_power; p->max_dash_angle = (REAL)s->max_dash_angle;
+  p->min_dash_angle = (REAL)s->min_dash_angle; p->dash_angle_step = (REAL)s->dash_angle_step;
+  p->inv_dash_angle_step = s->dash_angle_step > 0 ? (REAL)(1.0 / s->dash_angle_step) : R(0.0);
+  p->side_dash_rate = (REAL)s->side_dash_rate; p->back_dash_rate = (REAL)s->back_dash_rate;
+  p->max_moment = (REAL)s->max_moment; p->min_moment = (REAL)s->min_moment;
+  p->collision_vel_rate = (REAL)s->collision_vel_rate;
+  p->kick_power_rate = (REAL)m->kick_power_rate; p->kickable_margin = (REAL)m->kickable_margin;
+  p->inv_kickable_margin = (REAL)(1.0 / m->kickable_margin);
+  p->kickable_area = p->player_size + p->ball_size + p->kickable_margin;
+  p->kick_rand = (REAL)m->kick_rand; p->max_power = (REAL)m->max_power; p->min_power = (REAL)m->min_power;
+  p->inv_max_power = (REAL)(1.0 / m->max_power);
+  p->tackle_dist = (REAL)m->tackle_dist; p->tackle_back_dist = (REAL)m->tackle_back_dist;
+  p->tackle_width = (REAL)m->tackle_width; p->tackle_power_rate = (REAL)m->tackle_power_rate;
+  p->max_tackle_power = (REAL)m->max_tackle_power; p->max_back_tackle_power = (REAL)m->max_back_tackle_power;
+  p->goal_half_width = (REAL)(m->goal_width * 0.5);
+  p->offside_area2 = (REAL)(m->offside_active_area_size * m->offside_active_area_size);
+  p->free_kick_distance = (REAL)m->free_kick_distance;
+  p->inv_speed_decay = (REAL)(1.0 / (s->ball_speed_max * s->ball_decay));
+  p->tackle_cycles = m->tackle_cycles; p->half_time_cycles = m->half_time_cycles;
+  p->nr_normal_halfs = m->nr_normal_halfs; p->drop_ball_time = m->drop_ball_time; p->use_offside = m->use_offside;
+  p->seed = c->seed; p->env_id_offset = c->env_id_offset; p->auto_reset = c->auto_reset; p->noise = c->noise;
+}
+
+typedef struct Obj { REAL x, y, vx, vy, body, stamina, effort, recovery, capacity; int32_t tackle; } Obj;
+typedef struct Match {
+  Obj o[NOBJ];
+  int32_t cycle, mode, mode_side, score_left, score_right, last_touch_side, setplay_timer, offside_mask;
+  REAL reward_left; uint8_t done; int32_t nearest_left, nearest_right;
+} Match;
+
+static int side_of(int i) { return i < 11 ? SIDE_LEFT : SIDE_RIGHT; }
+static int other_side(int s) { return s == SIDE_LEFT ? SIDE_RIGHT : SIDE_LEFT; }
+static int is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D_GM_TIME_OVER; }
+
+/* kick-off formation of the left team (right team mirrored); DESIGN.md section 11 */
+static const REAL FORM_X[11] = {R(-50.0), R(-35.0), R(-35.0), R(-35.0), R(-35.0), R(-20.0), R(-20.0), R(-20.0), R(-20.0), R(-10.5), R(-10.5)};
+static const REAL FORM_Y[11] = {R(0.0), R(-20.0), R(-7.0), R(7.0), R(20.0), R(-22.0), R(-8.0), R(8.0), R(22.0), R(-6.0), R(6.0)};
+
+static void place_formation(Match *m, int kickoff_side) {
+  for (int i = 0; i < NP; ++i) {
+    int k = i % 11; int left = i < 11;
+    Obj *o = &m->o[i];
+    o->x = left ? FORM_X[k] : -FORM_X[k]; o->y = FORM_Y[k];
+    o->vx = R(0.0); o->vy = R(0.0); o->body = left ? R(0.0) : R(180.0); o->tackle = 0;
+  }
+  /* the taker stands at the ball */
+  if (kickoff_side == SIDE_LEFT) { m->o[10].x = R(-0.4); m->o[10].y = R(0.0); }
+  else { m->o[21].x = R(0.4); m->o[21].y = R(0.0); }
+  Obj *b = &m->o[BALL]; b->x = R(0.0); b->y = R(0.0); b->vx = R(0.0); b->vy = R(0.0);
+}
+static void recover_all(const MP *p, Match *m, int with_capacity) {
+  for (int i = 0; i < NP; ++i) {
+    Obj *o = &m->o[i];
+    o->stamina = p->stamina_max; o->effort = p->effort_init; o->recovery = p->recover_init;
+    if (with_capacity) o->capacity = p->stamina_capacity;
+  }
+}
+static void match_reset(const MP *p, Match *m) {
+  memset(m, 0, sizeof *m);
+  recover_all(p, m, 1);
+  place_formation(m, SIDE_LEFT);
+  m->mode = S2D_GM_KICK_OFF; m->mode_side = SIDE_LEFT;
+  m->nearest_left = 10; m->nearest_right = 20;
+}
+
+static REAL clampr(REAL v, REAL lo, REAL hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* Player::dash / Player::turn -- identical arithmetic to s2d_oracle.c (appendix A) */
+static void m_dash(const MP *p, Obj *o, REAL power, REAL dir, REAL *ax, REAL *ay) {
+  power = clampr(power, p->min_dash_power, p->max_dash_power);
+  dir = clampr(dir, p->min_dash_angle, p->max_dash_angle);
+  if (p->dash_angle_step > R(0.0)) dir = p->dash_angle_step * R(rint)(DIVC(dir, p->dash_angle_step, p->inv_dash_angle_step));
+  int back = power < R(0.0);
+  REAL need = back ? power * R(-2.0) : power;
+  REAL avail = o->stamina + p->extra_stamina;
+  if (need > avail) need = avail;
+  REAL st = o->stamina - need;
+  o->stamina = st > R(0.0) ? st : R(0.0);
+  power = back ? need / R(-2.0) : need;
+  REAL ad = R(fabs)(dir);
+  REAL dir_rate = ad > R(90.0)
+      ? p->back_dash_rate - ((p->back_dash_rate - p->side_dash_rate) * (R(1.0) - DIVC(ad - R(90.0), R(90.0), 0.011111111111111112f)))
+      : p->side_dash_rate + ((R(1.0) - p->side_dash_rate) * (R(1.0) - DIVC(ad, R(90.0), 0.011111111111111112f)));
+  dir_rate = clampr(dir_rate, R(0.0), R(1.0));
+  REAL acc = R(fabs)(o->effort * power * dir_rate * p->dash_power_rate);
+  if (back) dir += R(180.0);
+  REAL sn, cs;
+  sincos_deg(norm_deg(o->body + dir), &sn, &cs);
+  *ax = acc * cs; *ay = acc * sn;
+}
+static void m_turn(const MP *p, Obj *o, REAL moment, REAL noise_u) {
+  moment = clampr(moment, p->min_moment, p->max_moment);
+  REAL speed = hypot2(o->vx, o->vy);
+  REAL f = R(1.0);
+  if (p->noise) f = R(1.0) + (noise_u * R(2.0) - R(1.0)) * p->player_rand;
+  o->body = norm_deg(o->body + f * moment / (R(1.0) + p->inertia_moment * speed));
+}
+/* Player::kick -- appendix A "Kick(power, dir)".  Returns 1 if the ball was kickable. */
+static int m_kick(const MP *p, const Obj *o, const Obj *b, REAL power, REAL dir, REAL u_mag, REAL u_ang, REAL *kx, REAL *ky) {
+  REAL dx = b->x - o->x, dy = b->y - o->y;
+  REAL dist = hypot2(dx, dy);
+  if (!(dist <= p->kickable_area)) return 0;
+  power = clampr(power, p->min_power, p->max_power);
+  dir = clampr(dir, R(-180.0), R(180.0));
+  REAL dir_diff = R(fabs)(norm_deg(atan2_deg(dy, dx) - o->body));
+  REAL dist_ball = dist - p->player_size - p->ball_size;
+  REAL eff = power * p->kick_power_rate * (R(1.0) - R(0.25) * DIVC(dir_diff, R(180.0), 0.005555555555555556f)
+                                            - R(0.25) * DIVC(dist_ball, p->kickable_margin, p->inv_kickable_margin));
+  REAL sn, cs;
+  sincos_deg(norm_deg(o->body + dir), &sn, &cs);
+  REAL ax = eff * cs, ay = eff * sn;
+  if (p->noise) {
+    REAL pos_rate = R(0.5) + R(0.25) * (DIVC(dir_diff, R(180.0), 0.005555555555555556f) + DIVC(dist_ball, p->kickable_margin, p->inv_kickable_margin));
+    REAL speed_rate = R(0.5) + R(0.5) * (hypot2(b->vx, b->vy) * p->inv_speed_decay);
+    REAL max_rand = p->kick_rand * (power * p->inv_max_power) * (pos_rate + speed_rate);
+    REAL mag = u_mag * max_rand;
+    REAL s2, c2;
+    sincos_deg(u_ang * R(360.0) - R(180.0), &s2, &c2);
+    ax += mag * c2; ay += mag * s2;
+  }
+  *kx = ax; *ky = ay;
+  return 1;
+}
+/* Player::tackle (foul = false) -- appendix A.  `u` = uniform draw.  Returns 1 on success. */
+static int m_tackle(const MP *p, const Obj *o, const Obj *b, REAL dir, REAL u, REAL *kx, REAL *ky) {
+  REAL dx = b->x - o->x, dy = b->y - o->y;
+  REAL sn, cs;
+  sincos_deg(o->body, &sn, &cs);
+  REAL rx = dx * cs + dy * sn;                /* ball in the body frame */
+  REAL ry = dy * cs - dx * sn;
+  REAL d = rx > R(0.0) ? p->tackle_dist : p->tackle_back_dist;
+  REAL tx = d > R(0.0) ? R(fabs)(rx) / d : (rx == R(0.0) ? R(0.0) : R(1.0e9));
+  REAL ty = R(fabs)(ry) / p->tackle_width;
+  REAL tx2 = tx * tx, ty2 = ty * ty;
+  REAL fail = tx2 * tx2 * tx2 + ty2 * ty2 * ty2;    /* exponent 6 */
+  if (!(u >= fail)) return 0;
+  dir = clampr(dir, R(-180.0), R(180.0));
+  REAL ang_ball = R(fabs)(norm_deg(atan2_deg(dy, dx) - o->body));
+  REAL eff = (p->max_back_tackle_power + (p->max_tackle_power - p->max_back_tackle_power) * (R(1.0) - DIVC(R(fabs)(dir), R(180.0), 0.005555555555555556f)))
+             * p->tackle_power_rate * (R(1.0) - R(0.5) * DIVC(ang_ball, R(180.0), 0.005555555555555556f));
+  REAL s2, c2;
+  sincos_deg(norm_deg(o->body + dir), &s2, &c2);
+  *kx = eff * c2; *ky = eff * s2;
+  return 1;
+}
+static void m_update_stamina(const MP *p, Obj *e) {
+  if (e->stamina <= p->recover_dec_thr_value) {
+    if (e->recovery > p->recover_min) { REAL r = e->recovery - p->recover_dec; e->recovery = r > p->recover_min ? r : p->recover_min; }
+  }
+  if (e->stamina <= p->effort_dec_thr_value) {
+    if (e->effort > p->effort_min) { REAL f = e->effort - p->effort_dec; e->effort = f > p->effort_min ? f : p->effort_min; }
+  }
+  if (e->stamina >= p->effort_inc_thr_value) {
+    if (e->effort < p->effort_init) { REAL f = e->effort + p->effort_inc; e->effort = f < p->effort_init ? f : p->effort_init; }
+  }
+  REAL inc = e->recovery * p->stamina_inc_max;
+  REAL room = p->stamina_max - e->stamina;
+  if (inc > room) inc = room;
+  if (p->stamina_capacity >= R(0.0)) { if (inc > e->capacity) inc = e->capacity; }
+  e->stamina += inc;
+  if (e->stamina > p->stamina_max) e->stamina = p->stamina_max;
+  if (p->stamina_capacity >= R(0.0)) { REAL c = e->capacity - inc; e->capacity = c > R(0.0) ? c : R(0.0); }
+}
+static void add_noise(REAL *vx, REAL *vy, REAL rnd, REAL u_mag, REAL u_ang) {
+  REAL s = hypot2(*vx, *vy);
+  REAL mag = u_mag * (rnd * s);
+  REAL sn, cs;
+  sincos_deg(u_ang * R(360.0) - R(180.0), &sn, &cs);
+  *vx += mag * cs; *vy += mag * sn;
+}
+
+static void restart(Match *m, int mode, int side, REAL bx, REAL by) {
+  Obj *b = &m->o[BALL];
+  b->x = bx; b->y = by; b->vx = R(0.0); b->vy = R(0.0);
+  m->mode = mode; m->mode_side = side; m->setplay_timer = 0; m->offside_mask = 0;
+}
+
+typedef struct MatchStats { unsigned long long v[8]; } MatchStats;
+
+/* one cycle of one match; act = [22][3] {cmd, a, b} */
+static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, MatchStats *st) {
+  const uint32_t cyc = (uint32_t)m->cycle;
+  const int mode0 = m->mode, side0 = m->mode_side;
+  Obj *b = &m->o[BALL];
+  REAL x0[NOBJ];
+  for (int i = 0; i < NOBJ; ++i) x0[i] = m->o[i].x;
+  m->reward_left = R(0.0); m->done = 0;
+
+  /* 1. commands */
+  REAL ax[NP], ay[NP], kx[NP], ky[NP];
+  int kicked[NP];
+  uint32_t nzb[4] = {0, 0, 0, 0};
+  if (p->noise) draw(p->seed, gid, cyc, ST_NOISE, BALL, nzb);
+  for (int i = 0; i < NP; ++i) {
+    Obj *o = &m->o[i];
+    ax[i] = ay[i] = kx[i] = ky[i] = R(0.0); kicked[i] = 0;
+    int cmd = (int)act[i * 3 + 0];
+    REAL a = (REAL)act[i * 3 + 1], bb = (REAL)act[i * 3 + 2];
+    if (o->tackle > 0 || mode0 == S2D_GM_TIME_OVER) cmd = S2D_MCMD_NONE;
+    uint32_t nz[4] = {0, 0, 0, 0}, nk[4] = {0, 0, 0, 0};
+    if (p->noise) { draw(p->seed, gid, cyc, ST_NOISE, (uint32_t)i, nz); draw(p->seed, gid, cyc, ST_NOISE, 32u + (uint32_t)i, nk); }
+    int may_touch = !is_setplay(mode0) || side_of(i) == side0;      /* set play: only the taking side plays the ball */
+    if (cmd == S2D_MCMD_DASH) m_dash(p, o, a, bb, &ax[i], &ay[i]);
+    else if (cmd == S2D_MCMD_TURN) m_turn(p, o, a, rnd_u01(nz[2]));
+    else if (cmd == S2D_MCMD_KICK) {
+      int ok = m_kick(p, o, b, a, bb, rnd_u01(nk[0]), rnd_u01(nk[1]), &kx[i], &ky[i]);
+      if (ok && may_touch) { kicked[i] = 1; st->v[4]++; } else { kx[i] = ky[i] = R(0.0); }
+    } else if (cmd == S2D_MCMD_TACKLE) {
+      uint32_t w[4];
+      draw(p->seed, gid, cyc, ST_TACKLE, (uint32_t)i, w);
+      int ok = m_tackle(p, o, b, a, rnd_u01(w[0]), &kx[i], &ky[i]);
+      o->tackle = p->tackle_cycles + 1;
+      st->v[5]++;
+      if (ok && may_touch) kicked[i] = 1; else { kx[i] = ky[i] = R(0.0); }
+    }
+    /* _inc of player i */
+    if (cmd == S2D_MCMD_DASH) {
+      REAL a2 = sq2(ax[i], ay[i]);
+      if (a2 > p->player_accel_max2) { REAL k = p->player_accel_max / R(sqrt)(a2); ax[i] *= k; ay[i] *= k; }
+      o->vx += ax[i]; o->vy += ay[i];
+    }
+    REAL s2 = sq2(o->vx, o->vy);
+    if (s2 > p->player_speed_max2) { REAL k = p->player_speed_max / R(sqrt)(s2); o->vx *= k; o->vy *= k; }
+    if (p->noise) add_noise(&o->vx, &o->vy, p->player_rand, rnd_u01(nz[0]), rnd_u01(nz[1]));
+    o->x += o->vx; o->y += o->vy;
+  }
+  /* 2. ball: accelerations summed in player order */
+  REAL bax = R(0.0), bay = R(0.0);
+  int any_kick = 0, last_kicker = -1;
+  for (int i = 0; i < NP; ++i) if (kicked[i]) { bax += kx[i]; bay += ky[i]; any_kick = 1; last_kicker = i; }
+  if (any_kick) m->last_touch_side = side_of(last_kicker);
+  const int ball_live = !is_setplay(mode0) || any_kick;
+  if (ball_live) {
+    if (any_kick) {
+      REAL a2 = sq2(bax, bay);
+      if (a2 > p->ball_accel_max2) { REAL k = p->ball_accel_max / R(sqrt)(a2); bax *= k; bay *= k; }
+      b->vx += bax; b->vy += bay;
+    }
+    REAL s2 = sq2(b->vx, b->vy);
+    if (s2 > p->ball_speed_max2) { REAL k = p->ball_speed_max / R(sqrt)(s2); b->vx *= k; b->vy *= k; }
+    if (p->noise) add_noise(&b->vx, &b->vy, p->ball_rand, rnd_u01(nzb[0]), rnd_u01(nzb[1]));
+    b->x += b->vx; b->y += b->vy;
+  }
+  /* 3. collisions: Jacobi passes, every overlapping pair proposes symmetric contact positions */
+  int collided[NOBJ]; memset(collided, 0, sizeof collided);
+  int touch_player = -1;
+  for (int pass = 0; pass < 10; ++pass) {
+    REAL sx[NOBJ], sy[NOBJ]; int cnt[NOBJ]; int any = 0;
+    for (int i = 0; i < NOBJ; ++i) {
+      sx[i] = sy[i] = R(0.0); cnt[i] = 0;
+      REAL ri = i == BALL ? p->ball_size : p->player_size;
+      for (int j = 0; j < NOBJ; ++j) {
+        if (j == i) continue;
+        REAL rj = j == BALL ? p->ball_size : p->player_size;
+        REAL dx = m->o[i].x - m->o[j].x, dy = m->o[i].y - m->o[j].y;
+        REAL d2 = sq2(dx, dy), r = ri + rj;
+        if (d2 < r * r) {
+          REAL d = R(sqrt)(d2), ux, uy;
+          if (d > R(0.0)) { ux = dx / d; uy = dy / d; } else { ux = i < j ? R(-1.0) : R(1.0); uy = R(0.0); }
+          REAL mx = (m->o[i].x + m->o[j].x) * R(0.5), my = (m->o[i].y + m->o[j].y) * R(0.5), h = r * R(0.5);
+          sx[i] += mx + ux * h; sy[i] += my + uy * h; cnt[i]++;
+          if (i == BALL) touch_player = j;       /* last (highest index) player overlapping the ball */
+        }
+      }
+      if (cnt[i]) any = 1;
+    }
+    if (!any) break;
+    for (int i = 0; i < NOBJ; ++i) if (cnt[i]) {
+      m->o[i].x = sx[i] / (REAL)cnt[i]; m->o[i].y = sy[i] / (REAL)cnt[i]; collided[i] = 1;
+    }
+  }
+  for (int i = 0; i < NOBJ; ++i) if (collided[i]) { m->o[i].vx *= p->collision_vel_rate; m->o[i].vy *= p->collision_vel_rate; }
+  int coll_touch_side = SIDE_NONE;
+  if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
+    coll_touch_side = side_of(touch_player);
+    m->last_touch_side = coll_touch_side;
+  }
+  /* 4. set play: opponents keep free_kick_distance from the ball */
+  if (is_setplay(mode0)) {
+    for (int i = 0; i < NP; ++i) if (side_of(i) != side0) {
+      Obj *o = &m->o[i];
+      REAL dx = o->x - b->x, dy = o->y - b->y, d = hypot2(dx, dy);
+      if (d < p->free_kick_distance) {
+        REAL ux, uy;
+        if (d > R(0.0)) { ux = dx / d; uy = dy / d; } else { ux = side_of(i) == SIDE_LEFT ? R(-1.0) : R(1.0); uy = R(0.0); }
+        o->x = b->x + ux * p->free_kick_distance; o->y = b->y + uy * p->free_kick_distance;
+      }
+    }
+  }
+  /* 5. referee */
+  m->cycle += 1;
+  if (mode0 != S2D_GM_TIME_OVER) {
+    if (is_setplay(mode0)) {
+      if (any_kick) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; }
+      else { m->setplay_timer += 1; if (m->setplay_timer > p->drop_ball_time) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; } }
+    }
+    if (m->mode == S2D_GM_PLAY_ON) {
+      /* offside bookkeeping at the moment of a pass (positions before this cycle's movement) */
+      if (any_kick) {
+        int mask = 0;
+        int exempt = mode0 == S2D_GM_KICK_IN || mode0 == S2D_GM_GOAL_KICK || mode0 == S2D_GM_CORNER_KICK;
+        if (p->use_offside && !exempt) {
+          int S = side_of(last_kicker);
+          REAL dirS = S == SIDE_LEFT ? R(1.0) : R(-1.0);
+          int o0 = S == SIDE_LEFT ? 11 : 0;
+          REAL first = R(-1.0e9), second = R(-1.0e9);       /* two largest dirS*x among opponents */
+          for (int j = o0; j < o0 + 11; ++j) {
+            REAL v = dirS * x0[j];
+            if (v > first) { second = first; first = v; } else if (v > second) second = v;
+          }
+          REAL line = R(0.0);
+          if (second > line) line = second;
+          REAL bl = dirS * x0[BALL];
+          if (bl > line) line = bl;
+          int t0 = S == SIDE_LEFT ? 0 : 11;
+          for (int t = t0; t < t0 + 11; ++t) if (t != last_kicker && dirS * x0[t] > line) mask |= 1 << t;
+        }
+        m->offside_mask = mask;
+      } else if (coll_touch_side != SIDE_NONE && m->offside_mask) {
+        int flagged_side = (m->offside_mask & 0x7FF) ? SIDE_LEFT : SIDE_RIGHT;
+        if (coll_touch_side != flagged_side) m->offside_mask = 0;
+      }
+      REAL bx = b->x, by = b->y;
+      if (bx > p->half_l && R(fabs)(by) < p->goal_half_width) {              /* goal for the left team */
+        m->score_left += 1; m->reward_left = R(1.0); st->v[1]++;
+        place_formation(m, SIDE_RIGHT);
+        restart(m, S2D_GM_KICK_OFF, SIDE_RIGHT, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
+      } else if (bx < -p->half_l && R(fabs)(by) < p->goal_half_width) {      /* goal for the right team */
+        m->score_right += 1; m->reward_left = R(-1.0); st->v[2]++;
+        place_formation(m, SIDE_LEFT);
+        restart(m, S2D_GM_KICK_OFF, SIDE_LEFT, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
+      } else if (R(fabs)(bx) > p->half_l || R(fabs)(by) > p->half_w) {       /* ball out */
+        st->v[7]++;
+        int toucher = m->last_touch_side == SIDE_NONE ? SIDE_LEFT : m->last_touch_side;
+        REAL sy = by < R(0.0) ? R(-1.0) : R(1.0), sxn = bx < R(0.0) ? R(-1.0) : R(1.0);
+        if (R(fabs)(bx) <= p->half_l) {                                      /* over a side line: kick-in */
+          restart(m, S2D_GM_KICK_IN, other_side(toucher), clampr(bx, -p->half_l, p->half_l), sy * p->half_w);
+        } else {
+          int defender = bx > R(0.0) ? SIDE_RIGHT : SIDE_LEFT;               /* right team defends the +x goal */
+          if (toucher == defender) restart(m, S2D_GM_CORNER_KICK, other_side(defender), sxn * (p->half_l - R(1.0)), sy * (p->half_w - R(1.0)));
+          else restart(m, S2D_GM_GOAL_KICK, defender, sxn * (p->half_l - R(5.5)), sy * R(9.16));
+        }
+      } else if (m->offside_mask) {                                          /* flagged player plays the ball */
+        for (int t = 0; t < NP; ++t) if (m->offside_mask & (1 << t)) {
+          REAL dx = m->o[t].x - bx, dy = m->o[t].y - by;
+          if (sq2(dx, dy) < p->offside_area2) {
+            st->v[6]++;
+            restart(m, S2D_GM_OFF_SIDE, other_side(side_of(t)), m->o[t].x, m->o[t].y);
+            break;
+          }
+        }
+      }
+    }
+    /* half time / time over */
+    int total = p->half_time_cycles * p->nr_normal_halfs;
+    if (m->cycle >= total) {
+      m->mode = S2D_GM_TIME_OVER; m->mode_side = SIDE_NONE; m->done = 1; m->offside_mask = 0; st->v[3]++;
+    } else if (p->half_time_cycles > 0 && m->cycle % p->half_time_cycles == 0) {
+      int k = m->cycle / p->half_time_cycles;
+      int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
+      recover_all(p, m, 0);
+      place_formation(m, ks);
+      restart(m, S2D_GM_KICK_OFF, ks, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
+    }
+  }
+  /* 6. decay, tackle timers, stamina */
+  for (int i = 0; i < NP; ++i) {
+    Obj *o = &m->o[i];
+    o->vx *= p->player_decay; o->vy *= p->player_decay;
+    if (o->tackle > 0) o->tackle -= 1;
+    m_update_stamina(p, o);
+  }
+  b->vx *= p->ball_decay; b->vy *= p->ball_decay;
+  /* 7. nearest player to the ball per team (ties: lowest index) */
+  {
+    REAL best_l = R(3.0e38), best_r = R(3.0e38); int il = 0, ir = 11;
+    for (int i = 0; i < NP; ++i) {
+      REAL d2 = sq2(m->o[i].x - b->x, m->o[i].y - b->y);
+      if (i < 11) { if (d2 < best_l) { best_l = d2; il = i; } } else { if (d2 < best_r) { best_r = d2; ir = i; } }
+    }
+    m->nearest_left = il; m->nearest_right = ir;
+  }
+  st->v[0]++;
+  if (m->done && p->auto_reset) {
+    uint8_t d = m->done; REAL rw = m->reward_left;
+    match_reset(p, m);
+    m->done = d; m->reward_left = rw;
+  }
+}
+
+/* uniform random policy of the benchmark: Philox POLICY stream, block = player */
+static void random_actions(const MP *p, uint64_t gid, uint32_t cyc, float *act) {
+  for (int i = 0; i < NP; ++i) {
+    uint32_t w[4];
+    draw(p->seed, gid, cyc, ST_POLICY, (uint32_t)i, w);
+    int cmd = 1 + rnd_below(w[0], 4);
+    REAL u = rnd_u01(w[1]), s = rnd_u01(w[2]) * R(2.0) - R(1.0);
+    REAL a, b = R(0.0);
+    if (cmd == S2D_MCMD_DASH || cmd == S2D_MCMD_KICK) { a = u * R(100.0); b = s * R(180.0); }
+    else { a = s * R(180.0); }
+    act[i * 3 + 0] = (float)cmd; act[i * 3 + 1] = (float)a; act[i * 3 + 2] = (float)b;
+  }
+}
+
+/* ------------------------------------------------------------------ vectorised engine */
+typedef struct S2DMOEngine { MP p; int64_t n; Match *m; MatchStats st; } S2DMOEngine;
+
+API S2DMOEngine *s2dmo_create(const S2DMatchConfig *cfg, int64_t n) {
+  if (!cfg || n <= 0) return NULL;
+  S2DMOEngine *h = (S2DMOEngine *)calloc(1, sizeof *h);
+  mp_from_config(cfg, &h->p); h->n = n;
+  h->m = (Match *)calloc((size_t)n, sizeof(Match));
+  for (int64_t e = 0; e < n; ++e) match_reset(&h->p, &h->m[e]);
+  return h;
+}
+API void s2dmo_destroy(S2DMOEngine *h) { if (h) { free(h->m); free(h); } }
+API void s2dmo_reset(S2DMOEngine *h, const uint8_t *mask) {
+  for (int64_t e = 0; e < h->n; ++e) if (!mask || mask[e]) match_reset(&h->p, &h->m[e]);
+}
+API void s2dmo_step(S2DMOEngine *h, const float *actions) {
+  MatchStats tot; memset(&tot, 0, sizeof tot);
+#pragma omp parallel
+  {
+    MatchStats loc; memset(&loc, 0, sizeof loc);
+#pragma omp for schedule(static)
+    for (int64_t e = 0; e < h->n; ++e) {
+      float buf[NP * 3];
+      const float *a = actions ? actions + (size_t)e * NP * 3 : buf;
+      if (!actions) random_actions(&h->p, (uint64_t)(h->p.env_id_offset + e), (uint32_t)h->m[e].cycle, buf);
+      match_step(&h->p, &h->m[e], (uint64_t)(h->p.env_id_offset + e), a, &loc);
+    }
+#pragma omp critical
+    for (int k = 0; k < 8; ++k) tot.v[k] += loc.v[k];
+  }
+  for (int k = 0; k < 8; ++k) h->st.v[k] += tot.v[k];
+}
+/* field: 0..8 object planes x,y,vx,vy,body,stamina,effort,recovery,capacity -> out[n][24] (float as double);
+ * 9 tackle -> out[n][24]; 10.. per-env ints: cycle, mode, mode_side, score_left, score_right, last_touch_side,
+ * setplay_timer, offside_mask, 18 reward_left, 19 done, 20 nearest_left, 21 nearest_right -> out[n] */
+API int s2dmo_get(const S2DMOEngine *h, int field, double *out) {
+  for (int64_t e = 0; e < h->n; ++e) {
+    const Match *m = &h->m[e];
+    if (field <= 9) {
+      for (int s = 0; s < S2D_MATCH_SLOTS; ++s) {
+        double v = 0;
+        if (s < NOBJ) {
+          const Obj *o = &m->o[s];
+          switch (field) {
+            case 0: v = o->x; break; case 1: v = o->y; break; case 2: v = o->vx; break; case 3: v = o->vy; break;
+            case 4: v = o->body; break; case 5: v = o->stamina; break; case 6: v = o->effort; break;
+            case 7: v = o->recovery; break; case 8: v = o->capacity; break; default: v = o->tackle; break;
+          }
+        }
+        out[e * S2D_MATCH_SLOTS + s] = v;
+      }
+    } else {
+      double v;
+      switch (field) {
+        case 10: v = m->cycle; break; case 11: v = m->mode; break; case 12: v = m->mode_side; break;
+        case 13: v = m->score_left; break; case 14: v = m->score_right; break; case 15: v = m->last_touch_side; break;
+        case 16: v = m->setplay_timer; break; case 17: v = m->offside_mask; break; case 18: v = m->reward_left; break;
+        case 19: v = m->done; break; case 20: v = m->nearest_left; break; case 21: v = m->nearest_right; break;
+        default: return -1;
+      }
+      out[e] = v;
+    }
+  }
+  return 0;
+}
+/* place one object / set per-env ints (tests: hand-built scenarios).  slot 0..22; vals = 10 numbers in plane order */
+API int s2dmo_set_obj(S2DMOEngine *h, int64_t e, int slot, const double *v10) {
+  if (e < 0 || e >= h->n || slot < 0 || slot >= NOBJ) return -1;
+  Obj *o = &h->m[e].o[slot];
+  o->x = (REAL)v10[0]; o->y = (REAL)v10[1]; o->vx = (REAL)v10[2]; o->vy = (REAL)v10[3]; o->body = (REAL)v10[4];
+  o->stamina = (REAL)v10[5]; o->effort = (REAL)v10[6]; o->recovery = (REAL)v10[7]; o->capacity = (REAL)v10[8];
+  o->tackle = (int32_t)v10[9];
+  return 0;
+}
+API int s2dmo_set_game(S2DMOEngine *h, int64_t e, const int32_t *v8) {
+  if (e < 0 || e >= h->n) return -1;
+  Match *m = &h->m[e];
+  m->cycle = v8[0]; m->mode = v8[1]; m->mode_side = v8[2]; m->score_left = v8[3]; m->score_right = v8[4];
+  m->last_touch_side = v8[5]; m->setplay_timer = v8[6]; m->offside_mask = v8[7];
+  return 0;
+}
+API const unsigned long long *s2dmo_stats(const S2DMOEngine *h) { return h->st.v; }
+API void s2dmo_random_actions(const S2DMOEngine *h, float *out) {
+  for (int64_t e = 0; e < h->n; ++e)
+    random_actions(&h->p, (uint64_t)(h->p.env_id_offset + e), (uint32_t)h->m[e].cycle, out + (size_t)e * NP * 3);
+}

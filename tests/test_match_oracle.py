@@ -1,0 +1,209 @@
+"""Hand-built scenarios for the 11v11 match oracle (rcssserver rules restated, EXT /
+parity-unpinned): kick, tackle, collisions, goals, restarts, offside,
+half time, time over, determinism."""
+import numpy as np
+import pytest
+
+import match_oracle as MO
+from soccer2d_amd._capi_match import (GM_CORNER_KICK, GM_GOAL_KICK, GM_KICK_IN, GM_KICK_OFF, GM_OFF_SIDE, GM_PLAY_ON,
+                                      GM_TIME_OVER, MCMD_DASH, MCMD_KICK, MCMD_NONE, MCMD_TACKLE, MCMD_TURN)
+
+LEFT, RIGHT = 1, 2
+
+
+def fresh(n=1, **kw):
+    return MO.MatchOracle(MO.make_match_config(**kw), n)
+
+
+def acts(n=1, **per_player):
+    a = np.zeros((n, 22, 3), dtype=np.float32)
+    for k, v in per_player.items():
+        a[:, int(k[1:])] = v
+    return a
+
+
+def play_on(m, e=0):
+    m.set_game(e, mode=GM_PLAY_ON, mode_side=0)
+
+
+def test_reset_state():
+    m = fresh()
+    assert m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == LEFT and m.get('cycle')[0] == 0
+    x, y, body = m.get('x')[0], m.get('y')[0], m.get('body')[0]
+    assert x[0] == -50 and x[11] == 50 and body[0] == 0 and body[11] == 180
+    assert (x[:10] < 0).all() and (x[11:22] > 0).all() and x[10] == pytest.approx(-0.4) and x[22] == 0 and y[22] == 0
+    assert (m.get('stamina')[0][:22] == 8000).all()
+    # opponents of the taking side start outside the centre circle
+    assert (np.hypot(x[11:22], y[11:22]) > 9.15).all()
+
+
+def test_kickoff_kick_starts_play_and_ball_moves():
+    m = fresh()
+    m.step(acts(p10=[MCMD_KICK, 100, 0]))          # left #11 stands 0.4 m behind the ball, body 0
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('last_touch_side')[0] == LEFT
+    # eff = 100 * .027 * (1 - .25*0 - .25*(0.4-0.385)/0.7) -> ball speed 2.6855, then decay .94
+    eff = 100 * 0.027 * (1 - 0.25 * (0.4 - 0.385) / 0.7)
+    assert m.get('x')[0][22] == pytest.approx(eff, rel=1e-5) and m.get('vx')[0][22] == pytest.approx(eff * 0.94, rel=1e-5)
+    assert m.stats()[4] == 1
+
+
+def test_kick_needs_kickable_ball_and_side_in_set_play():
+    m = fresh()
+    m.step(acts(p21=[MCMD_KICK, 100, 0]))          # right player is not the taker: ignored even if close
+    assert m.get('mode')[0] == GM_KICK_OFF and m.get('x')[0][22] == 0 and m.get('setplay_timer')[0] == 1
+    m.step(acts(p5=[MCMD_KICK, 100, 0]))           # far away: not kickable
+    assert m.get('x')[0][22] == 0 and m.stats()[4] == 0
+
+
+def test_drop_ball_after_timeout():
+    m = fresh(drop_ball_time=5)
+    for _ in range(5):
+        m.step(acts())
+        assert m.get('mode')[0] == GM_KICK_OFF
+    m.step(acts())
+    assert m.get('mode')[0] == GM_PLAY_ON
+
+
+def test_goal_and_kickoff_for_conceding_side():
+    m = fresh()
+    play_on(m)
+    m.set_obj(0, 22, x=52.0, y=1.0, vx=1.5, vy=0.0)
+    m.step(acts())
+    assert m.get('score_left')[0] == 1 and m.get('reward_left')[0] == 1.0
+    assert m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == RIGHT
+    assert m.get('x')[0][22] == 0 and m.get('x')[0][21] == pytest.approx(0.4) and m.get('x')[0][10] == pytest.approx(-10.5)
+    m2 = fresh(); play_on(m2)
+    m2.set_obj(0, 22, x=-52.0, y=-6.9, vx=-1.5, vy=0.0)
+    m2.step(acts())
+    assert m2.get('score_right')[0] == 1 and m2.get('reward_left')[0] == -1.0 and m2.get('mode_side')[0] == LEFT
+
+
+def test_ball_out_restarts():
+    # side line -> kick-in for the side that did not touch last
+    m = fresh(); play_on(m); m.set_game(0, last_touch_side=LEFT)
+    m.set_obj(0, 22, x=10.0, y=33.5, vx=0.0, vy=1.0)
+    m.step(acts())
+    assert m.get('mode')[0] == GM_KICK_IN and m.get('mode_side')[0] == RIGHT
+    assert m.get('x')[0][22] == 10.0 and m.get('y')[0][22] == 34.0 and m.get('vx')[0][22] == 0
+    # goal line wide of the posts, last touched by the defender (right defends +x) -> corner for left
+    m = fresh(); play_on(m); m.set_game(0, last_touch_side=RIGHT)
+    m.set_obj(0, 22, x=52.0, y=20.0, vx=1.0, vy=0.0)
+    m.step(acts())
+    assert m.get('mode')[0] == GM_CORNER_KICK and m.get('mode_side')[0] == LEFT
+    assert m.get('x')[0][22] == 51.5 and m.get('y')[0][22] == 33.0
+    # ... last touched by the attacker -> goal kick for the defender
+    m = fresh(); play_on(m); m.set_game(0, last_touch_side=LEFT)
+    m.set_obj(0, 22, x=52.0, y=-20.0, vx=1.0, vy=0.0)
+    m.step(acts())
+    assert m.get('mode')[0] == GM_GOAL_KICK and m.get('mode_side')[0] == RIGHT
+    assert m.get('x')[0][22] == 47.0 and m.get('y')[0][22] == pytest.approx(-9.16)
+    assert m.stats()[7] == 1
+
+
+def test_free_kick_distance_is_enforced():
+    m = fresh(); play_on(m); m.set_game(0, last_touch_side=LEFT)
+    m.set_obj(0, 22, x=10.0, y=33.5, vx=0.0, vy=1.0)
+    m.set_obj(0, 3, x=10.0, y=30.0)                # left player near the spot: must retreat (right takes)
+    m.step(acts())
+    m.step(acts())
+    d = np.hypot(m.get('x')[0][3] - 10.0, m.get('y')[0][3] - 34.0)
+    assert d == pytest.approx(9.15, rel=1e-6)
+
+
+def test_tackle_freezes_and_back_tackle_fails():
+    m = fresh(); play_on(m)
+    m.set_obj(0, 22, x=-19.0, y=-22.0)             # 1 m in front of left #6 (index 5, body 0)
+    succ = 0
+    for s in range(40):
+        mm = fresh(seed=s); play_on(mm)
+        mm.set_obj(0, 22, x=-19.0, y=-22.0)
+        mm.step(acts(p5=[MCMD_TACKLE, 0, 0]))
+        assert mm.get('tackle_cycles')[0][5] == 10
+        succ += mm.get('vx')[0][22] > 0
+        mm.step(acts(p5=[MCMD_DASH, 100, 0]))      # frozen: the dash is ignored
+        assert mm.get('vx')[0][5] == 0 and mm.get('tackle_cycles')[0][5] == 9
+    # fail probability (1/2)^6 + 0 = 1.6 %: nearly always succeeds
+    assert succ >= 36
+    mm = fresh(); play_on(mm)
+    mm.set_obj(0, 22, x=-21.0, y=-22.0)            # behind the player: tackle_back_dist = 0 -> never
+    mm.step(acts(p5=[MCMD_TACKLE, 0, 0]))
+    assert mm.get('vx')[0][22] == 0 and mm.get('tackle_cycles')[0][5] == 10
+
+
+def test_player_player_and_player_ball_collisions():
+    m = fresh(); play_on(m)
+    m.set_obj(0, 1, x=0.0, y=20.0); m.set_obj(0, 12, x=0.4, y=20.0)      # overlap (0.4 < 0.6)
+    m.step(acts())
+    x = m.get('x')[0]
+    assert x[12] - x[1] == pytest.approx(0.6, rel=1e-6) and (x[1] + x[12]) / 2 == pytest.approx(0.2, abs=1e-6)
+    m = fresh(); play_on(m)
+    m.set_obj(0, 22, x=5.0, y=5.0, vx=0.5); m.set_obj(0, 15, x=5.6, y=5.0)
+    m.step(acts())
+    assert m.get('last_touch_side')[0] == RIGHT and m.get('vx')[0][22] == pytest.approx(0.5 * -0.1 * 0.94, rel=1e-5)
+    assert m.get('x')[0][15] - m.get('x')[0][22] == pytest.approx(0.385, rel=1e-5)
+
+
+def test_offside_is_called():
+    m = fresh(); play_on(m)
+    # left #10 (index 9) passes from midfield; left #11 (index 10) waits behind the last-but-one defender
+    for i in range(11, 22):
+        m.set_obj(0, i, x=30.0 - (i - 11), y=-30.0 + 2 * (i - 11))       # defenders at x = 30 .. 20
+    m.set_obj(0, 9, x=5.0, y=0.0, body=0.0)
+    m.set_obj(0, 22, x=5.5, y=0.0)
+    m.set_obj(0, 10, x=35.0, y=0.0)                                      # beyond 29 (second-last) and the ball
+    m.step(acts(p9=[MCMD_KICK, 100, 0]))
+    assert m.get('offside_mask')[0] == 1 << 10 and m.get('mode')[0] == GM_PLAY_ON
+    m.set_obj(0, 22, x=34.0, y=0.5, vx=0.0, vy=0.0)                      # ball arrives at the flagged player
+    m.step(acts())
+    assert m.get('mode')[0] == GM_OFF_SIDE and m.get('mode_side')[0] == RIGHT and m.stats()[6] == 1
+    assert m.get('x')[0][22] == pytest.approx(m.get('x')[0][10]) and m.get('offside_mask')[0] == 0
+    # not offside from a kick-in
+    m = fresh(); m.set_game(0, mode=GM_KICK_IN, mode_side=LEFT)
+    for i in range(11, 22):
+        m.set_obj(0, i, x=30.0 - (i - 11), y=-30.0 + 2 * (i - 11))
+    m.set_obj(0, 9, x=5.0, y=34.0, body=-90.0); m.set_obj(0, 22, x=5.0, y=33.5); m.set_obj(0, 10, x=35.0, y=0.0)
+    m.step(acts(p9=[MCMD_KICK, 50, 0]))
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('offside_mask')[0] == 0
+
+
+def test_half_time_and_time_over():
+    m = fresh(half_time_cycles=20, auto_reset=0)
+    play_on(m)
+    for _ in range(19):
+        m.step(acts(p3=[MCMD_DASH, 100, 0]))
+    assert m.get('stamina')[0][3] < 8000 and m.get('cycle')[0] == 19
+    m.step(acts())
+    assert m.get('cycle')[0] == 20 and m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == RIGHT
+    assert m.get('stamina')[0][3] == 8000 and m.get('stamina_capacity')[0][3] < 130600      # capacity is not restored
+    for _ in range(20):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1 and m.get('cycle')[0] == 40
+    m.step(acts(p3=[MCMD_DASH, 100, 0]))
+    assert m.get('done')[0] == 0 and m.get('vx')[0][3] == 0            # time over: commands ignored
+    m = fresh(half_time_cycles=5, auto_reset=1)
+    for _ in range(10):
+        m.step(acts())
+    assert m.get('done')[0] == 1 and m.get('cycle')[0] == 0 and m.get('mode')[0] == GM_KICK_OFF and m.stats()[3] == 1
+
+
+def test_random_matches_are_deterministic_and_eventful():
+    n = 64
+    a, b = fresh(n, half_time_cycles=400), fresh(n, half_time_cycles=400)
+    for _ in range(800):
+        a.step(None); b.step(None)
+    for f in MO.OBJ_FIELDS + MO.ENV_FIELDS:
+        assert np.array_equal(a.get(f), b.get(f)), f
+    st = a.stats()
+    assert st[0] == n * 800 and st[3] == n and st[4] > 0 and st[5] > 0 and st[7] > 0
+    assert np.isfinite(a.get('x')).all() and np.abs(a.get('x')[:, :22]).max() < 80
+    acts0 = a.random_actions()
+    assert set(np.unique(acts0[..., 0])) <= {1.0, 2.0, 3.0, 4.0}
+
+
+def test_nearest_player_reduction():
+    m = fresh(); play_on(m)
+    m.set_obj(0, 22, x=-34.0, y=6.0)
+    m.step(acts())
+    assert m.get('nearest_left')[0] == 3 and m.get('nearest_right')[0] in range(11, 22)
+    d = np.hypot(m.get('x')[0][11:22] - m.get('x')[0][22], m.get('y')[0][11:22] - m.get('y')[0][22])
+    assert m.get('nearest_right')[0] == 11 + int(np.argmin(d))
