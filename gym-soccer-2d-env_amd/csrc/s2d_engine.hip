@@ -561,6 +561,8 @@ __global__ void s2d_debug_eval_kernel(int op, const float* __restrict__ in, floa
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+// shared with s2d_match.hip (same library, hidden symbol)
+extern "C" void s2d_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
     hipError_t _e = (expr);                                                                   \

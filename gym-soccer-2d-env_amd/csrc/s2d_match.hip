@@ -1,0 +1,779 @@
+// s2d_match.hip -- 11v11 full-match engine for MI355X (gfx950): kernels + C ABI of
+// include/s2d_match.h.  Rules = rcssserver's, restated (EXT); the tests
+// hold an independent CPU restatement of the same rules which this file matches bit for bit.
+//
+// Mapping: ONE MATCH PER HALF-WAVE.  Lanes 0..21 of a 32-lane half are the players
+// (0..10 left team, 11..21 right team), lane 22 is the ball, lanes 23..31 idle; a wave runs
+// two matches, a 256-thread workgroup eight.  All per-object work (commands, movement,
+// stamina) is lane-local; the cross-object steps use half-wave shuffles (ds_bpermute, width
+// 32) and 64-bit ballots split per half:
+//   * kick / tackle impulses are summed into the ball in player order (fixed order = fixed
+//     fp32 result),
+//   * collisions are Jacobi passes: every lane scans the 23 objects of its match, proposes
+//     the symmetric contact position for each overlap and takes the mean (no ordering, no
+//     atomics), up to 10 passes,
+//   * referee decisions (goal, ball out, restarts, offside, half time) are evaluated
+//     redundantly by every lane of the half from broadcast values, so there is no divergence
+//     inside a match and no serial "referee lane",
+//   * nearest-player-to-ball per team is a 22-step scan in index order.
+// Every lane stays active for the whole kernel (shuffles need their source lanes), matches
+// beyond N only skip their loads and stores.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "s2d_device.h"
+#include "../../include/s2d_match.h"
+
+#define S2D_API extern "C" __attribute__((visibility("default")))
+
+static constexpr int kMBlock = 256;
+static constexpr int kHalf = 32;
+static constexpr int kEnvsPerBlock = kMBlock / kHalf;
+static constexpr int NP = S2D_MATCH_PLAYERS;
+static constexpr int BALL = S2D_MATCH_BALL;
+static constexpr int SLOTS = S2D_MATCH_SLOTS;
+
+enum { S2D_ST_TACKLE = 4 };
+enum { SIDE_NONE = 0, SIDE_LEFT = 1, SIDE_RIGHT = 2 };
+enum { MF_X, MF_Y, MF_VX, MF_VY, MF_BODY, MF_STAMINA, MF_EFFORT, MF_RECOVERY, MF_CAPACITY, MF_TACKLE, MF_OBJ_PLANES };
+enum { ME_CYCLE, ME_MODE, ME_MODE_SIDE, ME_SCORE_L, ME_SCORE_R, ME_LAST_TOUCH, ME_TIMER, ME_OFFSIDE, ME_REWARD, ME_NEAREST_L,
+       ME_NEAREST_R, ME_ENV_PLANES };
+
+struct MParams {   // every field rounded once on the host (double -> float)
+  float half_l, half_w, player_size, ball_size, player_decay, ball_decay, player_rand, ball_rand;
+  float player_speed_max, player_speed_max2, player_accel_max, player_accel_max2, ball_speed_max, ball_speed_max2;
+  float ball_accel_max, ball_accel_max2, inertia_moment;
+  float stamina_max, stamina_inc_max, stamina_capacity, extra_stamina;
+  float recover_init, recover_dec_thr_value, recover_min, recover_dec;
+  float effort_init, effort_dec_thr_value, effort_min, effort_dec, effort_inc_thr_value, effort_inc;
+  float dash_power_rate, max_dash_power, min_dash_power, max_dash_angle, min_dash_angle;
+  float dash_angle_step, inv_dash_angle_step, side_dash_rate, back_dash_rate, max_moment, min_moment;
+  float collision_vel_rate;
+  float kick_power_rate, kickable_area, kickable_margin, inv_kickable_margin, kick_rand, max_power, min_power, inv_max_power;
+  float tackle_dist, tackle_back_dist, tackle_width, tackle_power_rate, max_tackle_power, max_back_tackle_power;
+  float goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
+  int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside;
+  int auto_reset, noise;
+  uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
+};
+
+struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int tackle; };
+struct MGame { int cycle, mode, mode_side, score_l, score_r, last_touch, timer, offside; float reward; int done, nearest_l, nearest_r; };
+
+__constant__ float kFormX[11] = {-50.0f, -35.0f, -35.0f, -35.0f, -35.0f, -20.0f, -20.0f, -20.0f, -20.0f, -10.5f, -10.5f};
+__constant__ float kFormY[11] = {0.0f, -20.0f, -7.0f, 7.0f, 20.0f, -22.0f, -8.0f, 8.0f, 22.0f, -6.0f, 6.0f};
+
+S2D_DEV U4 m_draw(const MParams& p, uint32_t gl, uint32_t gh, uint32_t cyc, uint32_t stream, uint32_t block) {
+  return philox4x32_10(gl, gh, cyc, (stream << 16) | block, p.seed_lo, p.seed_hi);
+}
+S2D_DEV int side_of(int i) { return i < 11 ? SIDE_LEFT : SIDE_RIGHT; }
+S2D_DEV int other_side(int s) { return s == SIDE_LEFT ? SIDE_RIGHT : SIDE_LEFT; }
+S2D_DEV bool is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D_GM_TIME_OVER; }
+S2D_DEV float hbcast(float v, int src) { return __shfl(v, src, kHalf); }
+S2D_DEV int hbcasti(int v, int src) { return __shfl(v, src, kHalf); }
+// 32-bit ballot of this lane's half
+S2D_DEV uint32_t hballot(bool pred, int half) { return (uint32_t)(__ballot(pred) >> (half * kHalf)); }
+
+S2D_DEV void m_place(MObj& o, int l, int kickoff_side) {   // place_formation() for lane l
+  if (l < NP) {
+    int k = l % 11; bool left = l < 11;
+    o.x = left ? kFormX[k] : -kFormX[k]; o.y = kFormY[k];
+    o.vx = 0.0f; o.vy = 0.0f; o.body = left ? 0.0f : 180.0f; o.tackle = 0;
+    if (kickoff_side == SIDE_LEFT && l == 10) { o.x = -0.4f; o.y = 0.0f; }
+    if (kickoff_side == SIDE_RIGHT && l == 21) { o.x = 0.4f; o.y = 0.0f; }
+  } else if (l == BALL) {
+    o.x = 0.0f; o.y = 0.0f; o.vx = 0.0f; o.vy = 0.0f;
+  }
+}
+S2D_DEV void m_recover(const MParams& p, MObj& o, bool with_capacity) {
+  o.stamina = p.stamina_max; o.effort = p.effort_init; o.recovery = p.recover_init;
+  if (with_capacity) o.capacity = p.stamina_capacity;
+}
+S2D_DEV void m_reset(const MParams& p, MObj& o, MGame& g, int l) {
+  o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  g = MGame{0, S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0, 0, 0, 0.0f, 0, 10, 20};
+  if (l < NP) m_recover(p, o, true);
+  m_place(o, l, SIDE_LEFT);
+}
+S2D_DEV void m_dash(const MParams& p, MObj& o, float power, float dir, float& ax, float& ay) {
+  power = clampf(power, p.min_dash_power, p.max_dash_power);
+  dir = clampf(dir, p.min_dash_angle, p.max_dash_angle);
+  if (p.dash_angle_step > 0.0f) dir = p.dash_angle_step * rintf(dir * p.inv_dash_angle_step);
+  bool back = power < 0.0f;
+  float need = back ? power * -2.0f : power;
+  float avail = o.stamina + p.extra_stamina;
+  if (need > avail) need = avail;
+  float st = o.stamina - need;
+  o.stamina = st > 0.0f ? st : 0.0f;
+  power = back ? need / -2.0f : need;
+  float ad = fabsf(dir);
+  float dir_rate = ad > 90.0f
+      ? p.back_dash_rate - ((p.back_dash_rate - p.side_dash_rate) * (1.0f - (ad - 90.0f) * 0.011111111111111112f))
+      : p.side_dash_rate + ((1.0f - p.side_dash_rate) * (1.0f - ad * 0.011111111111111112f));
+  dir_rate = clampf(dir_rate, 0.0f, 1.0f);
+  float acc = fabsf(o.effort * power * dir_rate * p.dash_power_rate);
+  if (back) dir += 180.0f;
+  float sn, cs;
+  sincos_deg(norm_deg_any(o.body + dir), sn, cs);
+  ax = acc * cs; ay = acc * sn;
+}
+S2D_DEV void m_turn(const MParams& p, MObj& o, float moment, float noise_u) {
+  moment = clampf(moment, p.min_moment, p.max_moment);
+  float speed = hypot2(o.vx, o.vy);
+  float f = 1.0f;
+  if (p.noise) f = 1.0f + (noise_u * 2.0f - 1.0f) * p.player_rand;
+  o.body = norm_deg_any(o.body + f * moment / (1.0f + p.inertia_moment * speed));
+}
+S2D_DEV bool m_kick(const MParams& p, const MObj& o, float bx, float by, float bvx, float bvy, float power, float dir,
+                    float u_mag, float u_ang, float& kx, float& ky) {
+  float dx = bx - o.x, dy = by - o.y;
+  float dist = hypot2(dx, dy);
+  if (!(dist <= p.kickable_area)) return false;
+  power = clampf(power, p.min_power, p.max_power);
+  dir = clampf(dir, -180.0f, 180.0f);
+  float dir_diff = fabsf(norm_deg_any(atan2_deg(dy, dx) - o.body));
+  float dist_ball = dist - p.player_size - p.ball_size;
+  float eff = power * p.kick_power_rate * (1.0f - 0.25f * (dir_diff * 0.005555555555555556f)
+                                           - 0.25f * (dist_ball * p.inv_kickable_margin));
+  float sn, cs;
+  sincos_deg(norm_deg_any(o.body + dir), sn, cs);
+  float ax = eff * cs, ay = eff * sn;
+  if (p.noise) {
+    float pos_rate = 0.5f + 0.25f * (dir_diff * 0.005555555555555556f + dist_ball * p.inv_kickable_margin);
+    float speed_rate = 0.5f + 0.5f * (hypot2(bvx, bvy) * p.inv_speed_decay);
+    float max_rand = p.kick_rand * (power * p.inv_max_power) * (pos_rate + speed_rate);
+    float mag = u_mag * max_rand;
+    float s2, c2;
+    sincos_deg(u_ang * 360.0f - 180.0f, s2, c2);
+    ax += mag * c2; ay += mag * s2;
+  }
+  kx = ax; ky = ay;
+  return true;
+}
+S2D_DEV bool m_tackle(const MParams& p, const MObj& o, float bx, float by, float dir, float u, float& kx, float& ky) {
+  float dx = bx - o.x, dy = by - o.y;
+  float sn, cs;
+  sincos_deg(o.body, sn, cs);
+  float rx = dx * cs + dy * sn;
+  float ry = dy * cs - dx * sn;
+  float d = rx > 0.0f ? p.tackle_dist : p.tackle_back_dist;
+  float tx = d > 0.0f ? fabsf(rx) / d : (rx == 0.0f ? 0.0f : 1.0e9f);
+  float ty = fabsf(ry) / p.tackle_width;
+  float tx2 = tx * tx, ty2 = ty * ty;
+  float fail = tx2 * tx2 * tx2 + ty2 * ty2 * ty2;
+  if (!(u >= fail)) return false;
+  dir = clampf(dir, -180.0f, 180.0f);
+  float ang_ball = fabsf(norm_deg_any(atan2_deg(dy, dx) - o.body));
+  float eff = (p.max_back_tackle_power + (p.max_tackle_power - p.max_back_tackle_power) * (1.0f - fabsf(dir) * 0.005555555555555556f))
+              * p.tackle_power_rate * (1.0f - 0.5f * (ang_ball * 0.005555555555555556f));
+  float s2, c2;
+  sincos_deg(norm_deg_any(o.body + dir), s2, c2);
+  kx = eff * c2; ky = eff * s2;
+  return true;
+}
+S2D_DEV void m_update_stamina(const MParams& p, MObj& e) {
+  if (e.stamina <= p.recover_dec_thr_value) {
+    if (e.recovery > p.recover_min) { float r = e.recovery - p.recover_dec; e.recovery = r > p.recover_min ? r : p.recover_min; }
+  }
+  if (e.stamina <= p.effort_dec_thr_value) {
+    if (e.effort > p.effort_min) { float f = e.effort - p.effort_dec; e.effort = f > p.effort_min ? f : p.effort_min; }
+  }
+  if (e.stamina >= p.effort_inc_thr_value) {
+    if (e.effort < p.effort_init) { float f = e.effort + p.effort_inc; e.effort = f < p.effort_init ? f : p.effort_init; }
+  }
+  float inc = e.recovery * p.stamina_inc_max;
+  float room = p.stamina_max - e.stamina;
+  if (inc > room) inc = room;
+  if (p.stamina_capacity >= 0.0f) { if (inc > e.capacity) inc = e.capacity; }
+  e.stamina += inc;
+  if (e.stamina > p.stamina_max) e.stamina = p.stamina_max;
+  if (p.stamina_capacity >= 0.0f) { float c = e.capacity - inc; e.capacity = c > 0.0f ? c : 0.0f; }
+}
+S2D_DEV void m_noise(float& vx, float& vy, float rnd, float u_mag, float u_ang) {
+  float s = hypot2(vx, vy);
+  float mag = u_mag * (rnd * s);
+  float sn, cs;
+  sincos_deg(u_ang * 360.0f - 180.0f, sn, cs);
+  vx += mag * cs; vy += mag * sn;
+}
+
+struct MCounts { unsigned int goals_l, goals_r, finished, kicks, tackles, offsides, outs; };
+
+// One cycle of the match held by this half-wave.  l = lane within the half, half = 0/1.
+// cmd/a/b = this lane's command (players).  All 64 lanes execute every shuffle.
+S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, uint32_t gl, uint32_t gh, int cmd,
+                         float a, float bb, MCounts& cnt) {
+  const bool is_player = l < NP, is_ball = l == BALL;
+  const uint32_t cyc = (uint32_t)g.cycle;
+  const int mode0 = g.mode, side0 = g.mode_side;
+  const float x0 = o.x;
+  const float bx0 = hbcast(o.x, BALL), by0 = hbcast(o.y, BALL), bvx0 = hbcast(o.vx, BALL), bvy0 = hbcast(o.vy, BALL);
+  g.reward = 0.0f; g.done = 0;
+
+  // ---- 1. commands + player movement (lane-local)
+  float ax = 0.0f, ay = 0.0f, kx = 0.0f, ky = 0.0f;
+  bool kicked = false;
+  if (!is_player || o.tackle > 0 || mode0 == S2D_GM_TIME_OVER) cmd = S2D_MCMD_NONE;
+  U4 nz{0, 0, 0, 0}, nk{0, 0, 0, 0};
+  if (p.noise) { nz = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, (uint32_t)l); nk = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, 32u + (uint32_t)l); }
+  const bool may_touch = !is_setplay(mode0) || side_of(l) == side0;
+  if (cmd == S2D_MCMD_DASH) m_dash(p, o, a, bb, ax, ay);
+  else if (cmd == S2D_MCMD_TURN) m_turn(p, o, a, rnd_u01(nz.z));
+  else if (cmd == S2D_MCMD_KICK) {
+    bool ok = m_kick(p, o, bx0, by0, bvx0, bvy0, a, bb, rnd_u01(nk.x), rnd_u01(nk.y), kx, ky);
+    if (ok && may_touch) { kicked = true; cnt.kicks++; } else { kx = 0.0f; ky = 0.0f; }
+  } else if (cmd == S2D_MCMD_TACKLE) {
+    U4 w = m_draw(p, gl, gh, cyc, S2D_ST_TACKLE, (uint32_t)l);
+    bool ok = m_tackle(p, o, bx0, by0, a, rnd_u01(w.x), kx, ky);
+    o.tackle = p.tackle_cycles + 1;
+    cnt.tackles++;
+    if (ok && may_touch) kicked = true; else { kx = 0.0f; ky = 0.0f; }
+  }
+  if (is_player) {
+    if (cmd == S2D_MCMD_DASH) {
+      float a2 = sq2(ax, ay);
+      if (a2 > p.player_accel_max2) { float k = p.player_accel_max / sqrtf(a2); ax *= k; ay *= k; }
+      o.vx += ax; o.vy += ay;
+    }
+    float s2 = sq2(o.vx, o.vy);
+    if (s2 > p.player_speed_max2) { float k = p.player_speed_max / sqrtf(s2); o.vx *= k; o.vy *= k; }
+    if (p.noise) m_noise(o.vx, o.vy, p.player_rand, rnd_u01(nz.x), rnd_u01(nz.y));
+    o.x += o.vx; o.y += o.vy;
+  }
+  // ---- 2. ball: impulses summed in player order
+  const uint32_t kmask = hballot(kicked, half) & 0x3FFFFFu;
+  const bool any_kick = kmask != 0u;
+  const int last_kicker = any_kick ? 31 - __clz(kmask) : -1;
+  float bax = 0.0f, bay = 0.0f;
+  for (int j = 0; j < NP; ++j) {
+    float kxj = hbcast(kx, j), kyj = hbcast(ky, j);
+    if ((kmask >> j) & 1u) { bax += kxj; bay += kyj; }
+  }
+  if (any_kick) g.last_touch = side_of(last_kicker);
+  const bool ball_live = !is_setplay(mode0) || any_kick;
+  if (is_ball && ball_live) {
+    if (any_kick) {
+      float a2 = sq2(bax, bay);
+      if (a2 > p.ball_accel_max2) { float k = p.ball_accel_max / sqrtf(a2); bax *= k; bay *= k; }
+      o.vx += bax; o.vy += bay;
+    }
+    float s2 = sq2(o.vx, o.vy);
+    if (s2 > p.ball_speed_max2) { float k = p.ball_speed_max / sqrtf(s2); o.vx *= k; o.vy *= k; }
+    if (p.noise) m_noise(o.vx, o.vy, p.ball_rand, rnd_u01(nz.x), rnd_u01(nz.y));   // block 22 = the ball lane's own draw
+    o.x += o.vx; o.y += o.vy;
+  }
+  // ---- 3. collisions (Jacobi passes; loop bounds are wave-uniform)
+  bool collided = false;
+  int touch_player = -1;
+  const float ri = is_ball ? p.ball_size : p.player_size;
+  for (int pass = 0; pass < 10; ++pass) {
+    float sx = 0.0f, sy = 0.0f; int c = 0; int tp = -1;
+    for (int j = 0; j <= BALL; ++j) {
+      float xj = hbcast(o.x, j), yj = hbcast(o.y, j);
+      float rj = j == BALL ? p.ball_size : p.player_size;
+      float dx = o.x - xj, dy = o.y - yj;
+      float d2 = sq2(dx, dy), r = ri + rj;
+      if (l <= BALL && j != l && d2 < r * r) {
+        float d = sqrtf(d2), ux, uy;
+        if (d > 0.0f) { ux = dx / d; uy = dy / d; } else { ux = l < j ? -1.0f : 1.0f; uy = 0.0f; }
+        float mx = (o.x + xj) * 0.5f, my = (o.y + yj) * 0.5f, h = r * 0.5f;
+        sx += mx + ux * h; sy += my + uy * h; c++;
+        tp = j;
+      }
+    }
+    if (__ballot(c > 0) == 0ull) break;
+    if (c > 0) { o.x = sx / (float)c; o.y = sy / (float)c; collided = true; if (is_ball) touch_player = tp; }
+  }
+  if (collided) { o.vx *= p.collision_vel_rate; o.vy *= p.collision_vel_rate; }
+  touch_player = hbcasti(touch_player, BALL);
+  int coll_touch_side = SIDE_NONE;
+  if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
+    coll_touch_side = side_of(touch_player);
+    g.last_touch = coll_touch_side;
+  }
+  // ---- 4. set play: opponents keep their distance
+  {
+    float bxn = hbcast(o.x, BALL), byn = hbcast(o.y, BALL);
+    if (is_setplay(mode0) && is_player && side_of(l) != side0) {
+      float dx = o.x - bxn, dy = o.y - byn, d = hypot2(dx, dy);
+      if (d < p.free_kick_distance) {
+        float ux, uy;
+        if (d > 0.0f) { ux = dx / d; uy = dy / d; } else { ux = side_of(l) == SIDE_LEFT ? -1.0f : 1.0f; uy = 0.0f; }
+        o.x = bxn + ux * p.free_kick_distance; o.y = byn + uy * p.free_kick_distance;
+      }
+    }
+  }
+  // ---- 5. referee (every lane of the half evaluates the same decisions)
+  g.cycle += 1;
+  // inputs that need shuffles are gathered unconditionally (uniform control flow)
+  const float bx = hbcast(o.x, BALL), by = hbcast(o.y, BALL);
+  float first = -1.0e9f, second = -1.0e9f;      // two largest dirS*x0 among the kicker's opponents
+  const int S = any_kick ? side_of(last_kicker) : SIDE_LEFT;
+  const float dirS = S == SIDE_LEFT ? 1.0f : -1.0f;
+  {
+    const int o0 = S == SIDE_LEFT ? 11 : 0;
+    for (int j = 0; j < 11; ++j) {
+      float v = dirS * hbcast(x0, o0 + j);
+      if (v > first) { second = first; first = v; } else if (v > second) second = v;
+    }
+  }
+  bool restart_form = false; int form_side = SIDE_LEFT;      // formation placement requested
+  bool place_ball = false; float pbx = 0.0f, pby = 0.0f;     // ball placement requested
+  bool recover_half = false;
+  if (mode0 != S2D_GM_TIME_OVER) {
+    if (is_setplay(mode0)) {
+      if (any_kick) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; }
+      else { g.timer += 1; if (g.timer > p.drop_ball_time) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; } }
+    }
+    // offside candidates: each lane tests itself, the mask is assembled by ballot
+    float line = 0.0f;
+    if (second > line) line = second;
+    { float bl = dirS * bx0; if (bl > line) line = bl; }
+    const bool cand = is_player && side_of(l) == S && l != last_kicker && dirS * x0 > line;
+    const uint32_t cand_mask = hballot(cand, half) & 0x3FFFFFu;
+    // flagged players near the ball (for the offside call), tested on the post-move positions
+    const bool near_ball = is_player && sq2(o.x - bx, o.y - by) < p.offside_area2;
+    const uint32_t near_mask = hballot(near_ball, half) & 0x3FFFFFu;
+    if (g.mode == S2D_GM_PLAY_ON) {
+      if (any_kick) {
+        const bool exempt = mode0 == S2D_GM_KICK_IN || mode0 == S2D_GM_GOAL_KICK || mode0 == S2D_GM_CORNER_KICK;
+        g.offside = (p.use_offside && !exempt) ? (int)cand_mask : 0;
+      } else if (coll_touch_side != SIDE_NONE && g.offside) {
+        int flagged_side = (g.offside & 0x7FF) ? SIDE_LEFT : SIDE_RIGHT;
+        if (coll_touch_side != flagged_side) g.offside = 0;
+      }
+      if (bx > p.half_l && fabsf(by) < p.goal_half_width) {
+        g.score_l += 1; g.reward = 1.0f; if (is_ball) cnt.goals_l++;
+        restart_form = true; form_side = SIDE_RIGHT;
+        g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_RIGHT; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+      } else if (bx < -p.half_l && fabsf(by) < p.goal_half_width) {
+        g.score_r += 1; g.reward = -1.0f; if (is_ball) cnt.goals_r++;
+        restart_form = true; form_side = SIDE_LEFT;
+        g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_LEFT; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+      } else if (fabsf(bx) > p.half_l || fabsf(by) > p.half_w) {
+        if (is_ball) cnt.outs++;
+        int toucher = g.last_touch == SIDE_NONE ? SIDE_LEFT : g.last_touch;
+        float sy = by < 0.0f ? -1.0f : 1.0f, sxn = bx < 0.0f ? -1.0f : 1.0f;
+        place_ball = true; g.timer = 0; g.offside = 0;
+        if (fabsf(bx) <= p.half_l) {
+          g.mode = S2D_GM_KICK_IN; g.mode_side = other_side(toucher);
+          pbx = clampf(bx, -p.half_l, p.half_l); pby = sy * p.half_w;
+        } else {
+          int defender = bx > 0.0f ? SIDE_RIGHT : SIDE_LEFT;
+          if (toucher == defender) {
+            g.mode = S2D_GM_CORNER_KICK; g.mode_side = other_side(defender);
+            pbx = sxn * (p.half_l - 1.0f); pby = sy * (p.half_w - 1.0f);
+          } else {
+            g.mode = S2D_GM_GOAL_KICK; g.mode_side = defender;
+            pbx = sxn * (p.half_l - 5.5f); pby = sy * 9.16f;
+          }
+        }
+      } else if (g.offside) {
+        uint32_t hit = (uint32_t)g.offside & near_mask;
+        if (hit) {
+          int t = __ffs((int)hit) - 1;            // first flagged player in index order
+          if (is_ball) cnt.offsides++;
+          place_ball = true; pbx = 0.0f; pby = 0.0f;   // coordinates fetched below (needs a shuffle)
+          g.mode = S2D_GM_OFF_SIDE; g.mode_side = other_side(side_of(t)); g.timer = 0;
+          g.offside = -1 - t;                       // marker: ball goes to player t (resolved below)
+        }
+      }
+    }
+    int total = p.half_time_cycles * p.nr_normal_halfs;
+    if (g.cycle >= total) {
+      g.mode = S2D_GM_TIME_OVER; g.mode_side = SIDE_NONE; g.done = 1; if (g.offside > 0) g.offside = 0; if (is_ball) cnt.finished++;
+    } else if (p.half_time_cycles > 0 && g.cycle % p.half_time_cycles == 0) {
+      int k = g.cycle / p.half_time_cycles;
+      int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
+      recover_half = true; restart_form = true; form_side = ks; place_ball = false;
+      g.mode = S2D_GM_KICK_OFF; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+    }
+  }
+  // resolve the offside spot (uniform shuffle, then apply)
+  {
+    int t = g.offside < 0 ? -1 - g.offside : 0;
+    float tx = hbcast(o.x, t), ty = hbcast(o.y, t);
+    if (g.offside < 0) {
+      if (place_ball) { pbx = tx; pby = ty; }
+      g.offside = 0;
+    }
+  }
+  if (recover_half && is_player) m_recover(p, o, false);
+  if (restart_form) m_place(o, l, form_side);
+  else if (place_ball && is_ball) { o.x = pbx; o.y = pby; o.vx = 0.0f; o.vy = 0.0f; }
+  // ---- 6. decay, tackle timers, stamina
+  if (is_player) {
+    o.vx *= p.player_decay; o.vy *= p.player_decay;
+    if (o.tackle > 0) o.tackle -= 1;
+    m_update_stamina(p, o);
+  } else if (is_ball) {
+    o.vx *= p.ball_decay; o.vy *= p.ball_decay;
+  }
+  // ---- 7. nearest player to the ball per team: scan in index order (ties -> lowest index)
+  {
+    float bxn = hbcast(o.x, BALL), byn = hbcast(o.y, BALL);
+    float d2 = sq2(o.x - bxn, o.y - byn);
+    float best_l = 3.0e38f, best_r = 3.0e38f; int il = 0, ir = 11;
+    for (int j = 0; j < NP; ++j) {
+      float dj = hbcast(d2, j);
+      if (j < 11) { if (dj < best_l) { best_l = dj; il = j; } } else { if (dj < best_r) { best_r = dj; ir = j; } }
+    }
+    g.nearest_l = il; g.nearest_r = ir;
+  }
+  if (g.done && p.auto_reset) {
+    int d = g.done; float rw = g.reward;
+    m_reset(p, o, g, l);
+    g.done = d; g.reward = rw;
+  }
+}
+
+// benchmark policy: Philox POLICY stream, block = player
+S2D_DEV void m_random_action(const MParams& p, uint32_t gl, uint32_t gh, uint32_t cyc, int l, int& cmd, float& a, float& b) {
+  U4 w = m_draw(p, gl, gh, cyc, S2D_ST_POLICY, (uint32_t)l);
+  cmd = 1 + rnd_below(w.x, 4);
+  float u = rnd_u01(w.y), s = rnd_u01(w.z) * 2.0f - 1.0f;
+  b = 0.0f;
+  if (cmd == S2D_MCMD_DASH || cmd == S2D_MCMD_KICK) { a = u * 100.0f; b = s * 180.0f; }
+  else { a = s * 180.0f; }
+}
+
+// ------------------------------------------------------------------------------------------
+// memory <-> registers
+// ------------------------------------------------------------------------------------------
+struct MPtrs { float* obj; int32_t* env; float* reward; uint8_t* done; unsigned long long* stats; int64_t obj_stride; int64_t env_stride; };
+
+S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g) {
+  o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (l < SLOTS) {
+    int64_t k = e * SLOTS + l;
+    o.x = q.obj[MF_X * q.obj_stride + k]; o.y = q.obj[MF_Y * q.obj_stride + k];
+    o.vx = q.obj[MF_VX * q.obj_stride + k]; o.vy = q.obj[MF_VY * q.obj_stride + k];
+    o.body = q.obj[MF_BODY * q.obj_stride + k];
+    o.stamina = q.obj[MF_STAMINA * q.obj_stride + k]; o.effort = q.obj[MF_EFFORT * q.obj_stride + k];
+    o.recovery = q.obj[MF_RECOVERY * q.obj_stride + k]; o.capacity = q.obj[MF_CAPACITY * q.obj_stride + k];
+    o.tackle = __float_as_int(q.obj[MF_TACKLE * q.obj_stride + k]);
+  }
+  g.cycle = q.env[ME_CYCLE * q.env_stride + e]; g.mode = q.env[ME_MODE * q.env_stride + e];
+  g.mode_side = q.env[ME_MODE_SIDE * q.env_stride + e]; g.score_l = q.env[ME_SCORE_L * q.env_stride + e];
+  g.score_r = q.env[ME_SCORE_R * q.env_stride + e]; g.last_touch = q.env[ME_LAST_TOUCH * q.env_stride + e];
+  g.timer = q.env[ME_TIMER * q.env_stride + e]; g.offside = q.env[ME_OFFSIDE * q.env_stride + e];
+  g.reward = 0.0f; g.done = 0; g.nearest_l = q.env[ME_NEAREST_L * q.env_stride + e]; g.nearest_r = q.env[ME_NEAREST_R * q.env_stride + e];
+}
+S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGame& g) {
+  if (l < SLOTS) {
+    int64_t k = e * SLOTS + l;
+    q.obj[MF_X * q.obj_stride + k] = o.x; q.obj[MF_Y * q.obj_stride + k] = o.y;
+    q.obj[MF_VX * q.obj_stride + k] = o.vx; q.obj[MF_VY * q.obj_stride + k] = o.vy;
+    q.obj[MF_BODY * q.obj_stride + k] = o.body;
+    q.obj[MF_STAMINA * q.obj_stride + k] = o.stamina; q.obj[MF_EFFORT * q.obj_stride + k] = o.effort;
+    q.obj[MF_RECOVERY * q.obj_stride + k] = o.recovery; q.obj[MF_CAPACITY * q.obj_stride + k] = o.capacity;
+    q.obj[MF_TACKLE * q.obj_stride + k] = __int_as_float(o.tackle);
+  }
+  if (l == BALL) {
+    q.env[ME_CYCLE * q.env_stride + e] = g.cycle; q.env[ME_MODE * q.env_stride + e] = g.mode;
+    q.env[ME_MODE_SIDE * q.env_stride + e] = g.mode_side; q.env[ME_SCORE_L * q.env_stride + e] = g.score_l;
+    q.env[ME_SCORE_R * q.env_stride + e] = g.score_r; q.env[ME_LAST_TOUCH * q.env_stride + e] = g.last_touch;
+    q.env[ME_TIMER * q.env_stride + e] = g.timer; q.env[ME_OFFSIDE * q.env_stride + e] = g.offside;
+    q.env[ME_NEAREST_L * q.env_stride + e] = g.nearest_l; q.env[ME_NEAREST_R * q.env_stride + e] = g.nearest_r;
+    q.reward[e] = g.reward; q.done[e] = (uint8_t)g.done;
+  }
+}
+S2D_DEV void m_flush_counts(const MCounts& c, bool valid, unsigned long long* stats) {
+  // per-lane counters -> wave sums by shuffle tree -> one atomic per wave and counter
+  unsigned int v[7] = {c.goals_l, c.goals_r, c.finished, c.kicks, c.tackles, c.offsides, c.outs};
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    unsigned int s = valid ? v[k] : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[1 + k], (unsigned long long)s);
+  }
+}
+
+__global__ __launch_bounds__(kMBlock) void s2d_match_reset_kernel(MParams p, MPtrs q, int64_t n, const uint8_t* __restrict__ mask) {
+  const int l = threadIdx.x & (kHalf - 1);
+  const int64_t e = (int64_t)blockIdx.x * kEnvsPerBlock + threadIdx.x / kHalf;
+  if (e >= n) return;
+  if (mask && !mask[e]) return;
+  MObj o; MGame g;
+  m_reset(p, o, g, l);
+  m_store(q, e, l, o, g);
+}
+
+struct MRoll { float* obs; float* reward; int32_t* mode; uint8_t* done; };
+
+// n_steps cycles; actions = [T][N][22][3] or NULL (random policy).  n_steps = 1 with ro = {} is the per-step API.
+__global__ __launch_bounds__(kMBlock) void s2d_match_rollout_kernel(MParams p, MPtrs q, int64_t n, int n_steps,
+                                                                     const float* __restrict__ actions, MRoll ro) {
+  const int l = threadIdx.x & (kHalf - 1);
+  const int half = (threadIdx.x >> 5) & 1;
+  const int64_t e = (int64_t)blockIdx.x * kEnvsPerBlock + threadIdx.x / kHalf;
+  const bool valid = e < n;
+  const int64_t ec = valid ? e : n - 1;              // lanes of out-of-range matches shadow the last match (no stores)
+  MObj o; MGame g;
+  m_load(q, ec, l, o, g);
+  const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)ec;
+  const uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
+  MCounts cnt{0, 0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < n_steps; ++t) {
+    int cmd = S2D_MCMD_NONE; float a = 0.0f, b = 0.0f;
+    if (l < NP) {
+      if (actions) {
+        const float* ap = actions + (((int64_t)t * n + ec) * NP + l) * 3;
+        cmd = (int)ap[0]; a = ap[1]; b = ap[2];
+      } else {
+        m_random_action(p, gl, gh, (uint32_t)g.cycle, l, cmd, a, b);
+      }
+    }
+    match_cycle(p, o, g, l, half, gl, gh, cmd, a, b, cnt);
+    if (valid) {
+      const int64_t row = (int64_t)t * n + e;
+      if (ro.obs && l < SLOTS) {
+        float* d = ro.obs + (row * SLOTS + l) * S2D_MATCH_OBJ_WORDS;
+        d[0] = o.x; d[1] = o.y; d[2] = o.vx; d[3] = o.vy; d[4] = o.body;
+      }
+      if (l == BALL) {
+        if (ro.reward) ro.reward[row] = g.reward;
+        if (ro.mode) ro.mode[row] = g.mode;
+        if (ro.done) ro.done[row] = (uint8_t)g.done;
+      }
+    }
+  }
+  if (valid) m_store(q, e, l, o, g);
+  m_flush_counts(cnt, valid, q.stats);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&q.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct S2DMatchEngine {
+  S2DMatchConfig cfg; MParams mp; int64_t n, stride; int device;
+  char* arena; size_t arena_bytes; bool owns_arena;
+  S2DMatchBuffers buf; MPtrs ptrs;
+};
+
+// errors share the thread-local text of s2d_last_error() (defined in s2d_engine.hip)
+extern "C" void s2d_internal_set_error(const char* msg);
+static int mfail(int code, const std::string& msg) { s2d_internal_set_error(msg.c_str()); return code; }
+#define MHIP_TRY(expr)                                                                          \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) return mfail(S2D_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+static size_t m_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
+struct MLayout { size_t obj, env, reward, done, stats, total; int64_t stride; };
+static MLayout m_layout(int64_t n) {
+  MLayout L; L.stride = (int64_t)m_align((size_t)n, 64);
+  size_t off = 0;
+  L.obj = off; off += m_align((size_t)MF_OBJ_PLANES * (size_t)L.stride * SLOTS * 4, 256);
+  L.env = off; off += m_align((size_t)ME_ENV_PLANES * (size_t)L.stride * 4, 256);
+  L.reward = off; off += m_align((size_t)L.stride * 4, 256);
+  L.done = off; off += m_align((size_t)L.stride, 256);
+  L.stats = off; off += 256;
+  L.total = off;
+  return L;
+}
+
+S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
+  if (!c) return;
+  S2DConfig base; s2d_default_config(&base);
+  std::memset(c, 0, sizeof *c);
+  c->abi_version = S2D_ABI_VERSION; c->struct_bytes = (uint32_t)sizeof(S2DMatchConfig);
+  c->sp = base.sp;
+  S2DMatchParams& m = c->mp;   // rcssserver stock values (EXT)
+  m.kick_power_rate = 0.027; m.kickable_margin = 0.7; m.kick_rand = 0.1; m.max_power = 100.0; m.min_power = -100.0;
+  m.tackle_dist = 2.0; m.tackle_back_dist = 0.0; m.tackle_width = 1.25; m.tackle_power_rate = 0.027;
+  m.max_tackle_power = 100.0; m.max_back_tackle_power = 0.0;
+  m.goal_width = 14.02; m.offside_active_area_size = 2.5; m.free_kick_distance = 9.15;
+  m.tackle_cycles = 10; m.half_time_cycles = 3000; m.nr_normal_halfs = 2; m.drop_ball_time = 100; m.use_offside = 1;
+  c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
+}
+
+S2D_API int s2d_match_validate_config(const S2DMatchConfig* c) {
+  if (!c) return mfail(S2D_EINVAL, "config is NULL");
+  if (c->abi_version != S2D_ABI_VERSION) return mfail(S2D_EINVAL, "config.abi_version mismatch");
+  if (c->struct_bytes != sizeof(S2DMatchConfig)) return mfail(S2D_EINVAL, "config.struct_bytes != sizeof(S2DMatchConfig)");
+  if (!(c->sp.pitch_half_length > 0) || !(c->sp.pitch_half_width > 0)) return mfail(S2D_EINVAL, "pitch extents must be > 0");
+  if (!(c->mp.kickable_margin > 0) || !(c->mp.max_power > 0) || !(c->mp.tackle_width > 0))
+    return mfail(S2D_EINVAL, "kickable_margin, max_power and tackle_width must be > 0");
+  if (c->mp.half_time_cycles < 1 || c->mp.nr_normal_halfs < 1) return mfail(S2D_EINVAL, "half_time_cycles and nr_normal_halfs must be >= 1");
+  if (c->mp.tackle_cycles < 0 || c->mp.drop_ball_time < 0) return mfail(S2D_EINVAL, "tackle_cycles / drop_ball_time must be >= 0");
+  if (c->env_id_offset < 0) return mfail(S2D_EINVAL, "env_id_offset must be >= 0");
+  return S2D_OK;
+}
+
+static void mparams_from_config(const S2DMatchConfig& c, MParams& p) {
+  const S2DServerParams& s = c.sp; const S2DMatchParams& m = c.mp;
+  std::memset(&p, 0, sizeof p);
+  p.half_l = (float)s.pitch_half_length; p.half_w = (float)s.pitch_half_width;
+  p.player_size = (float)s.player_size; p.ball_size = (float)s.ball_size;
+  p.player_decay = (float)s.player_decay; p.ball_decay = (float)s.ball_decay;
+  p.player_rand = (float)s.player_rand; p.ball_rand = (float)s.ball_rand;
+  p.player_speed_max = (float)s.player_speed_max; p.player_speed_max2 = p.player_speed_max * p.player_speed_max;
+  p.player_accel_max = (float)s.player_accel_max; p.player_accel_max2 = p.player_accel_max * p.player_accel_max;
+  p.ball_speed_max = (float)s.ball_speed_max; p.ball_speed_max2 = p.ball_speed_max * p.ball_speed_max;
+  p.ball_accel_max = (float)s.ball_accel_max; p.ball_accel_max2 = p.ball_accel_max * p.ball_accel_max;
+  p.inertia_moment = (float)s.inertia_moment;
+  p.stamina_max = (float)s.stamina_max; p.stamina_inc_max = (float)s.stamina_inc_max;
+  p.stamina_capacity = (float)s.stamina_capacity; p.extra_stamina = (float)s.extra_stamina;
+  p.recover_init = (float)s.recover_init; p.recover_dec_thr_value = (float)(s.recover_dec_thr * s.stamina_max);
+  p.recover_min = (float)s.recover_min; p.recover_dec = (float)s.recover_dec;
+  p.effort_init = (float)s.effort_init; p.effort_dec_thr_value = (float)(s.effort_dec_thr * s.stamina_max);
+  p.effort_min = (float)s.effort_min; p.effort_dec = (float)s.effort_dec;
+  p.effort_inc_thr_value = (float)(s.effort_inc_thr * s.stamina_max); p.effort_inc = (float)s.effort_inc;
+  p.dash_power_rate = (float)s.dash_power_rate; p.max_dash_power = (float)s.max_dash_power;
+  p.min_dash_power = (float)s.min_dash_power; p.max_dash_angle = (float)s.max_dash_angle;
+  p.min_dash_angle = (float)s.min_dash_angle; p.dash_angle_step = (float)s.dash_angle_step;
+  p.inv_dash_angle_step = s.dash_angle_step > 0 ? (float)(1.0 / s.dash_angle_step) : 0.0f;
+  p.side_dash_rate = (float)s.side_dash_rate; p.back_dash_rate = (float)s.back_dash_rate;
+  p.max_moment = (float)s.max_moment; p.min_moment = (float)s.min_moment;
+  p.collision_vel_rate = (float)s.collision_vel_rate;
+  p.kick_power_rate = (float)m.kick_power_rate; p.kickable_margin = (float)m.kickable_margin;
+  p.inv_kickable_margin = (float)(1.0 / m.kickable_margin);
+  p.kickable_area = p.player_size + p.ball_size + p.kickable_margin;
+  p.kick_rand = (float)m.kick_rand; p.max_power = (float)m.max_power; p.min_power = (float)m.min_power;
+  p.inv_max_power = (float)(1.0 / m.max_power);
+  p.tackle_dist = (float)m.tackle_dist; p.tackle_back_dist = (float)m.tackle_back_dist;
+  p.tackle_width = (float)m.tackle_width; p.tackle_power_rate = (float)m.tackle_power_rate;
+  p.max_tackle_power = (float)m.max_tackle_power; p.max_back_tackle_power = (float)m.max_back_tackle_power;
+  p.goal_half_width = (float)(m.goal_width * 0.5);
+  p.offside_area2 = (float)(m.offside_active_area_size * m.offside_active_area_size);
+  p.free_kick_distance = (float)m.free_kick_distance;
+  p.inv_speed_decay = (float)(1.0 / (s.ball_speed_max * s.ball_decay));
+  p.tackle_cycles = m.tackle_cycles; p.half_time_cycles = m.half_time_cycles;
+  p.nr_normal_halfs = m.nr_normal_halfs; p.drop_ball_time = m.drop_ball_time; p.use_offside = m.use_offside;
+  p.auto_reset = c.auto_reset; p.noise = c.noise;
+  p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
+  p.gid_lo = (uint32_t)(uint64_t)c.env_id_offset; p.gid_hi = (uint32_t)((uint64_t)c.env_id_offset >> 32);
+}
+
+S2D_API size_t s2d_match_arena_bytes(const S2DMatchConfig* cfg, int64_t n_envs) {
+  if (!cfg || n_envs <= 0) return 0;
+  return m_layout(n_envs).total;
+}
+
+struct MDeviceGuard {
+  int prev = -1; bool ok = false;
+  explicit MDeviceGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess) ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess); }
+  ~MDeviceGuard() { if (ok && prev >= 0) (void)hipSetDevice(prev); }
+};
+static unsigned m_grid(int64_t n) { return (unsigned)((n + kEnvsPerBlock - 1) / kEnvsPerBlock); }
+
+S2D_API int s2d_match_reset(S2DMatchHandle h, const uint8_t* mask_dev, void* stream) {
+  if (!h) return mfail(S2D_EINVAL, "NULL handle");
+  MDeviceGuard guard(h->device);
+  hipLaunchKernelGGL(s2d_match_reset_kernel, dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
+                     h->ptrs, h->n, mask_dev);
+  MHIP_TRY(hipGetLastError());
+  return S2D_OK;
+}
+
+S2D_API int s2d_match_create(const S2DMatchConfig* cfg, int64_t n_envs, int device, void* arena_dev, size_t arena_bytes,
+                             void* stream, S2DMatchHandle* out) {
+  if (!out) return mfail(S2D_EINVAL, "out handle is NULL");
+  *out = nullptr;
+  int rc = s2d_match_validate_config(cfg);
+  if (rc != S2D_OK) return rc;
+  if (n_envs <= 0 || n_envs > (int64_t)1 << 28) return mfail(S2D_EINVAL, "n_envs must be in [1, 2^28]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return mfail(S2D_ENODEV, "no HIP device visible");
+  if (device < 0 || device >= ndev) return mfail(S2D_EINVAL, "device index out of range");
+  MDeviceGuard guard(device);
+  if (!guard.ok) return mfail(S2D_EHIP, "hipSetDevice failed");
+  MLayout L = m_layout(n_envs);
+  S2DMatchEngine* h = new (std::nothrow) S2DMatchEngine();
+  if (!h) return mfail(S2D_ENOMEM, "host allocation failed");
+  h->cfg = *cfg; h->n = n_envs; h->stride = L.stride; h->device = device;
+  mparams_from_config(*cfg, h->mp);
+  if (arena_dev) {
+    if (arena_bytes < L.total) { delete h; return mfail(S2D_ENOMEM, "arena smaller than s2d_match_arena_bytes()"); }
+    if (reinterpret_cast<uintptr_t>(arena_dev) & 255u) { delete h; return mfail(S2D_EINVAL, "arena must be 256-byte aligned"); }
+    h->arena = static_cast<char*>(arena_dev); h->owns_arena = false;
+  } else {
+    void* pmem = nullptr;
+    if (hipMalloc(&pmem, L.total) != hipSuccess) { delete h; return mfail(S2D_ENOMEM, "hipMalloc of the arena failed"); }
+    h->arena = static_cast<char*>(pmem); h->owns_arena = true;
+  }
+  h->arena_bytes = L.total;
+  float* obj = reinterpret_cast<float*>(h->arena + L.obj);
+  int32_t* env = reinterpret_cast<int32_t*>(h->arena + L.env);
+  const size_t os = (size_t)L.stride * SLOTS, es = (size_t)L.stride;
+  S2DMatchBuffers& b = h->buf;
+  b.n_envs = n_envs;
+  b.x = obj + MF_X * os; b.y = obj + MF_Y * os; b.vx = obj + MF_VX * os; b.vy = obj + MF_VY * os; b.body = obj + MF_BODY * os;
+  b.stamina = obj + MF_STAMINA * os; b.effort = obj + MF_EFFORT * os; b.recovery = obj + MF_RECOVERY * os;
+  b.stamina_capacity = obj + MF_CAPACITY * os; b.tackle_cycles = reinterpret_cast<int32_t*>(obj + MF_TACKLE * os);
+  b.cycle = env + ME_CYCLE * es; b.mode = env + ME_MODE * es; b.mode_side = env + ME_MODE_SIDE * es;
+  b.score_left = env + ME_SCORE_L * es; b.score_right = env + ME_SCORE_R * es; b.last_touch_side = env + ME_LAST_TOUCH * es;
+  b.setplay_timer = env + ME_TIMER * es; b.offside_mask = env + ME_OFFSIDE * es;
+  b.reward_left = reinterpret_cast<float*>(h->arena + L.reward);
+  b.done = reinterpret_cast<uint8_t*>(h->arena + L.done);
+  b.nearest_left = env + ME_NEAREST_L * es; b.nearest_right = env + ME_NEAREST_R * es;
+  b.stats = reinterpret_cast<unsigned long long*>(h->arena + L.stats);
+  h->ptrs = MPtrs{obj, env, b.reward_left, b.done, b.stats, (int64_t)os, (int64_t)es};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(h->arena, 0, L.total, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(s2d_match_reset_kernel, dim3(m_grid(n_envs)), dim3(kMBlock), 0, st, h->mp, h->ptrs, h->n,
+                       (const uint8_t*)nullptr);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) {
+    std::string msg = std::string("arena initialisation: ") + hipGetErrorString(e);
+    if (h->owns_arena) (void)hipFree(h->arena);
+    delete h;
+    return mfail(S2D_EHIP, msg);
+  }
+  *out = h;
+  return S2D_OK;
+}
+
+S2D_API void s2d_match_destroy(S2DMatchHandle h) {
+  if (!h) return;
+  if (h->owns_arena && h->arena) { MDeviceGuard guard(h->device); (void)hipFree(h->arena); }
+  delete h;
+}
+S2D_API int s2d_match_buffers(S2DMatchHandle h, S2DMatchBuffers* out) {
+  if (!h || !out) return mfail(S2D_EINVAL, "NULL argument");
+  *out = h->buf;
+  return S2D_OK;
+}
+S2D_API int s2d_match_buffer_offsets(S2DMatchHandle h, int64_t* offsets, int n_offsets) {
+  if (!h || !offsets) return mfail(S2D_EINVAL, "NULL argument");
+  const S2DMatchBuffers& b = h->buf;
+  const void* ptrs[] = {b.x, b.y, b.vx, b.vy, b.body, b.stamina, b.effort, b.recovery, b.stamina_capacity, b.tackle_cycles,
+                        b.cycle, b.mode, b.mode_side, b.score_left, b.score_right, b.last_touch_side, b.setplay_timer,
+                        b.offside_mask, b.reward_left, b.done, b.nearest_left, b.nearest_right, b.stats};
+  const int count = 1 + (int)(sizeof ptrs / sizeof ptrs[0]);
+  if (n_offsets < count) return mfail(S2D_EINVAL, "offsets array too small (need 24)");
+  offsets[0] = (int64_t)h->arena_bytes;
+  for (int k = 1; k < count; ++k) offsets[k] = (int64_t)(static_cast<const char*>(ptrs[k - 1]) - h->arena);
+  return S2D_OK;
+}
+
+static int m_launch(S2DMatchHandle h, int n_steps, const float* actions, const S2DMatchRollout* out, void* stream) {
+  MRoll ro{nullptr, nullptr, nullptr, nullptr};
+  if (out) ro = MRoll{out->obs, out->reward, out->mode, out->done};
+  MDeviceGuard guard(h->device);
+  hipLaunchKernelGGL(s2d_match_rollout_kernel, dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
+                     h->ptrs, h->n, n_steps, actions, ro);
+  MHIP_TRY(hipGetLastError());
+  return S2D_OK;
+}
+S2D_API int s2d_match_step(S2DMatchHandle h, const float* actions_dev, void* stream) {
+  if (!h) return mfail(S2D_EINVAL, "NULL handle");
+  return m_launch(h, 1, actions_dev, nullptr, stream);
+}
+S2D_API int s2d_match_rollout(S2DMatchHandle h, int n_steps, const float* actions_dev, const S2DMatchRollout* out, void* stream) {
+  if (!h) return mfail(S2D_EINVAL, "NULL handle");
+  if (n_steps < 0) return mfail(S2D_EINVAL, "n_steps must be >= 0");
+  if (n_steps == 0) return S2D_OK;
+  return m_launch(h, n_steps, actions_dev, out, stream);
+}

@@ -1,0 +1,145 @@
+"""MatchEngine / Soccer2DMatchVecEnv: N lockstep 11v11 matches on one MI355X (include/s2d_match.h).
+
+The reference has no 11v11 task env; what is mirrored is the protobuf schema its agents see
+and speak: per-cycle body commands {Dash, Turn, Kick, Tackle} (idl/service.proto:380-402) in,
+WorldModel-shaped tensors (ball, teammates/opponents tables, game_mode_type, scores, cycle;
+idl/service.proto:144-175, 306-349) out.  Device tensors end to end, zero-copy views of the
+engine arena, launches on torch's current stream.  No CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi, _capi_match as M
+
+_TD = {'float32': torch.float32, 'int32': torch.int32, 'uint8': torch.uint8, 'int64': torch.int64}
+_ITEM = {'float32': 4, 'int32': 4, 'uint8': 1, 'int64': 8}
+
+
+def make_match_config(seed=0x5EED, env_id_offset=0, auto_reset=True, noise=False, server_params=None, **match_params):
+    lib = M.bind(_capi.load_library())
+    cfg = M.S2DMatchConfig()
+    lib.s2d_match_default_config(C.byref(cfg))
+    for k, v in (server_params or {}).items():
+        if not hasattr(cfg.sp, k):
+            raise ValueError(f"unknown ServerParam field {k!r}")
+        setattr(cfg.sp, k, float(v))
+    for k, v in match_params.items():
+        if not hasattr(cfg.mp, k):
+            raise ValueError(f"unknown match parameter {k!r}")
+        setattr(cfg.mp, k, type(getattr(cfg.mp, k))(v))
+    cfg.seed, cfg.env_id_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(env_id_offset)
+    cfg.auto_reset, cfg.noise = int(bool(auto_reset)), int(bool(noise))
+    _capi.check(lib, lib.s2d_match_validate_config(C.byref(cfg)), 's2d_match_validate_config')
+    return cfg
+
+
+class MatchEngine:
+    def __init__(self, num_envs, device='cuda:0', cfg=None, **kwargs):
+        self.lib = M.bind(_capi.load_library())
+        if not torch.cuda.is_available():
+            raise RuntimeError("the s2d HIP engine needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.cfg = cfg if cfg is not None else make_match_config(**kwargs)
+        self.num_envs = int(num_envs)
+        if self.num_envs <= 0:
+            raise ValueError("num_envs must be positive")
+        nbytes = self.lib.s2d_match_arena_bytes(C.byref(self.cfg), self.num_envs)
+        self._raw = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        shift = (-self._raw.data_ptr()) % 256
+        self.arena = self._raw[shift:shift + nbytes]
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.s2d_match_create(C.byref(self.cfg), self.num_envs, self.device.index, self.arena.data_ptr(), nbytes,
+                                           self._stream(), C.byref(h))
+        _capi.check(self.lib, rc, 's2d_match_create')
+        self._h = h
+        off = (C.c_int64 * 24)()
+        _capi.check(self.lib, self.lib.s2d_match_buffer_offsets(self._h, off, 24), 's2d_match_buffer_offsets')
+        n = self.num_envs
+        for k, (name, _ct, dt, trail) in enumerate(M.MATCH_BUFFER_FIELDS):
+            o = off[k + 1]
+            shape = (8,) if trail is None else (n,) + tuple(trail)
+            count = 1
+            for d in shape:
+                count *= d
+            setattr(self, name, self.arena[o:o + count * _ITEM[dt]].view(_TD[dt]).view(shape))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.s2d_match_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _actions(self, actions, T=None):
+        if actions is None:
+            return None, None
+        a = torch.as_tensor(actions, device=self.device).to(torch.float32).contiguous()
+        want = (self.num_envs, M.MATCH_PLAYERS, 3) if T is None else (T, self.num_envs, M.MATCH_PLAYERS, 3)
+        if tuple(a.shape) != want:
+            raise ValueError(f"actions must have shape {want}, got {tuple(a.shape)}")
+        return a, C.c_void_p(a.data_ptr())
+
+    def reset(self, mask=None):
+        ptr = None
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            if tuple(mask.shape) != (self.num_envs,):
+                raise ValueError(f"mask must have shape ({self.num_envs},)")
+            ptr = C.c_void_p(mask.data_ptr())
+        _capi.check(self.lib, self.lib.s2d_match_reset(self._h, ptr, self._stream()), 's2d_match_reset')
+        self._keep = mask
+
+    def step(self, actions=None):
+        """actions float[N,22,3] = (command, a, b) per player, None = random policy."""
+        keep, ptr = self._actions(actions)
+        _capi.check(self.lib, self.lib.s2d_match_step(self._h, ptr, self._stream()), 's2d_match_step')
+        self._keep = keep
+        return self.reward_left, self.done
+
+    def alloc_rollout(self, T, with_obs=True):
+        n, dev = self.num_envs, self.device
+        return dict(obs=torch.empty((T, n, M.MATCH_SLOTS, M.MATCH_OBJ_WORDS), dtype=torch.float32, device=dev) if with_obs else None,
+                    reward=torch.empty((T, n), dtype=torch.float32, device=dev),
+                    mode=torch.empty((T, n), dtype=torch.int32, device=dev),
+                    done=torch.empty((T, n), dtype=torch.uint8, device=dev))
+
+    def rollout(self, n_steps, actions=None, out=None, with_obs=True):
+        T = int(n_steps)
+        keep, ptr = self._actions(actions, T)
+        if out is None:
+            out = self.alloc_rollout(T, with_obs)
+        ro = M.S2DMatchRollout()
+        for name in ('obs', 'reward', 'mode', 'done'):
+            v = out.get(name)
+            if v is not None:
+                if not v.is_contiguous() or v.shape[0] < T or v.shape[1] != self.num_envs:
+                    raise ValueError(f"rollout buffer {name!r} must be contiguous [T>={T},{self.num_envs},...]")
+                setattr(ro, name, v.data_ptr())
+        _capi.check(self.lib, self.lib.s2d_match_rollout(self._h, T, ptr, C.byref(ro), self._stream()), 's2d_match_rollout')
+        self._keep = (keep, out)
+        return out
+
+    def world_model(self):
+        """dict proto-path -> device tensor (left team's point of view = absolute coordinates)."""
+        P = M.MATCH_PLAYERS
+        wm = {'world_model.cycle': self.cycle, 'world_model.game_mode_type': self.mode, 'world_model.game_mode_side': self.mode_side,
+              'world_model.left_team_score': self.score_left, 'world_model.right_team_score': self.score_right,
+              'world_model.last_kick_side': self.last_touch_side,
+              'world_model.ball.position.x': self.x[:, M.MATCH_BALL], 'world_model.ball.position.y': self.y[:, M.MATCH_BALL],
+              'world_model.ball.velocity.x': self.vx[:, M.MATCH_BALL], 'world_model.ball.velocity.y': self.vy[:, M.MATCH_BALL]}
+        for team, sl in (('teammates', slice(0, 11)), ('opponents', slice(11, P))):
+            for f, t in (('position.x', self.x), ('position.y', self.y), ('velocity.x', self.vx), ('velocity.y', self.vy),
+                         ('body_direction', self.body), ('stamina', self.stamina), ('is_tackling', self.tackle_cycles)):
+                wm[f'world_model.{team}.{f}'] = t[:, sl]
+        return wm

@@ -12,8 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, 'include', 's2d.h')
 
 
-def declared_functions():
-    src = open(HDR).read()
+MATCH_HDR = os.path.join(ROOT, 'include', 's2d_match.h')
+
+
+def declared_functions(path=None):
+    src = open(path or HDR).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(s2d_[a-z_0-9]+)\s*\(', src)))
 
@@ -34,6 +37,34 @@ def test_header_functions_all_exported(lib):
     assert set(names) == bound, (set(names) ^ bound)
     for n in names:
         assert hasattr(lib, n), n
+
+
+def test_match_header_functions_all_exported(lib):
+    from soccer2d_amd import _capi_match as M
+    names = [n for n in declared_functions(MATCH_HDR) if n.startswith('s2d_match_')]
+    assert set(names) == {p[0] for p in M.MATCH_PROTOTYPES}
+    M.bind(lib)
+    for n in names:
+        assert hasattr(lib, n), n
+    import ctypes as C
+    import match_oracle as MO
+    cfg = M.S2DMatchConfig()
+    lib.s2d_match_default_config(C.byref(cfg))
+    assert bytes(memoryview(cfg)) == bytes(memoryview(MO.make_match_config()))
+    assert lib.s2d_match_validate_config(C.byref(cfg)) == 0
+    assert lib.s2d_match_arena_bytes(C.byref(cfg), 8192) >= 8192 * (24 * 10 * 4 + 12 * 4)
+
+
+def test_match_struct_sizes_match_c(tmp_path):
+    from soccer2d_amd import _capi_match as M
+    prog = tmp_path / 'szm.c'
+    prog.write_text('#include <stdio.h>\n#include "s2d_match.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
+                    'sizeof(S2DMatchConfig),sizeof(S2DMatchParams),sizeof(S2DMatchBuffers),sizeof(S2DMatchRollout));return 0;}\n')
+    exe = tmp_path / 'szm'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(prog), '-o', str(exe)], check=True)
+    got = list(map(int, subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()))
+    want = [C.sizeof(x) for x in (M.S2DMatchConfig, M.S2DMatchParams, M.S2DMatchBuffers, M.S2DMatchRollout)]
+    assert got == want
 
 
 def test_struct_sizes_match_c(tmp_path):

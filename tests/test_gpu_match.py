@@ -1,0 +1,109 @@
+"""11v11 match engine on the GPU vs its CPU oracle: bit-exact state after every cycle."""
+import numpy as np
+import pytest
+
+import match_oracle as MO
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def _pair(n, **kw):
+    from soccer2d_amd.match import MatchEngine, make_match_config
+    server = kw.pop('server', None)
+    eng = MatchEngine(n, 'cuda:0', cfg=make_match_config(server_params=server, **kw))
+    okw = dict(kw)
+    orc = MO.MatchOracle(MO.make_match_config(seed=okw.pop('seed', 0x5EED), env_id_offset=okw.pop('env_id_offset', 0),
+                                              auto_reset=int(okw.pop('auto_reset', True)), noise=int(okw.pop('noise', False)),
+                                              server=server, **okw), n)
+    return eng, orc
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+def assert_match_same(eng, orc, tag):
+    torch.cuda.synchronize()
+    for f in MO.OBJ_FIELDS + MO.ENV_FIELDS:
+        g = getattr(eng, f).cpu().numpy()
+        c = orc.get(f)
+        if not np.array_equal(_bits(g), _bits(c)):
+            bad = np.argwhere(_bits(g) != _bits(c))
+            i = tuple(bad[0])
+            raise AssertionError(f'{tag} {f}: {len(bad)} words differ; first at {i}: gpu={g[i]!r} cpu={c[i]!r}')
+
+
+def test_match_default_config_matches_test_table():
+    import ctypes as C
+    from soccer2d_amd import _capi, _capi_match as M
+    lib = M.bind(_capi.load_library())
+    cfg = M.S2DMatchConfig()
+    lib.s2d_match_default_config(C.byref(cfg))
+    assert bytes(memoryview(cfg)) == bytes(memoryview(MO.make_match_config()))
+
+
+@pytest.mark.parametrize('n', [1, 7, 64])
+def test_match_reset_parity(n):
+    eng, orc = _pair(n)
+    assert_match_same(eng, orc, 'reset')
+
+
+@pytest.mark.parametrize('name,kw', [
+    ('default', dict(half_time_cycles=150)),
+    ('noise', dict(half_time_cycles=120, noise=True)),
+    ('no-offside-no-autoreset', dict(half_time_cycles=100, use_offside=0, auto_reset=False)),
+    ('short-drop', dict(half_time_cycles=200, drop_ball_time=3, tackle_cycles=2)),
+])
+def test_match_step_parity_random_policy(name, kw):
+    """In-kernel Philox policy, per-step launches, 330 cycles (kick-offs, restarts, half time,
+    time over + auto-reset all occur): every word equal after every cycle."""
+    n = 37
+    eng, orc = _pair(n, **dict(kw))
+    for t in range(330):
+        eng.step(None); orc.step(None)
+        if t % 10 == 9 or t < 12:
+            assert_match_same(eng, orc, f'{name} t={t}')
+    assert_match_same(eng, orc, name)
+    st = eng.stats.cpu().numpy()
+    assert list(st) == list(orc.stats())
+    assert st[0] == 330 * n and st[4] > 0 and st[5] > 0
+
+
+def test_match_caller_actions_and_rollout():
+    n, T = 50, 120
+    eng, orc = _pair(n, half_time_cycles=90)
+    eng2, _ = _pair(n, half_time_cycles=90)
+    rs = np.random.RandomState(0)
+    acts = np.zeros((T, n, 22, 3), dtype=np.float32)
+    acts[..., 0] = rs.randint(0, 5, (T, n, 22))
+    acts[..., 1] = rs.uniform(-120, 120, (T, n, 22))
+    acts[..., 2] = rs.uniform(-200, 200, (T, n, 22))
+    # crowd the ball so that kicks, tackles and collisions happen
+    for t in range(T):
+        eng.step(torch.as_tensor(acts[t], device='cuda:0')); orc.step(acts[t])
+        if t % 20 == 19:
+            assert_match_same(eng, orc, f'caller t={t}')
+    assert_match_same(eng, orc, 'caller actions')
+    out = eng2.rollout(T, torch.as_tensor(acts, device='cuda:0'))
+    torch.cuda.synchronize()
+    for f in MO.OBJ_FIELDS + MO.ENV_FIELDS:
+        assert torch.equal(getattr(eng, f), getattr(eng2, f)), f
+    obs = out['obs'][-1].cpu().numpy()
+    assert np.array_equal(obs[:, :23, 0], eng.x.cpu().numpy()[:, :23]) and np.array_equal(obs[:, :23, 4], eng.body.cpu().numpy()[:, :23])
+    assert torch.equal(out['mode'][-1], eng.mode) and torch.equal(out['reward'][-1], eng.reward_left)
+
+
+def test_match_full_size_rollout_parity():
+    """BASELINE.json configs[3] size: 8 192 matches, random policy, 64 fused cycles."""
+    n, T = 8192, 64
+    eng, orc = _pair(n)
+    eng.rollout(T, with_obs=False)
+    for _ in range(T):
+        orc.step(None)
+    assert_match_same(eng, orc, 'full-size')
+    assert list(eng.stats.cpu().numpy()) == list(orc.stats())
+    wm = eng.world_model()
+    assert wm['world_model.teammates.position.x'].shape == (n, 11) and wm['world_model.opponents.body_direction'].shape == (n, 11)
+    assert int(wm['world_model.cycle'].min()) == T
