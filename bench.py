@@ -47,6 +47,8 @@ def parse():
     ap.add_argument('--mode', choices=('rollout', 'step', 'graph'), default='rollout')
     ap.add_argument('--fuse', type=int, default=64, help='cycles per launch (rollout) / per graph (graph)')
     ap.add_argument('--noise', action='store_true', help='player_rand/ball_rand Philox noise on')
+    ap.add_argument('--task', choices=('reach_ball', 'match'), default='reach_ball',
+                    help='reach_ball = the BASELINE.json metric (default); match = 11v11 engine, configs[3] (8 192 matches)')
     ap.add_argument('--variant', choices=('dqn', 'no-auto-reset', 'never-done'), default='dqn',
                     help='experiments only: dqn = the benchmark workload; the others switch episode ends off')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -93,6 +95,108 @@ def cpu_baseline(n_envs, sample_steps):
                       f'reference rcssserver+proxy+gRPC chain not measurable (binaries absent offline)'}
 
 
+def match_cpu_baseline(n_envs):
+    """11v11 oracle (oracle/s2d_match_oracle.c, OpenMP over matches) timed on the host cores."""
+    import ctypes as C
+    import match_oracle as MO
+    cores_avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    threads = max(1, min(cores_avail, 16))
+    try:
+        C.CDLL('libgomp.so.1').omp_set_num_threads(threads)
+    except OSError:
+        threads = 1
+    orc = MO.MatchOracle(MO.make_match_config(), n_envs)
+    for _ in range(2):
+        orc.step(None)
+    t0 = time.perf_counter()
+    orc.step(None)
+    per = time.perf_counter() - t0
+    steps = max(4, min(512, int(8.0 / per)))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.step(None)
+    dt = time.perf_counter() - t0
+    return {'value': n_envs * steps / dt, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n_envs} matches x {steps} cycles, {threads} OpenMP threads, {dt:.2f} s; oracle/s2d_match_oracle.c fp32'}
+
+
+def bench_match(args):
+    """BASELINE.json configs[3]: 11v11 full-match engine, 8 192 matches per GPU, random policy."""
+    import torch
+    from soccer2d_amd.match import MatchEngine, make_match_config
+    rank = int(os.environ.get('RANK', '0')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    n = args.envs if args.envs != 65536 else 8192
+    eng = MatchEngine(n, dev, cfg=make_match_config(env_id_offset=rank * n, noise=args.noise))
+    T, K, W = max(1, args.fuse), args.steps, args.warmup
+    ro = eng.alloc_rollout(T) if args.mode == 'rollout' else None
+    stream = torch.cuda.current_stream(dev)
+
+    def run(k):
+        if args.mode == 'rollout':
+            full, rem = divmod(k, T)
+            for _ in range(full):
+                eng.rollout(T, out=ro)
+            if rem:
+                eng.rollout(rem, out=ro)
+            return full + (1 if rem else 0)
+        for _ in range(k):
+            eng.step(None)
+        return k
+    run(W)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    launches = run(K)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    state_b, rec_b = 23 * 10 * 4 + 11 * 4, 24 * 5 * 4 + 4 + 4 + 1
+    per_launch_steps = T if args.mode == 'rollout' else 1
+    alg = n * (2 * state_b + (per_launch_steps * rec_b if args.mode == 'rollout' else 5))
+    launch_s = e0.elapsed_time(e1) * 1e-3 / launches
+    achieved = alg / launch_s / 1e9
+    st = eng.stats.cpu().tolist()
+    if rank == 0:
+        line = {'metric': 'env-steps/sec, 11v11 full-match engine (22 players, kick/tackle/offside/stamina)',
+                'value': world * n * K / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+                'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': f'11v11 match, {n} matches per GPU, random policy (BASELINE.json configs[3])',
+                           'envs_per_gpu': n, 'mode': args.mode, 'cycles_per_launch': per_launch_steps,
+                           'player_steps_per_s': world * n * K * 22 / elapsed},
+                'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 's2d_match_rollout_kernel',
+                             'launch_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg,
+                             'algorithmic_bytes_per_env_step': alg / (n * per_launch_steps)},
+                'events': {'goals_left': st[1], 'goals_right': st[2], 'matches': st[3], 'kicks': st[4], 'tackles': st[5],
+                           'offsides': st[6], 'ball_outs': st[7]}}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = match_cpu_baseline(n)
+            except Exception as ex:
+                line['cpu_baseline'] = {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port', 'sample': f'failed: {ex!r}'}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def load_traffic(mode, fuse, n_envs):
     """HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/traffic_*.json)."""
     best = None
@@ -113,6 +217,8 @@ def load_traffic(mode, fuse, n_envs):
 
 def main():
     args = parse()
+    if args.task == 'match':
+        return bench_match(args)
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -83,7 +83,9 @@ S2D_DEV void store_obs_tile(float* tile, const ObsOut& ob, int lane, bool active
 }
 
 // episode counters: one popcount of a 64-lane ballot per label, one atomic per wave
+S2D_DEV unsigned long long* stats_stripe(unsigned long long* stats) { return stats + (blockIdx.x % S2D_STATS_STRIPES) * 8; }
 S2D_DEV void wave_count_results(int res, bool active, int lane, unsigned long long* stats) {
+  stats = stats_stripe(stats);
 #pragma unroll
   for (int r = S2D_RESULT_GOAL; r <= S2D_RESULT_TIMEOUT; ++r) {
     unsigned long long m = __ballot(active && res == r);
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
   int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
   store_obs_tile(lds[wv], ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, (int)rows * S2D_OBS_DIM);
   wave_count_results(res, active, lane, o.stats);
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&o.stats[0], (unsigned long long)n);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n);
 }
 
 // T fused cycles per launch: the 17 state words stay in registers, only the rollout record
@@ -322,11 +324,11 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
     cnt1 += __shfl_down(cnt1, off); cnt2 += __shfl_down(cnt2, off); cnt3 += __shfl_down(cnt3, off);
   }
   if (lane == 0) {
-    if (cnt1) atomicAdd(&o.stats[1], (unsigned long long)cnt1);
-    if (cnt2) atomicAdd(&o.stats[2], (unsigned long long)cnt2);
-    if (cnt3) atomicAdd(&o.stats[3], (unsigned long long)cnt3);
+    if (cnt1) atomicAdd(&stats_stripe(o.stats)[1], (unsigned long long)cnt1);
+    if (cnt2) atomicAdd(&stats_stripe(o.stats)[2], (unsigned long long)cnt2);
+    if (cnt3) atomicAdd(&stats_stripe(o.stats)[3], (unsigned long long)cnt3);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&o.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n * (unsigned long long)n_steps);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
       const int b = t & 1;
       if (p.auto_reset && __popcll(__ballot(active && !have_prep)) >= kRefillMin) {   // batched refill
 #if S2D_HACK == 5
-        if (lane == 0) atomicAdd(&o.stats[4], 1ull);
+        if (lane == 0) atomicAdd(&stats_stripe(o.stats)[4], 1ull);
 #endif
         if (active && !have_prep) { prep_fill(p, rp, prep[g], lane, e, gl, gh); have_prep = true; }
       }
@@ -415,8 +417,8 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
         snap[g][b][WS_DIST][lane] = dist; snap[g][b][WS_FLAGS][lane] = __int_as_float(flags);
         if (flags && p.auto_reset) {                       // rare
 #if S2D_HACK == 5
-          if (!have_prep) atomicAdd(&o.stats[5], 1ull);
-          atomicAdd(&o.stats[6], 1ull);
+          if (!have_prep) atomicAdd(&stats_stripe(o.stats)[5], 1ull);
+          atomicAdd(&stats_stripe(o.stats)[6], 1ull);
 #endif
 #if S2D_HACK != 2
           if (!have_prep) prep_fill(p, rp, prep[g], lane, e, gl, gh);
@@ -501,12 +503,12 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
       cnt1 += __shfl_down(cnt1, off); cnt2 += __shfl_down(cnt2, off); cnt3 += __shfl_down(cnt3, off);
     }
     if (lane == 0) {
-      if (cnt1) atomicAdd(&o.stats[1], (unsigned long long)cnt1);
-      if (cnt2) atomicAdd(&o.stats[2], (unsigned long long)cnt2);
-      if (cnt3) atomicAdd(&o.stats[3], (unsigned long long)cnt3);
+      if (cnt1) atomicAdd(&stats_stripe(o.stats)[1], (unsigned long long)cnt1);
+      if (cnt2) atomicAdd(&stats_stripe(o.stats)[2], (unsigned long long)cnt2);
+      if (cnt3) atomicAdd(&stats_stripe(o.stats)[3], (unsigned long long)cnt3);
     }
     if (blockIdx.x == 0 && g == 0 && lane == 0)
-      atomicAdd(&o.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
+      atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n * (unsigned long long)n_steps);
   }
 }
 
@@ -605,7 +607,7 @@ static ArenaLayout layout_for(int64_t n) {
   L.terminal_obs = off; off += align_up(s * S2D_OBS_DIM * 4, 256);
   L.action_dir = off; off += align_up(s * 4, 256);
   L.action_cmd = off; off += align_up(s, 256);
-  L.stats = off; off += 256;
+  L.stats = off; off += (size_t)S2D_STATS_STRIPES * 8 * sizeof(unsigned long long);
   L.rare = off; off += align_up(sizeof(S2DRare), 256);
   L.total = off;
   return L;
@@ -930,7 +932,7 @@ S2D_API int s2d_world_model(S2DHandle h, const S2DWorldModel* out, void* stream)
 S2D_API int s2d_stats_reset(S2DHandle h, void* stream) {
   if (!h) return fail(S2D_EINVAL, "NULL handle");
   DeviceGuard guard(h->device);
-  HIP_TRY(hipMemsetAsync(h->buf.stats, 0, 8 * sizeof(unsigned long long), static_cast<hipStream_t>(stream)));
+  HIP_TRY(hipMemsetAsync(h->buf.stats, 0, (size_t)S2D_STATS_STRIPES * 8 * sizeof(unsigned long long), static_cast<hipStream_t>(stream)));
   return S2D_OK;
 }
 

@@ -206,8 +206,13 @@ struct MCounts { unsigned int goals_l, goals_r, finished, kicks, tackles, offsid
 
 // One cycle of the match held by this half-wave.  l = lane within the half, half = 0/1.
 // cmd/a/b = this lane's command (players).  All 64 lanes execute every shuffle.
+S2D_DEV void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, uint32_t gl, uint32_t gh, int cmd,
-                         float a, float bb, MCounts& cnt) {
+                         float a, float bb, MCounts& cnt, float2* pos) {
   const bool is_player = l < NP, is_ball = l == BALL;
   const uint32_t cyc = (uint32_t)g.cycle;
   const int mode0 = g.mode, side0 = g.mode_side;
@@ -250,9 +255,12 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
   const bool any_kick = kmask != 0u;
   const int last_kicker = any_kick ? 31 - __clz(kmask) : -1;
   float bax = 0.0f, bay = 0.0f;
-  for (int j = 0; j < NP; ++j) {
-    float kxj = hbcast(kx, j), kyj = hbcast(ky, j);
-    if ((kmask >> j) & 1u) { bax += kxj; bay += kyj; }
+  const bool wave_kick = __ballot(kicked) != 0ull;          // wave-uniform: kicks are rare events
+  if (wave_kick) {
+    for (int j = 0; j < NP; ++j) {
+      float kxj = hbcast(kx, j), kyj = hbcast(ky, j);
+      if ((kmask >> j) & 1u) { bax += kxj; bay += kyj; }
+    }
   }
   if (any_kick) g.last_touch = side_of(last_kicker);
   const bool ball_live = !is_setplay(mode0) || any_kick;
@@ -273,8 +281,11 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
   const float ri = is_ball ? p.ball_size : p.player_size;
   for (int pass = 0; pass < 10; ++pass) {
     float sx = 0.0f, sy = 0.0f; int c = 0; int tp = -1;
+    pos[l] = make_float2(o.x, o.y);                       // wave-private tile: LDS ops of a wave are in order
+    wave_fence();
     for (int j = 0; j <= BALL; ++j) {
-      float xj = hbcast(o.x, j), yj = hbcast(o.y, j);
+      const float2 pj = pos[j];                           // same address for the whole half: broadcast read
+      float xj = pj.x, yj = pj.y;
       float rj = j == BALL ? p.ball_size : p.player_size;
       float dx = o.x - xj, dy = o.y - yj;
       float d2 = sq2(dx, dy), r = ri + rj;
@@ -286,6 +297,7 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
         tp = j;
       }
     }
+    wave_fence();
     if (__ballot(c > 0) == 0ull) break;
     if (c > 0) { o.x = sx / (float)c; o.y = sy / (float)c; collided = true; if (is_ball) touch_player = tp; }
   }
@@ -315,7 +327,7 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
   float first = -1.0e9f, second = -1.0e9f;      // two largest dirS*x0 among the kicker's opponents
   const int S = any_kick ? side_of(last_kicker) : SIDE_LEFT;
   const float dirS = S == SIDE_LEFT ? 1.0f : -1.0f;
-  {
+  if (wave_kick) {
     const int o0 = S == SIDE_LEFT ? 11 : 0;
     for (int j = 0; j < 11; ++j) {
       float v = dirS * hbcast(x0, o0 + j);
@@ -483,16 +495,22 @@ S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGam
     q.reward[e] = g.reward; q.done[e] = (uint8_t)g.done;
   }
 }
-S2D_DEV void m_flush_counts(const MCounts& c, bool valid, unsigned long long* stats) {
-  // per-lane counters -> wave sums by shuffle tree -> one atomic per wave and counter
-  unsigned int v[7] = {c.goals_l, c.goals_r, c.finished, c.kicks, c.tackles, c.offsides, c.outs};
-#pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    unsigned int s = valid ? v[k] : 0u;
+// per-lane counters -> wave sums (shuffle tree) -> workgroup sums (LDS) -> ONE striped atomic per
+// workgroup and counter (thousands of waves adding to one address cost ~12 ns each, serially)
+S2D_DEV void m_flush_counts(const MCounts& c, bool valid, unsigned long long* stats, unsigned int* lds_cnt) {
+  if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  auto flush = [&](unsigned int v, int k) {
+    unsigned int s = valid ? v : 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[1 + k], (unsigned long long)s);
-  }
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&lds_cnt[k], s);
+  };
+  flush(c.goals_l, 1); flush(c.goals_r, 2); flush(c.finished, 3); flush(c.kicks, 4);
+  flush(c.tackles, 5); flush(c.offsides, 6); flush(c.outs, 7);
+  __syncthreads();
+  if (threadIdx.x >= 1 && threadIdx.x < 8 && lds_cnt[threadIdx.x])
+    atomicAdd(&stats[(blockIdx.x % S2D_STATS_STRIPES) * 8 + threadIdx.x], (unsigned long long)lds_cnt[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(kMBlock) void s2d_match_reset_kernel(MParams p, MPtrs q, int64_t n, const uint8_t* __restrict__ mask) {
@@ -510,6 +528,8 @@ struct MRoll { float* obs; float* reward; int32_t* mode; uint8_t* done; };
 // n_steps cycles; actions = [T][N][22][3] or NULL (random policy).  n_steps = 1 with ro = {} is the per-step API.
 __global__ __launch_bounds__(kMBlock) void s2d_match_rollout_kernel(MParams p, MPtrs q, int64_t n, int n_steps,
                                                                      const float* __restrict__ actions, MRoll ro) {
+  __shared__ float2 pos_tile[kEnvsPerBlock][kHalf];
+  __shared__ unsigned int lds_cnt[8];
   const int l = threadIdx.x & (kHalf - 1);
   const int half = (threadIdx.x >> 5) & 1;
   const int64_t e = (int64_t)blockIdx.x * kEnvsPerBlock + threadIdx.x / kHalf;
@@ -530,7 +550,7 @@ __global__ __launch_bounds__(kMBlock) void s2d_match_rollout_kernel(MParams p, M
         m_random_action(p, gl, gh, (uint32_t)g.cycle, l, cmd, a, b);
       }
     }
-    match_cycle(p, o, g, l, half, gl, gh, cmd, a, b, cnt);
+    match_cycle(p, o, g, l, half, gl, gh, cmd, a, b, cnt, pos_tile[threadIdx.x / kHalf]);
     if (valid) {
       const int64_t row = (int64_t)t * n + e;
       if (ro.obs && l < SLOTS) {
@@ -545,7 +565,7 @@ __global__ __launch_bounds__(kMBlock) void s2d_match_rollout_kernel(MParams p, M
     }
   }
   if (valid) m_store(q, e, l, o, g);
-  m_flush_counts(cnt, valid, q.stats);
+  m_flush_counts(cnt, valid, q.stats, lds_cnt);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&q.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
 }
 
@@ -576,7 +596,7 @@ static MLayout m_layout(int64_t n) {
   L.env = off; off += m_align((size_t)ME_ENV_PLANES * (size_t)L.stride * 4, 256);
   L.reward = off; off += m_align((size_t)L.stride * 4, 256);
   L.done = off; off += m_align((size_t)L.stride, 256);
-  L.stats = off; off += 256;
+  L.stats = off; off += (size_t)S2D_STATS_STRIPES * 8 * sizeof(unsigned long long);
   L.total = off;
   return L;
 }

@@ -88,8 +88,9 @@ class Engine:
         self.buffers = {}
         for k, (name, _ct, dt, trail) in enumerate(BUFFER_FIELDS):
             o = off[k + 1]
-            if trail is None:          # stats: 8 counters
-                count, shape = 8, (8,)
+            if trail is None:          # stats: [S2D_STATS_STRIPES][8] striped counters
+                count, shape = 64 * 8, (64, 8)
+                name = 'stats_striped'
             else:
                 count = n
                 for d in trail:
@@ -201,6 +202,11 @@ class Engine:
             setattr(wm, k, v.data_ptr())
         _capi.check(self.lib, self.lib.s2d_world_model(self._h, C.byref(wm), self._stream()), 's2d_world_model')
         return self._wm
+
+    @property
+    def stats(self):
+        """int64[8]: env-steps, Goal, Out, Timeout, ... (sum over the device-side stripes)."""
+        return self.stats_striped.sum(dim=0)
 
     def stats_reset(self):
         _capi.check(self.lib, self.lib.s2d_stats_reset(self._h, self._stream()), 's2d_stats_reset')

@@ -61,14 +61,20 @@ class MatchEngine:
         n = self.num_envs
         for k, (name, _ct, dt, trail) in enumerate(M.MATCH_BUFFER_FIELDS):
             o = off[k + 1]
-            shape = (8,) if trail is None else (n,) + tuple(trail)
+            shape = (64, 8) if trail is None else (n,) + tuple(trail)
             count = 1
             for d in shape:
                 count *= d
-            setattr(self, name, self.arena[o:o + count * _ITEM[dt]].view(_TD[dt]).view(shape))
+            setattr(self, 'stats_striped' if trail is None else name,
+                    self.arena[o:o + count * _ITEM[dt]].view(_TD[dt]).view(shape))
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def stats(self):
+        """int64[8]: env-steps, goals left/right, matches, kicks, tackles, offsides, ball-outs."""
+        return self.stats_striped.sum(dim=0)
 
     def close(self):
         if getattr(self, '_h', None):

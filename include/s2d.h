@@ -119,6 +119,7 @@ typedef struct S2DConfig {
  * consumers expect.  Valid for the life of the handle; contents change at every
  * s2d_step / s2d_reset / s2d_rollout.                                                     */
 #define S2D_OBS_DIM 10
+#define S2D_STATS_STRIPES 64
 typedef struct S2DBuffers {
   int64_t n_envs;
   /* state, row S of SURVEY.md 8(a): 15 float + 2 int32 words per env */
@@ -136,7 +137,9 @@ typedef struct S2DBuffers {
   float *terminal_obs;   /* [N][10] observation of the finished episode (valid where done) */
   float *action_dir;     /* [N] decoded relative direction in degrees of the last command  */
   uint8_t *action_cmd;   /* [N] S2D_CMD_* of the last command                              */
-  /* episode statistics: [0]=env-steps, [1]=Goal, [2]=Out, [3]=Timeout, [4..7] reserved     */
+  /* episode statistics, striped to keep device atomics off one address:
+   * stats[S2D_STATS_STRIPES][8]; the value of counter k is the sum over stripes of [s][k].
+   * k: 0 = env-steps, 1 = Goal, 2 = Out, 3 = Timeout, 4..7 reserved                        */
   unsigned long long *stats;
 } S2DBuffers;
 

@@ -69,8 +69,9 @@ typedef struct S2DMatchBuffers {
   float *reward_left;      /* [N] +1 left goal, -1 right goal this cycle */
   uint8_t *done;           /* [N] 1 when the match reached TimeOver this cycle */
   int32_t *nearest_left, *nearest_right;              /* [N] index of the player closest to the ball, per team */
-  unsigned long long *stats;  /* [0] env-steps [1] goals left [2] goals right [3] matches finished
-                                 [4] kicks [5] tackles [6] offsides [7] ball-outs */
+  unsigned long long *stats;  /* [S2D_STATS_STRIPES][8], sum over stripes: [0] env-steps [1] goals left
+                                 [2] goals right [3] matches finished [4] kicks [5] tackles [6] offsides
+                                 [7] ball-outs */
 } S2DMatchBuffers;
 
 typedef struct S2DMatchRollout {
