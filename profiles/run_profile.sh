@@ -16,3 +16,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step -- python
 find $OUT -name "*kernel_stats.csv" | while read f; do echo "== $f"; head -8 "$f"; done > $OUT/kernel_stats_summary.txt
 cat $OUT/bench_*.json
 cat $OUT/kernel_stats_summary.txt
+# 11v11 match engine (BASELINE.json configs[3])
+python bench.py --task match --steps 1024 --warmup 64 > $OUT/bench_match_rollout.json 2> $OUT/bench_match_rollout.err
+python bench.py --task match --steps 512 --warmup 32 --mode step --no-cpu-baseline > $OUT/bench_match_step.json 2> $OUT/bench_match_step.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_match -- python3 bench.py --task match --steps 1024 --warmup 64 --no-cpu-baseline > $OUT/prof_match.log 2>&1
+find $OUT/prof_match -name "*kernel_stats.csv" | while read f; do echo "== $f"; head -5 "$f"; done >> $OUT/kernel_stats_summary.txt
