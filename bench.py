@@ -95,6 +95,37 @@ def cpu_baseline(n_envs, sample_steps):
                       f'reference rcssserver+proxy+gRPC chain not measurable (binaries absent offline)'}
 
 
+def init_distributed(rank, local_rank, world):
+    """One process per GPU (RCCL = backend 'nccl').  S2D_DIST_BACKEND=gloo + S2D_BENCH_SHARE_GPU=1 is a
+    rehearsal mode for a one-GPU box: all ranks use cuda:0 and only the timing max travels over gloo."""
+    import torch
+    backend = os.environ.get('S2D_DIST_BACKEND', 'nccl')
+    share = os.environ.get('S2D_BENCH_SHARE_GPU', '0') == '1'
+    idx = 0 if share else local_rank
+    torch.cuda.set_device(idx)
+    dev = torch.device('cuda', idx)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return dev, dist
+
+
+def max_over_ranks(dist, dev, elapsed):
+    if dist is None:
+        return elapsed
+    import torch
+    on = dev if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([elapsed], dtype=torch.float64, device=on)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def match_cpu_baseline(n_envs):
     """11v11 oracle (oracle/s2d_match_oracle.c, OpenMP over matches) timed on the host cores."""
     import ctypes as C
@@ -126,12 +157,7 @@ def bench_match(args):
     from soccer2d_amd.match import MatchEngine, make_match_config
     rank = int(os.environ.get('RANK', '0')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    dev, dist = init_distributed(rank, local_rank, world)
     n = args.envs if args.envs != 65536 else 8192
     eng = MatchEngine(n, dev, cfg=make_match_config(env_id_offset=rank * n, noise=args.noise))
     T, K, W = max(1, args.fuse), args.steps, args.warmup
@@ -161,11 +187,7 @@ def bench_match(args):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, dev, time.perf_counter() - t0)
     state_b, rec_b = 23 * 10 * 4 + 11 * 4, 24 * 5 * 4 + 4 + 4 + 1
     per_launch_steps = T if args.mode == 'rollout' else 1
     alg = n * (2 * state_b + (per_launch_steps * rec_b if args.mode == 'rollout' else 5))
@@ -228,14 +250,7 @@ def main():
             sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)')
         args.gpus = world
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    dev, dist = init_distributed(rank, local_rank, world)
 
     from soccer2d_amd.engine import Engine, make_config
     n = args.envs
@@ -316,10 +331,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, dev, elapsed)
 
     # dominant-kernel launch duration from HIP events on the launch stream
     if args.mode == 'rollout' and per_launch_events:
