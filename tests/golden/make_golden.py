@@ -303,8 +303,85 @@ def gen_reset():
     return rows
 
 
+# ----------------------------------------------------------------------------- wire format
+def gen_wire():
+    """Bytes produced by the reference's generated protobuf classes (service_pb2) for messages on the
+    path: a player `State`, `PlayerAction`s and the trainer reset actions.  Pins soccer2d_amd/wire.py."""
+    out = {'states': [], 'player_actions': [], 'trainer_actions': []}
+    rs = np.random.RandomState(5)
+    for k in range(6):
+        s = pb2.State()
+        wm = s.world_model
+        vals = dict(our_side=1, cycle=int(rs.randint(1, 6000)), game_mode_type=int(rs.choice([2, 3, 4, 7])),
+                    left_team_score=int(rs.randint(0, 4)), right_team_score=int(rs.randint(0, 4)), stoped_cycle=0)
+        wm.our_side = vals['our_side']; wm.cycle = vals['cycle']; wm.game_mode_type = vals['game_mode_type']
+        wm.left_team_score = vals['left_team_score']; wm.right_team_score = vals['right_team_score']
+        wm.our_team_score = vals['left_team_score']; wm.their_team_score = vals['right_team_score']
+        wm.game_mode_side = 2 if k % 2 else 1
+        f32 = lambda v: float(np.float32(v))
+        me = dict(x=f32(rs.uniform(-50, 50)), y=f32(rs.uniform(-30, 30)), vx=f32(rs.uniform(-1, 1)), vy=f32(rs.uniform(-1, 1)),
+                  side=1, uniform_number=int(rs.randint(1, 12)), body_direction=f32(rs.uniform(-180, 180)),
+                  stamina=f32(rs.uniform(1000, 8000)), effort=f32(rs.uniform(0.6, 1)), recovery=f32(rs.uniform(0.5, 1)),
+                  stamina_capacity=f32(rs.uniform(1e4, 1.3e5)), dist_from_ball=f32(rs.uniform(1, 60)),
+                  angle_from_ball=f32(rs.uniform(-180, 180)))
+        sf = wm.self
+        sf.position.x, sf.position.y, sf.velocity.x, sf.velocity.y = me['x'], me['y'], me['vx'], me['vy']
+        sf.side, sf.uniform_number, sf.body_direction = me['side'], me['uniform_number'], me['body_direction']
+        sf.stamina, sf.effort, sf.recovery, sf.stamina_capacity = me['stamina'], me['effort'], me['recovery'], me['stamina_capacity']
+        sf.dist_from_ball, sf.angle_from_ball = me['dist_from_ball'], me['angle_from_ball']
+        ball = dict(x=f32(rs.uniform(-50, 50)), y=f32(rs.uniform(-30, 30)), vx=f32(rs.uniform(-3, 3)), vy=f32(rs.uniform(-3, 3)),
+                    rel_x=f32(rs.uniform(-9, 9)), rel_y=f32(rs.uniform(-9, 9)), dist_from_self=f32(rs.uniform(1, 60)),
+                    angle_from_self=f32(rs.uniform(-180, 180)))
+        b = wm.ball
+        b.position.x, b.position.y, b.velocity.x, b.velocity.y = ball['x'], ball['y'], ball['vx'], ball['vy']
+        b.relative_position.x, b.relative_position.y = ball['rel_x'], ball['rel_y']
+        b.dist_from_self, b.angle_from_self = ball['dist_from_self'], ball['angle_from_self']
+        mates, opps = [], []
+        for team, lst, side in ((wm.teammates, mates, 1), (wm.opponents, opps, 2)):
+            for u in range(1, 1 + int(rs.randint(1, 4))):
+                d = dict(x=f32(rs.uniform(-50, 50)), y=f32(rs.uniform(-30, 30)), vx=f32(rs.uniform(-1, 1)), vy=f32(rs.uniform(-1, 1)),
+                         side=side, uniform_number=u, body_direction=f32(rs.uniform(-180, 180)), is_tackling=bool(u == 2))
+                p = team.add()
+                p.position.x, p.position.y, p.velocity.x, p.velocity.y = d['x'], d['y'], d['vx'], d['vy']
+                p.side, p.uniform_number, p.body_direction, p.is_tackling = d['side'], d['uniform_number'], d['body_direction'], d['is_tackling']
+                lst.append(d)
+        vals.update(self=me, ball=ball, teammates=mates, opponents=opps, our_team_score=vals['left_team_score'],
+                    their_team_score=vals['right_team_score'], game_mode_side=2 if k % 2 else 1)
+        out['states'].append({'fields': vals, 'hex': s.SerializeToString().hex()})
+    for cmd, a, b in (('dash', 100.0, -22.5), ('dash', 55.5, 180.0), ('turn', 90.0, 0.0), ('turn', -12.25, 0.0),
+                      ('kick', 80.0, 45.0), ('tackle', -30.0, 0.0)):
+        if cmd == 'dash':
+            m = pb2.PlayerAction(dash=pb2.Dash(power=a, relative_direction=b))
+        elif cmd == 'turn':
+            m = pb2.PlayerAction(turn=pb2.Turn(relative_direction=a))
+        elif cmd == 'kick':
+            m = pb2.PlayerAction(kick=pb2.Kick(power=a, relative_direction=b))
+        else:
+            m = pb2.PlayerAction(tackle=pb2.Tackle(power_or_dir=a, foul=False))
+        out['player_actions'].append({'cmd': cmd, 'a': a, 'b': b, 'hex': m.SerializeToString().hex(),
+                                      'list_hex': pb2.PlayerActions(actions=[m], ignore_preprocess=True).SerializeToString().hex()})
+    env = make_env(use_continuous_action=False, change_ball_velocity=True)
+    import sample_environments.reach_ball_env as mod
+    real = mod.random
+    mod.random = _Recorder(4242)
+    try:
+        for a in env.trainer_reset_actions():
+            out['trainer_actions'].append({'kind': a.WhichOneof('action'), 'hex': a.SerializeToString().hex(),
+                                           'fields': {'ball_pos': [a.do_move_ball.position.x, a.do_move_ball.position.y],
+                                                      'ball_vel': [a.do_move_ball.velocity.x, a.do_move_ball.velocity.y],
+                                                      'player_pos': [a.do_move_player.position.x, a.do_move_player.position.y],
+                                                      'body': a.do_move_player.body_direction, 'unum': a.do_move_player.uniform_number,
+                                                      'our_side': a.do_move_player.our_side}})
+    finally:
+        mod.random = real
+    m = pb2.TrainerAction(do_change_mode=pb2.DoChangeMode(game_mode_type=pb2.GameModeType.PlayOn, side=pb2.Side.LEFT))   # soccer_2d_env.py:242
+    out['trainer_actions'].append({'kind': 'do_change_mode', 'hex': m.SerializeToString().hex(), 'fields': {'mode': 2, 'side': 1}})
+    return out
+
+
 def main():
     out = {
+        'wire.json': gen_wire(),
         'action_map.json': gen_action_map(),
         'obs.json': gen_obs(),
         'reward.json': gen_reward(),
