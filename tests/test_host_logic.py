@@ -118,3 +118,52 @@ def test_two_rank_gloo_shards_and_all_gather():
         assert np.array_equal(full[k].view(np.uint8), np.ascontiguousarray(ref[k]).view(np.uint8)), k
     assert raw_shapes['obs'] == (2, T, n_global // 2, 10)
     assert list(stats[:4]) == list(whole.stats()[:4].astype(np.int64))
+
+
+def _league_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'gym-soccer-2d-env_amd'))
+    from soccer2d_amd.league import League, exchange_results
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lg = League(5, seed=3)
+    n_local = 12
+    for rnd in range(3):
+        left, right = lg.pairing(rnd, rank * n_local, n_local)
+        g = torch.Generator().manual_seed(100 * rnd + rank)
+        gl, gr = torch.randint(0, 4, (n_local,), generator=g), torch.randint(0, 4, (n_local,), generator=g)
+        L, R, GL, GR = exchange_results(left, right, gl, gr)
+        lg.update(L, R, GL, GR)
+    q.put((rank, lg.elo.clone(), lg.games.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_league_table_stays_replicated_over_two_ranks():
+    """configs[4] plumbing on CPU: results all-gathered with gloo, identical Elo tables on both ranks,
+    equal to a single process that saw every match."""
+    import torch.multiprocessing as mp
+    from soccer2d_amd.league import League
+    world, port = 2, 29800 + (os.getpid() % 1000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_league_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][2], got[1][2])
+    ref = League(5, seed=3)
+    for rnd in range(3):
+        parts = []
+        for rank in range(world):
+            left, right = ref.pairing(rnd, rank * 12, 12)
+            g = torch.Generator().manual_seed(100 * rnd + rank)
+            parts.append((left, right, torch.randint(0, 4, (12,), generator=g), torch.randint(0, 4, (12,), generator=g)))
+        ref.update(*(torch.cat([p[k] for p in parts]) for k in range(4)))
+    assert torch.allclose(ref.elo, got[0][1]) and int(got[0][2].sum()) == 2 * 3 * 24
+    left, right = ref.pairing(0, 0, 1000)
+    assert bool((left != right).all()) and int(left.min()) == 0 and int(left.max()) == 4
