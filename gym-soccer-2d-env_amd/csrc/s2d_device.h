@@ -40,7 +40,7 @@ struct S2DHot {  // by value (kernarg -> SGPRs): everything the always-taken pat
   float effort_init, effort_dec_thr_value, effort_min, effort_dec, effort_inc_thr_value, effort_inc;
   float dash_power_rate, max_dash_power, min_dash_power, max_dash_angle, min_dash_angle;
   float dash_angle_step, inv_dash_angle_step, side_dash_rate, back_dash_rate;
-  float min_distance_to_ball, act_scale;
+  float min_distance_to_ball, min_dist2_thr, act_scale;
   int max_steps, n_actions, auto_reset;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
   // read only by the TURN4 / NOISE instantiations
@@ -84,6 +84,7 @@ S2D_DEV S2DHot hot_in_vgprs(const S2DHot& p) {
   v.inv_dash_angle_step = to_vgpr(p.inv_dash_angle_step);
   v.side_dash_rate = to_vgpr(p.side_dash_rate); v.back_dash_rate = to_vgpr(p.back_dash_rate);
   v.min_distance_to_ball = to_vgpr(p.min_distance_to_ball); v.act_scale = to_vgpr(p.act_scale);
+  v.min_dist2_thr = to_vgpr(p.min_dist2_thr);
   return v;
 }
 
@@ -258,6 +259,17 @@ S2D_DEV int judge(const S2DHot& p, float px, float py, float bx, float by, int s
   int f = (dist < p.min_distance_to_ball) ? S2D_FLAG_GOAL : 0;                       // :137
   f |= (fabsf(px) > p.half_l || fabsf(py) > p.half_w) ? S2D_FLAG_OUT : 0;            // :142
   f |= (step_number > p.max_steps) ? S2D_FLAG_TIMEOUT : 0;                           // :147 strict >
+  return f;
+}
+// The same decision without the square root: sqrt is correctly rounded and monotone, so
+// sqrtf(d2) < m  <=>  d2 < T  with T = the smallest float whose rounded root reaches m (found on
+// the host).  Lets the simulating wave decide "done" from d2 and leaves the root to the
+// observing wave, which needs the distance for the reward anyway.
+S2D_DEV int judge_sq(const S2DHot& p, float px, float py, float bx, float by, int step_number) {
+  float d2 = sq2(bx - px, by - py);
+  int f = (d2 < p.min_dist2_thr) ? S2D_FLAG_GOAL : 0;
+  f |= (fabsf(px) > p.half_l || fabsf(py) > p.half_w) ? S2D_FLAG_OUT : 0;
+  f |= (step_number > p.max_steps) ? S2D_FLAG_TIMEOUT : 0;
   return f;
 }
 // state_to_observation, reach_ball_env.py:87-111; returns the body->ball angle difference

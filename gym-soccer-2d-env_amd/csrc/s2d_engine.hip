@@ -408,13 +408,16 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
         if (MODE == S2D_MODE_TURN4) u = rnd_u01(s2d_draw(p, gl, gh, (uint32_t)e.cycle, S2D_ST_SELECT, 0).x);
         float power;
         action_map<MODE>(p, a, u, cmd, power, dir);
+#if S2D_HACK != 7
         sim_cycle<NOISE, true>(p, rp, e, gl, gh, cmd, power, dir);
-        float dist;
-        int flags = judge(p, e.px, e.py, e.bx, e.by, e.step_number, dist);
+#else
+        e.cycle += 1; e.px += dir * 1e-3f;
+#endif
+        int flags = judge_sq(p, e.px, e.py, e.bx, e.by, e.step_number);
         snap[g][b][WS_PX][lane] = e.px; snap[g][b][WS_PY][lane] = e.py; snap[g][b][WS_BODY][lane] = e.body;
         snap[g][b][WS_BX][lane] = e.bx; snap[g][b][WS_BY][lane] = e.by;
         snap[g][b][WS_BVX][lane] = e.bvx; snap[g][b][WS_BVY][lane] = e.bvy;
-        snap[g][b][WS_DIST][lane] = dist; snap[g][b][WS_FLAGS][lane] = __int_as_float(flags);
+        snap[g][b][WS_FLAGS][lane] = __int_as_float(flags);
         if (flags && p.auto_reset) {                       // rare
 #if S2D_HACK == 5
           if (!have_prep) atomicAdd(&stats_stripe(o.stats)[5], 1ull);
@@ -460,11 +463,15 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
       const int b = t & 1;
       __syncthreads();                                     // wait for snapshot t
       res = 0;
+#if S2D_HACK == 6
+      if (false) {
+#else
       if (active) {
+#endif
         float px = snap[g][b][WS_PX][lane], py = snap[g][b][WS_PY][lane], body = snap[g][b][WS_BODY][lane];
         float bx = snap[g][b][WS_BX][lane], by = snap[g][b][WS_BY][lane];
         float bvx = snap[g][b][WS_BVX][lane], bvy = snap[g][b][WS_BVY][lane];
-        float dist = snap[g][b][WS_DIST][lane];
+        float dist = hypot2(bx - px, by - py);
         int flags = __float_as_int(snap[g][b][WS_FLAGS][lane]);
         float rel = observe(p, px, py, body, bx, by, bvx, bvy, ob);
         reward = reward_of(prev_dist, prev_angle, dist, rel, flags, res);
@@ -490,7 +497,9 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
         if (ro.result) ro.result[row + i] = (uint8_t)res;
         cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
       }
+#if S2D_HACK != 6
       if (ro.obs && rows > 0) store_obs_tile(tile[g], ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
+#endif
     }
     if (active) {
       S[F_PREV_DIST * stride + i] = prev_dist; S[F_PREV_ANGLE * stride + i] = prev_angle;
@@ -692,6 +701,15 @@ static void dev_params_from_config(const S2DConfig& c, S2DHot& h, S2DRare& r) {
   h.inv_dash_angle_step = s.dash_angle_step > 0 ? (float)(1.0 / s.dash_angle_step) : 0.0f;
   h.side_dash_rate = (float)s.side_dash_rate; h.back_dash_rate = (float)s.back_dash_rate;
   h.min_distance_to_ball = (float)t.min_distance_to_ball;
+  {  // smallest float T with sqrtf(T) >= min_distance (correctly rounded sqrt is monotone)
+    const float m = h.min_distance_to_ball;
+    float T = m > 0.0f ? m * m : 0.0f;
+    if (m > 0.0f) {
+      while (T > 0.0f && std::sqrt(std::nextafter(T, 0.0f)) >= m) T = std::nextafter(T, 0.0f);
+      while (std::sqrt(T) < m) T = std::nextafter(T, INFINITY);
+    }
+    h.min_dist2_thr = T;
+  }
   h.act_scale = (float)(360.0 / (double)(t.action_space_size > 0 ? t.action_space_size : 1));
   h.max_steps = t.max_steps; h.n_actions = t.action_space_size; h.auto_reset = c.auto_reset;
   h.seed_lo = (uint32_t)c.seed; h.seed_hi = (uint32_t)(c.seed >> 32);
