@@ -55,15 +55,29 @@ def test_match_header_functions_all_exported(lib):
     assert lib.s2d_match_arena_bytes(C.byref(cfg), 8192) >= 8192 * (24 * 10 * 4 + 12 * 4)
 
 
+def test_gtc_header_functions_all_exported(lib):
+    from soccer2d_amd import gtc
+    names = [n for n in declared_functions(os.path.join(ROOT, 'include', 's2d_gtc.h')) if n.startswith('s2d_gtc_')]
+    assert set(names) == {p[0] for p in gtc.GTC_PROTOTYPES}
+    gtc.bind(lib)
+    for n in names:
+        assert hasattr(lib, n), n
+    cfg = gtc.S2DGtcConfig()
+    lib.s2d_gtc_default_config(C.byref(cfg))
+    assert (cfg.x_min, cfg.x_max, cfg.y_min, cfg.y_max, cfg.max_steps, cfg.min_distance_to_center) == (-52.5, 52.5, -34.0, 34.0, 200, 5.0)
+    assert lib.s2d_gtc_arena_bytes(C.byref(cfg), 1000) > 1000 * 7 * 4
+
+
 def test_match_struct_sizes_match_c(tmp_path):
     from soccer2d_amd import _capi_match as M
     prog = tmp_path / 'szm.c'
-    prog.write_text('#include <stdio.h>\n#include "s2d_match.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
-                    'sizeof(S2DMatchConfig),sizeof(S2DMatchParams),sizeof(S2DMatchBuffers),sizeof(S2DMatchRollout));return 0;}\n')
+    prog.write_text('#include <stdio.h>\n#include "s2d_match.h"\n#include "s2d_gtc.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+                    'sizeof(S2DMatchConfig),sizeof(S2DMatchParams),sizeof(S2DMatchBuffers),sizeof(S2DMatchRollout),sizeof(S2DGtcConfig));return 0;}\n')
     exe = tmp_path / 'szm'
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(prog), '-o', str(exe)], check=True)
     got = list(map(int, subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()))
-    want = [C.sizeof(x) for x in (M.S2DMatchConfig, M.S2DMatchParams, M.S2DMatchBuffers, M.S2DMatchRollout)]
+    from soccer2d_amd.gtc import S2DGtcConfig
+    want = [C.sizeof(x) for x in (M.S2DMatchConfig, M.S2DMatchParams, M.S2DMatchBuffers, M.S2DMatchRollout, S2DGtcConfig)]
     assert got == want
 
 
