@@ -149,3 +149,45 @@ class MatchEngine:
                          ('body_direction', self.body), ('stamina', self.stamina), ('is_tackling', self.tackle_cycles)):
                 wm[f'world_model.{team}.{f}'] = t[:, sl]
         return wm
+
+
+class Soccer2DMatchVecEnv:
+    """gym-style surface over MatchEngine for BASELINE.json configs[3] ("11v11 full-match env"):
+    ``reset() -> obs``, ``step(actions) -> (obs, reward, done, info)`` with device tensors.
+
+    obs     float32 [N, 23, 5]  (x, y, vx, vy, body) of the 22 players and the ball (row 22), absolute
+            coordinates (left team attacks +x); a zero-copy view of the engine's last rollout row.
+    actions float32 [N, 22, 3]  (command, a, b) per player, commands of include/s2d_match.h.
+    reward  float32 [N]         +1 when the left team scores, -1 when the right team scores
+            (zero-sum: the right team's reward is the negative).
+    done    uint8 [N]           1 when a match reached TimeOver (auto-restart follows the VecEnv convention).
+    info    dict of tensors     game_mode_type, game_mode_side, scores, cycle, nearest player per team.
+    """
+
+    def __init__(self, num_envs, device='cuda:0', **kwargs):
+        import numpy as np
+        from .spaces import Box
+        self.engine = MatchEngine(num_envs, device, **kwargs)
+        self.num_envs, self.device = self.engine.num_envs, self.engine.device
+        self.observation_space = Box(low=-200.0, high=200.0, shape=(23, 5), dtype=np.float32)
+        self.action_space = Box(low=-180.0, high=180.0, shape=(22, 3), dtype=np.float32)
+        self._ro = self.engine.alloc_rollout(1)
+
+    def _obs(self):
+        e = self.engine
+        return torch.stack([e.x[:, :23], e.y[:, :23], e.vx[:, :23], e.vy[:, :23], e.body[:, :23]], dim=2)
+
+    def reset(self, mask=None):
+        self.engine.reset(mask)
+        return self._obs()
+
+    def step(self, actions=None):
+        a = None if actions is None else torch.as_tensor(actions, device=self.device).to(torch.float32).reshape(1, self.num_envs, 22, 3)
+        self.engine.rollout(1, actions=a, out=self._ro)
+        e = self.engine
+        info = {'game_mode_type': e.mode, 'game_mode_side': e.mode_side, 'left_team_score': e.score_left,
+                'right_team_score': e.score_right, 'cycle': e.cycle, 'nearest_left': e.nearest_left, 'nearest_right': e.nearest_right}
+        return self._ro['obs'][0, :, :23], e.reward_left, e.done, info
+
+    def close(self):
+        self.engine.close()

@@ -127,3 +127,24 @@ def test_scripted_policy_beats_idle_and_random_in_league_round():
     assert chaser_goals >= 30 and chaser_goals > 5 * max(1, other_goals), (chaser_goals, other_goals)
     lg.update(left, right, gl, gr)
     assert lg.elo[0] > lg.elo[1] and lg.elo[0] > lg.elo[2]
+
+
+def test_match_vec_env_surface():
+    from soccer2d_amd.match import Soccer2DMatchVecEnv
+    env = Soccer2DMatchVecEnv(32, half_time_cycles=30)
+    orc = MO.MatchOracle(MO.make_match_config(half_time_cycles=30), 32)
+    obs = env.reset()
+    assert obs.shape == (32, 23, 5) and env.action_space.shape == (22, 3) and env.observation_space.shape == (23, 5)
+    rs = np.random.RandomState(4)
+    dones = 0
+    for t in range(70):
+        a = np.zeros((32, 22, 3), dtype=np.float32)
+        a[..., 0] = rs.randint(0, 5, (32, 22)); a[..., 1] = rs.uniform(-100, 100, (32, 22)); a[..., 2] = rs.uniform(-180, 180, (32, 22))
+        obs, rew, done, info = env.step(torch.as_tensor(a, device='cuda:0'))
+        orc.step(a)
+        assert np.array_equal(obs[..., 0].cpu().numpy().view(np.int32), orc.get('x')[:, :23].view(np.int32))
+        assert np.array_equal(obs[..., 4].cpu().numpy().view(np.int32), orc.get('body')[:, :23].view(np.int32))
+        assert np.array_equal(rew.cpu().numpy(), orc.get('reward_left')) and np.array_equal(done.cpu().numpy(), orc.get('done'))
+        assert np.array_equal(info['game_mode_type'].cpu().numpy(), orc.get('mode'))
+        dones += int(done.sum())
+    assert dones == 32
