@@ -426,16 +426,21 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
   } else if (is_ball) {
     o.vx *= p.ball_decay; o.vy *= p.ball_decay;
   }
-  // ---- 7. nearest player to the ball per team: scan in index order (ties -> lowest index)
+  // ---- 7. nearest player to the ball per team (ties -> lowest index): butterfly min-reduction over
+  // the half-wave on the 64-bit key (bits(d2) << 8 | index); d2 >= 0, so its bit pattern orders like
+  // the value and the key orders like (d2, index) -- the same winner as a scan in index order.
   {
     float bxn = hbcast(o.x, BALL), byn = hbcast(o.y, BALL);
     float d2 = sq2(o.x - bxn, o.y - byn);
-    float best_l = 3.0e38f, best_r = 3.0e38f; int il = 0, ir = 11;
-    for (int j = 0; j < NP; ++j) {
-      float dj = hbcast(d2, j);
-      if (j < 11) { if (dj < best_l) { best_l = dj; il = j; } } else { if (dj < best_r) { best_r = dj; ir = j; } }
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 8) | (unsigned long long)l;
+    unsigned long long kl = (is_player && l < 11) ? key : ~0ull;
+    unsigned long long kr = (is_player && l >= 11) ? key : ~0ull;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+      unsigned long long ol = __shfl_xor(kl, off, kHalf), orr = __shfl_xor(kr, off, kHalf);
+      kl = ol < kl ? ol : kl; kr = orr < kr ? orr : kr;
     }
-    g.nearest_l = il; g.nearest_r = ir;
+    g.nearest_l = (int)(kl & 0xFFull); g.nearest_r = (int)(kr & 0xFFull);
   }
   if (g.done && p.auto_reset) {
     int d = g.done; float rw = g.reward;
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(kMBlock) void s2d_match_reset_kernel(MParams p, MPt
 struct MRoll { float* obs; float* reward; int32_t* mode; uint8_t* done; };
 
 // n_steps cycles; actions = [T][N][22][3] or NULL (random policy).  n_steps = 1 with ro = {} is the per-step API.
-__global__ __launch_bounds__(kMBlock) void s2d_match_rollout_kernel(MParams p, MPtrs q, int64_t n, int n_steps,
+__global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p, MPtrs q, int64_t n, int n_steps,
                                                                      const float* __restrict__ actions, MRoll ro) {
   __shared__ float2 pos_tile[kEnvsPerBlock][kHalf];
   __shared__ unsigned int lds_cnt[8];
