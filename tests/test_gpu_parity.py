@@ -285,3 +285,41 @@ def test_errors_are_loud():
         eng.step(torch.zeros(9, dtype=torch.int64, device='cuda:0'))
     with pytest.raises(ValueError):
         Engine(0, 'cuda:0')
+
+
+def test_edge_inputs_parity():
+    """Edge cases: discrete actions outside [0, n) (floor-mod wrap, reach_ball_env.py:84), huge and tiny
+    continuous actions (not clipped, :81; dash angle clamps to +-180), a single env, reset with an
+    all-zero and an all-one mask, zero-step rollout."""
+    kw = dict(use_continuous_action=False, action_space_size=16, change_ball_velocity=True, max_steps=30)
+    n = 130
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    rs = np.random.RandomState(7)
+    for t in range(40):
+        a = rs.randint(-40, 60, n).astype(np.int32)
+        obs, rew, done, res = eng.step(torch.as_tensor(a, device='cuda:0'))
+        o_obs, o_rew, o_done, o_res = orc.step(a)
+        assert_same(obs, o_obs, f'oob t={t} obs'); assert_same(rew, o_rew, f'oob t={t} reward')
+        assert_same(eng.action_dir, orc.action_dir(), f'oob t={t} dir')
+    assert_state_same(eng, orc, 'out-of-range discrete')
+    kw = dict(use_continuous_action=True, use_turning=False, max_steps=25)
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    for t in range(30):
+        a = (rs.uniform(-1, 1, (n, 1)) * 10.0 ** rs.randint(-8, 9, (n, 1))).astype(np.float32)
+        obs, rew, done, res = eng.step(torch.as_tensor(a, device='cuda:0'))
+        o = orc.step(a)
+        assert_same(obs, o[0], f'huge t={t} obs')
+    assert_state_same(eng, orc, 'huge continuous')
+    one, orc1 = _engine(1, **dict(kw)), _oracle(1, **dict(kw))
+    one.reset(); orc1.reset()
+    one.rollout(70); orc1.rollout(70)
+    assert_state_same(one, orc1, 'single env')
+    before = one.arena.clone()
+    one.reset(torch.zeros(1, dtype=torch.uint8, device='cuda:0'))     # empty mask: nothing changes
+    one.rollout(0)
+    torch.cuda.synchronize()
+    assert torch.equal(before, one.arena)
+    one.reset(torch.ones(1, dtype=torch.uint8, device='cuda:0')); orc1.reset(np.ones(1, dtype=np.uint8))
+    assert_state_same(one, orc1, 'full mask')
