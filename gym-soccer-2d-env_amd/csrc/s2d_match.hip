@@ -1,5 +1,5 @@
 // s2d_match.hip -- 11v11 full-match engine for MI355X (gfx950): kernels + C ABI of
-// include/s2d_match.h.  Rules = rcssserver's, restated (EXT, DESIGN.md section 11); the tests
+// include/s2d_match.h.  Rules = rcssserver's, restated (EXT, DESIGN.md section 10); the tests
 // hold an independent CPU restatement of the same rules which this file matches bit for bit.
 //
 // Mapping: ONE MATCH PER HALF-WAVE.  Lanes 0..21 of a 32-lane half are the players

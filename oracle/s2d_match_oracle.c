@@ -6,7 +6,7 @@
  * published match model (EXT) -- dash / turn / kick / tackle, stamina,
  * movement, player-player and player-ball collisions, goals, ball-out restarts (kick-in,
  * corner, goal kick), a basic offside rule, kick-off, half time, time over -- in the
- * simplified form documented in DESIGN.md section 11.  PARITY UNPINNED against a real
+ * simplified form documented in DESIGN.md section 10.  PARITY UNPINNED against a real
  * rcssserver; pinned by the hand-derived scenarios of tests/test_match_oracle.py.
  *
  * One source of truth for the HIP kernels: gym-soccer-2d-env_amd/csrc/s2d_match.hip must
@@ -94,7 +94,7 @@ static int side_of(int i) { return i < 11 ? SIDE_LEFT : SIDE_RIGHT; }
 static int other_side(int s) { return s == SIDE_LEFT ? SIDE_RIGHT : SIDE_LEFT; }
 static int is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D_GM_TIME_OVER; }
 
-/* kick-off formation of the left team (right team mirrored); DESIGN.md section 11 */
+/* kick-off formation of the left team (right team mirrored); DESIGN.md section 10 */
 static const REAL FORM_X[11] = {R(-50.0), R(-35.0), R(-35.0), R(-35.0), R(-35.0), R(-20.0), R(-20.0), R(-20.0), R(-20.0), R(-10.5), R(-10.5)};
 static const REAL FORM_Y[11] = {R(0.0), R(-20.0), R(-7.0), R(7.0), R(20.0), R(-22.0), R(-8.0), R(8.0), R(22.0), R(-6.0), R(6.0)};
 
