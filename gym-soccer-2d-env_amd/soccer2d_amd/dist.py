@@ -38,6 +38,9 @@ def all_gather_rollout(rollout, group=None, time_major=True):
     One collective per field; fields are small in number and large in bytes, which is the
     shape direct xGMI all-gathers want (7 links x ~153 GB/s per GPU)."""
     import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):      # single process: the local shard is the whole batch
+        # (copies, like the collective: the caller may reuse its rollout buffers)
+        return {k: (v.clone() if time_major else v.clone().unsqueeze(0)) for k, v in rollout.items() if v is not None}
     world = dist.get_world_size(group)
     out = {}
     for name, t in rollout.items():

@@ -185,3 +185,21 @@ def test_device_dqn_learns_to_reach_the_ball():
     got = m.test(tenv, model, 220)
     assert got['Goal'] > base['Goal'] + 0.25, (base, got)
     assert got['mean_return'] > base['mean_return'] + 5.0, (base, got)
+
+
+def test_league_rollout_exchange_single_rank_overlaps_streams():
+    """LeagueRolloutExchange on one GPU (no process group: the gather degenerates to the local
+    shard): rollout k is handed over while rollout k+1 simulates; contents equal a plain rollout."""
+    from soccer2d_amd.dist import LeagueRolloutExchange, make_sharded_vec_env
+    a = make_sharded_vec_env(4096, 0, 1, device='cuda:0', **KW)
+    b = make_sharded_vec_env(4096, 0, 1, device='cuda:0', **KW)
+    a.reset(); b.reset()
+    ex = LeagueRolloutExchange(a, 16)
+    got = [ex.step() for _ in range(3)] + [ex.flush()]
+    assert got[0] is None
+    for g in got[1:]:
+        ref = b.rollout(16)
+        torch.cuda.synchronize()
+        assert g['obs'].shape == (1, 16, 4096, 10)
+        for k in ('obs', 'action', 'reward', 'done', 'result'):
+            assert torch.equal(g[k][0], ref[k]), k
