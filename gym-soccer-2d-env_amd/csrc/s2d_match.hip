@@ -574,6 +574,32 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&q.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
 }
 
+// Relative tables (Player.dist_from_self / angle_from_self of every agent's WorldModel): lane p scans the
+// 23 objects of its match through a broadcast-read LDS tile and writes one row of 23 values.
+__global__ __launch_bounds__(kMBlock) void s2d_match_relative_kernel(MPtrs q, int64_t n, float* __restrict__ dist,
+                                                                      float* __restrict__ angle) {
+  __shared__ float2 pos_tile[kEnvsPerBlock][kHalf];
+  const int l = threadIdx.x & (kHalf - 1);
+  const int64_t e = (int64_t)blockIdx.x * kEnvsPerBlock + threadIdx.x / kHalf;
+  const bool valid = e < n;
+  const int64_t ec = valid ? e : n - 1;
+  float x = 0.0f, y = 0.0f;
+  if (l <= BALL) { x = q.obj[MF_X * q.obj_stride + ec * SLOTS + l]; y = q.obj[MF_Y * q.obj_stride + ec * SLOTS + l]; }
+  float2* pos = pos_tile[threadIdx.x / kHalf];
+  pos[l] = make_float2(x, y);
+  wave_fence();
+  if (valid && l < NP) {
+    float* drow = dist + ((e * NP + l) * (int64_t)(BALL + 1));
+    float* arow = angle + ((e * NP + l) * (int64_t)(BALL + 1));
+    for (int j = 0; j <= BALL; ++j) {
+      const float2 pj = pos[j];
+      float dx = pj.x - x, dy = pj.y - y;
+      drow[j] = j == l ? 0.0f : hypot2(dx, dy);
+      arow[j] = j == l ? 0.0f : atan2_deg(dy, dx);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -789,6 +815,14 @@ static int m_launch(S2DMatchHandle h, int n_steps, const float* actions, const S
   MDeviceGuard guard(h->device);
   hipLaunchKernelGGL(s2d_match_rollout_kernel, dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
                      h->ptrs, h->n, n_steps, actions, ro);
+  MHIP_TRY(hipGetLastError());
+  return S2D_OK;
+}
+S2D_API int s2d_match_relative(S2DMatchHandle h, float* dist_dev, float* angle_dev, void* stream) {
+  if (!h || !dist_dev || !angle_dev) return mfail(S2D_EINVAL, "NULL argument");
+  MDeviceGuard guard(h->device);
+  hipLaunchKernelGGL(s2d_match_relative_kernel, dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->ptrs,
+                     h->n, dist_dev, angle_dev);
   MHIP_TRY(hipGetLastError());
   return S2D_OK;
 }

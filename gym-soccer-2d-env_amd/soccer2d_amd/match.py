@@ -136,6 +136,17 @@ class MatchEngine:
         self._keep = (keep, out)
         return out
 
+    def relative_tables(self):
+        """(dist, angle) float32 [N,22,23]: Player.dist_from_self / angle_from_self (and the ball's, column 22)
+        as seen by each of the 22 agents (idl/service.proto:84-85, 155-156)."""
+        if getattr(self, '_rel', None) is None:
+            shape = (self.num_envs, M.MATCH_PLAYERS, M.MATCH_BALL + 1)
+            self._rel = (torch.empty(shape, dtype=torch.float32, device=self.device),
+                         torch.empty(shape, dtype=torch.float32, device=self.device))
+        d, a = self._rel
+        _capi.check(self.lib, self.lib.s2d_match_relative(self._h, d.data_ptr(), a.data_ptr(), self._stream()), 's2d_match_relative')
+        return d, a
+
     def world_model(self):
         """dict proto-path -> device tensor (left team's point of view = absolute coordinates)."""
         P = M.MATCH_PLAYERS

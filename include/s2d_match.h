@@ -100,6 +100,12 @@ int s2d_match_step(S2DMatchHandle h, const float *actions_dev, void *stream);
 int s2d_match_rollout(S2DMatchHandle h, int n_steps, const float *actions_dev /* [T][N][22][3] or NULL */,
                       const S2DMatchRollout *out, void *stream);
 
+/* Per-agent relative tables of the WorldModel every player receives: for agent p (0..21) and object
+ * j (0..21 players, 22 = ball) dist[N][22][23] = Player.dist_from_self / Ball.dist_from_self and
+ * angle[N][22][23] = Player.angle_from_self / Ball.angle_from_self (absolute direction of j seen from
+ * p, degrees; idl/service.proto:84-85, 155-156).  The diagonal (j = p) is 0. */
+int s2d_match_relative(S2DMatchHandle h, float *dist_dev, float *angle_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

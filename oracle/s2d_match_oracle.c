@@ -546,6 +546,16 @@ API int s2dmo_set_game(S2DMOEngine *h, int64_t e, const int32_t *v8) {
   return 0;
 }
 API const unsigned long long *s2dmo_stats(const S2DMOEngine *h) { return h->st.v; }
+/* Player.dist_from_self / angle_from_self tables (idl/service.proto:84-85, 155-156): out[n][22][23] as float */
+API void s2dmo_relative(const S2DMOEngine *h, float *dist, float *angle) {
+  for (int64_t e = 0; e < h->n; ++e) for (int p = 0; p < NP; ++p) for (int j = 0; j < NOBJ; ++j) {
+    const Match *m = &h->m[e];
+    REAL dx = m->o[j].x - m->o[p].x, dy = m->o[j].y - m->o[p].y;
+    size_t k = ((size_t)e * NP + p) * NOBJ + j;
+    dist[k] = j == p ? 0.0f : (float)hypot2(dx, dy);
+    angle[k] = j == p ? 0.0f : (float)atan2_deg(dy, dx);
+  }
+}
 API void s2dmo_random_actions(const S2DMOEngine *h, float *out) {
   for (int64_t e = 0; e < h->n; ++e)
     random_actions(&h->p, (uint64_t)(h->p.env_id_offset + e), (uint32_t)h->m[e].cycle, out + (size_t)e * NP * 3);

@@ -61,6 +61,7 @@ def lib():
         L.s2dmo_set_game.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]; L.s2dmo_set_game.restype = C.c_int
         L.s2dmo_stats.argtypes = [C.c_void_p]; L.s2dmo_stats.restype = C.POINTER(C.c_ulonglong)
         L.s2dmo_random_actions.argtypes = [C.c_void_p, C.c_void_p]; L.s2dmo_random_actions.restype = None
+        L.s2dmo_relative.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; L.s2dmo_relative.restype = None
         _lib = L
     return _lib
 
@@ -116,6 +117,12 @@ class MatchOracle:
 
     def stats(self):
         return np.ctypeslib.as_array(self.L.s2dmo_stats(self.h), shape=(8,)).astype(np.int64)
+
+    def relative(self):
+        d = np.zeros((self.n, 22, 23), dtype=np.float32)
+        a = np.zeros((self.n, 22, 23), dtype=np.float32)
+        self.L.s2dmo_relative(self.h, d.ctypes.data, a.ctypes.data)
+        return d, a
 
     def set_obj(self, e, slot, **kw):
         cur = [float(self.get(f)[e, slot]) for f in OBJ_FIELDS]

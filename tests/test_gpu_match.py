@@ -148,3 +148,21 @@ def test_match_vec_env_surface():
         assert np.array_equal(info['game_mode_type'].cpu().numpy(), orc.get('mode'))
         dones += int(done.sum())
     assert dones == 32
+
+
+def test_relative_tables_parity_and_nearest_k():
+    """Per-agent dist_from_self / angle_from_self tables == oracle bit for bit; K nearest opponents by topk."""
+    n = 300
+    eng, orc = _pair(n, half_time_cycles=500)
+    for _ in range(40):
+        eng.step(None); orc.step(None)
+    d, a = eng.relative_tables()
+    od, oa = orc.relative()
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.int32), od.view(np.int32))
+    assert np.array_equal(a.cpu().numpy().view(np.int32), oa.view(np.int32))
+    # ball column agrees with the nearest-player reduction of the step kernel
+    assert torch.equal(d[:, :11, 22].argmin(dim=1).int(), eng.nearest_left)
+    assert torch.equal(d[:, 11:, 22].argmin(dim=1).int() + 11, eng.nearest_right)
+    near3 = d[:, :11, 11:22].topk(3, dim=2, largest=False).indices      # 3 nearest opponents of each left player
+    assert near3.shape == (n, 11, 3)
