@@ -83,6 +83,13 @@ S2D_DEV void store_obs_tile(float* tile, const ObsOut& ob, int lane, bool active
 }
 
 // episode counters: one popcount of a 64-lane ballot per label, one atomic per wave
+// S2D_HACK 8 / 9: section timers of the simulate / observe wave (s_memtime), summed into the
+// spare statistics counters 4..7 (profiles/experiments/ws_sections.py).  Timing builds only.
+#if S2D_HACK == 8 || S2D_HACK == 9
+#define S2D_TICK(acc) do { unsigned long long now_ = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); acc += now_ - tk_; tk_ = now_; } while (0)
+#else
+#define S2D_TICK(acc) do { } while (0)
+#endif
 S2D_DEV unsigned long long* stats_stripe(unsigned long long* stats) { return stats + (blockIdx.x % S2D_STATS_STRIPES) * 8; }
 S2D_DEV void wave_count_results(int res, bool active, int lane, unsigned long long* stats) {
   stats = stats_stripe(stats);
@@ -388,6 +395,11 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
     bool have_prep = false;
     if (active && p.auto_reset) { prep_fill(p, rp, prep[g], lane, e, gl, gh); have_prep = true; }   // full wave
     int64_t row = 0;
+#if S2D_HACK == 8
+    unsigned long long tk_ = __builtin_readcyclecounter(), ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0;
+#elif S2D_HACK == 9
+    unsigned long long tk_ = 0, ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0;
+#endif
     for (int t = 0; t < n_steps; ++t, row += n) {
       const int b = t & 1;
       if (p.auto_reset && __popcll(__ballot(active && !have_prep)) >= kRefillMin) {   // batched refill
@@ -403,6 +415,10 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
           else if (MODE == S2D_MODE_CONT1) static_cast<float*>(ro.action)[row + i] = a.a0;
           else static_cast<float4*>(ro.action)[row + i] = make_float4(a.a0, a.a1, a.a2, a.a3);
         }
+#if S2D_HACK == 8
+        asm volatile("" :: "v"(a.a0));
+        S2D_TICK(ta_);                                     // refill check + policy draw
+#endif
         e.step_number += 1;                                // reach_ball_env.py:55
         float u = 0.0f;
         if (MODE == S2D_MODE_TURN4) u = rnd_u01(s2d_draw(p, gl, gh, (uint32_t)e.cycle, S2D_ST_SELECT, 0).x);
@@ -412,6 +428,10 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
         sim_cycle<NOISE, true>(p, rp, e, gl, gh, cmd, power, dir);
 #else
         e.cycle += 1; e.px += dir * 1e-3f;
+#endif
+#if S2D_HACK == 8
+        asm volatile("" :: "v"(e.px), "v"(e.py), "v"(e.bx), "v"(e.by), "v"(e.stamina), "v"(e.effort), "v"(e.vx), "v"(e.vy));
+        S2D_TICK(tb_);                                     // action map + simulator cycle
 #endif
         int flags = judge_sq(p, e.px, e.py, e.bx, e.by, e.step_number);
         snap[g][b][WS_PX][lane] = e.px; snap[g][b][WS_PY][lane] = e.py; snap[g][b][WS_BODY][lane] = e.body;
@@ -433,8 +453,21 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
           post[g][b][WS_BVX][lane] = e.bvx; post[g][b][WS_BVY][lane] = e.bvy;
         }
       }
+#if S2D_HACK == 8
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      S2D_TICK(tc_);                                       // done test + snapshot + reset
+#endif
       __syncthreads();                                     // snapshot t published
+#if S2D_HACK == 8
+      S2D_TICK(td_);                                       // barrier
+#endif
     }
+#if S2D_HACK == 8
+    if (lane == 0) {
+      atomicAdd(&stats_stripe(o.stats)[4], ta_); atomicAdd(&stats_stripe(o.stats)[5], tb_);
+      atomicAdd(&stats_stripe(o.stats)[6], tc_); atomicAdd(&stats_stripe(o.stats)[7], td_);
+    }
+#endif
     if (active) {                                          // prev_dist / prev_angle belong to the O-wave
       S[F_PX * stride + i] = e.px; S[F_PY * stride + i] = e.py;
       S[F_VX * stride + i] = e.vx; S[F_VY * stride + i] = e.vy;
@@ -459,9 +492,15 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
     unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
     int64_t row = 0;
+#if S2D_HACK == 9
+    unsigned long long tk_ = __builtin_readcyclecounter(), ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0;
+#endif
     for (int t = 0; t < n_steps; ++t, row += n) {
       const int b = t & 1;
       __syncthreads();                                     // wait for snapshot t
+#if S2D_HACK == 9
+      S2D_TICK(ta_);                                       // barrier
+#endif
       res = 0;
 #if S2D_HACK == 6
       if (false) {
@@ -477,6 +516,10 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
         reward = reward_of(prev_dist, prev_angle, dist, rel, flags, res);
         prev_dist = dist; prev_angle = rel;
         done = flags ? 1 : 0;
+#if S2D_HACK == 9
+        asm volatile("" :: "v"(reward), "v"(ob.o[0]), "v"(ob.o[6]), "v"(ob.o[7]), "v"(res));
+        S2D_TICK(tb_);                                     // snapshot read + observe + reward
+#endif
 #if S2D_HACK == 1
         if (false) {
 #else
@@ -497,10 +540,23 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
         if (ro.result) ro.result[row + i] = (uint8_t)res;
         cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
       }
+#if S2D_HACK == 9
+      S2D_TICK(tc_);                                       // reset branch + reward/done/result stores
+#endif
 #if S2D_HACK != 6
       if (ro.obs && rows > 0) store_obs_tile(tile[g], ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
 #endif
+#if S2D_HACK == 9
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      S2D_TICK(td_);                                       // observation tile
+#endif
     }
+#if S2D_HACK == 9
+    if (lane == 0) {
+      atomicAdd(&stats_stripe(o.stats)[4], ta_); atomicAdd(&stats_stripe(o.stats)[5], tb_);
+      atomicAdd(&stats_stripe(o.stats)[6], tc_); atomicAdd(&stats_stripe(o.stats)[7], td_);
+    }
+#endif
     if (active) {
       S[F_PREV_DIST * stride + i] = prev_dist; S[F_PREV_ANGLE * stride + i] = prev_angle;
       o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
