@@ -109,6 +109,18 @@ S2D_DEV U4 s2d_draw(const S2DHot& p, uint32_t gid_lo, uint32_t gid_hi, uint32_t 
                     uint32_t block) {
   return philox4x32_10(gid_lo, gid_hi, cycle, (stream << 16) | block, p.seed_lo, p.seed_hi);
 }
+// In-engine policy randomness is keyed by the env's policy_step k (not by its cycle), so the
+// draw of step t does not depend on whether an episode ended before t: a rollout kernel can
+// draw ahead of the simulation, and one Philox call serves four steps (word k & 3 of the block
+// at counter k >> 2).  The 4-D turning policy uses the four words of POLICY block 1 at counter k.
+S2D_DEV U4 policy_quad(const S2DHot& p, uint32_t gid_lo, uint32_t gid_hi, uint32_t k, uint32_t stream) {
+  return s2d_draw(p, gid_lo, gid_hi, k >> 2, stream, 0);
+}
+S2D_DEV uint32_t quad_word(const U4& q, uint32_t k) {
+  uint32_t j = k & 3u;
+  uint32_t lo = (j & 1u) ? q.y : q.x, hi = (j & 1u) ? q.w : q.z;
+  return (j & 2u) ? hi : lo;
+}
 S2D_DEV int rnd_below(uint32_t w, uint32_t span) { return (int)__umulhi(w, span); }
 S2D_DEV float rnd_u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-8f; }
 
@@ -189,7 +201,9 @@ struct Env {
 };
 enum {  // SoA plane order == S2DBuffers state pointers
   F_PX, F_PY, F_VX, F_VY, F_BODY, F_STAMINA, F_EFFORT, F_RECOVERY, F_CAPACITY,
-  F_BX, F_BY, F_BVX, F_BVY, F_PREV_DIST, F_PREV_ANGLE, F_STEP, F_CYCLE, F_COUNT
+  F_BX, F_BY, F_BVX, F_BVY, F_PREV_DIST, F_PREV_ANGLE, F_STEP, F_CYCLE,
+  F_POLICY,   // policy_step: touched only by launches that draw in-engine policy randomness
+  F_COUNT
 };
 
 S2D_DEV void env_load(Env& e, const float* __restrict__ S, int64_t stride, int64_t i) {
@@ -253,9 +267,9 @@ struct ObsOut { float o[S2D_OBS_DIM]; };
 // (wave-specialised rollout kernel).
 enum { S2D_FLAG_GOAL = 1, S2D_FLAG_OUT = 2, S2D_FLAG_TIMEOUT = 4 };
 
-// distance + done conditions, reach_ball_env.py:121, 137, 142, 147
-S2D_DEV int judge(const S2DHot& p, float px, float py, float bx, float by, int step_number, float& dist) {
-  dist = hypot2(bx - px, by - py);                       // :121
+// distance + done conditions, reach_ball_env.py:121, 137, 142, 147 (d2 = |ball - player|^2)
+S2D_DEV int judge(const S2DHot& p, float px, float py, float d2, int step_number, float& dist) {
+  dist = sqrtf(d2);                                      // :121  == hypot2(bx - px, by - py)
   int f = (dist < p.min_distance_to_ball) ? S2D_FLAG_GOAL : 0;                       // :137
   f |= (fabsf(px) > p.half_l || fabsf(py) > p.half_w) ? S2D_FLAG_OUT : 0;            // :142
   f |= (step_number > p.max_steps) ? S2D_FLAG_TIMEOUT : 0;                           // :147 strict >
@@ -265,8 +279,7 @@ S2D_DEV int judge(const S2DHot& p, float px, float py, float bx, float by, int s
 // sqrtf(d2) < m  <=>  d2 < T  with T = the smallest float whose rounded root reaches m (found on
 // the host).  Lets the simulating wave decide "done" from d2 and leaves the root to the
 // observing wave, which needs the distance for the reward anyway.
-S2D_DEV int judge_sq(const S2DHot& p, float px, float py, float bx, float by, int step_number) {
-  float d2 = sq2(bx - px, by - py);
+S2D_DEV int judge_sq(const S2DHot& p, float px, float py, float d2, int step_number) {
   int f = (d2 < p.min_dist2_thr) ? S2D_FLAG_GOAL : 0;
   f |= (fabsf(px) > p.half_l || fabsf(py) > p.half_w) ? S2D_FLAG_OUT : 0;
   f |= (step_number > p.max_steps) ? S2D_FLAG_TIMEOUT : 0;
@@ -306,10 +319,11 @@ S2D_DEV float reward_of(float prev_dist, float prev_angle, float dist, float rel
   return r;
 }
 
-S2D_DEV void observe_and_check(const S2DHot& p, Env& e, ObsOut& ob, int& done, float& reward, int& result) {
+// d2 = |ball - player|^2 of the state in `e` (sim_cycle returns it)
+S2D_DEV void observe_and_check(const S2DHot& p, Env& e, float d2, ObsOut& ob, int& done, float& reward, int& result) {
   float rel = observe(p, e.px, e.py, e.body, e.bx, e.by, e.bvx, e.bvy, ob);
   float dist;
-  int flags = judge(p, e.px, e.py, e.bx, e.by, e.step_number, dist);
+  int flags = judge(p, e.px, e.py, d2, e.step_number, dist);
   reward = reward_of(e.prev_dist, e.prev_angle, dist, rel, flags, result);
   e.prev_dist = dist;                                    // :158
   e.prev_angle = rel;                                    // :159
@@ -317,11 +331,23 @@ S2D_DEV void observe_and_check(const S2DHot& p, Env& e, ObsOut& ob, int& done, f
 }
 
 // ------------------------------------------------------------------ S: rcssserver cycle (EXT)
-S2D_DEV void cmd_dash(const S2DHot& p, Env& e, float power, float dir, float& ax, float& ay) {
+// Dash(power, dir), appendix A.  Split in two so that the part that depends on the command
+// alone (clamps, direction discretisation, direction rate) can be evaluated ahead of the
+// simulation by another wave; the arithmetic and its order are those of the one-piece form.
+struct CmdPrep { float power, dir, dir_rate; };   // TURN: dir = the raw moment, the rest unused
+S2D_DEV CmdPrep dash_prepare(const S2DHot& p, float power, float dir) {
   power = clampf(power, p.min_dash_power, p.max_dash_power);
   dir = clampf(dir, p.min_dash_angle, p.max_dash_angle);
   float disc = p.dash_angle_step * rintf(dir * p.inv_dash_angle_step);
   dir = (p.dash_angle_step > 0.0f) ? disc : dir;
+  float ad = fabsf(dir);
+  float r_back = p.back_dash_rate - ((p.back_dash_rate - p.side_dash_rate) * (1.0f - (ad - 90.0f) * 0.011111111111111112f));
+  float r_fwd = p.side_dash_rate + ((1.0f - p.side_dash_rate) * (1.0f - ad * 0.011111111111111112f));
+  float dir_rate = clampf(ad > 90.0f ? r_back : r_fwd, 0.0f, 1.0f);
+  return CmdPrep{power, dir, dir_rate};
+}
+S2D_DEV void dash_apply(const S2DHot& p, Env& e, const CmdPrep& c, float& ax, float& ay) {
+  float power = c.power;
   bool back = power < 0.0f;
   float need = back ? power * -2.0f : power;
   float avail = e.stamina + p.extra_stamina;
@@ -329,16 +355,16 @@ S2D_DEV void cmd_dash(const S2DHot& p, Env& e, float power, float dir, float& ax
   float st = e.stamina - need;
   e.stamina = st > 0.0f ? st : 0.0f;
   power = back ? need / -2.0f : need;
-  float ad = fabsf(dir);
-  float r_back = p.back_dash_rate - ((p.back_dash_rate - p.side_dash_rate) * (1.0f - (ad - 90.0f) * 0.011111111111111112f));
-  float r_fwd = p.side_dash_rate + ((1.0f - p.side_dash_rate) * (1.0f - ad * 0.011111111111111112f));
-  float dir_rate = clampf(ad > 90.0f ? r_back : r_fwd, 0.0f, 1.0f);
-  float acc = fabsf(e.effort * power * dir_rate * p.dash_power_rate);
-  dir = back ? dir + 180.0f : dir;
+  float acc = fabsf(e.effort * power * c.dir_rate * p.dash_power_rate);
+  float dir = back ? c.dir + 180.0f : c.dir;
   float sn, cs;
   sincos_deg(norm_deg(e.body + dir), sn, cs);
   ax = acc * cs;
   ay = acc * sn;
+}
+S2D_DEV CmdPrep cmd_prepare(const S2DHot& p, int cmd, float power, float dir) {
+  if (cmd == S2D_CMD_DASH) return dash_prepare(p, power, dir);
+  return CmdPrep{power, dir, 0.0f};
 }
 S2D_DEV void cmd_turn(const S2DHot& p, Env& e, float moment, bool noise, float noise_u) {
   moment = clampf(moment, p.min_moment, p.max_moment);
@@ -375,52 +401,89 @@ S2D_DEV void update_stamina(const S2DHot& p, Env& e) {
   c = c > 0.0f ? c : 0.0f;
   e.capacity = capped ? c : e.capacity;
 }
-// one cycle, play_on, referee off (coach mode: soccer_2d_env.py:363-366).
-// HAS_CMD=false is the command-less cycle a reset consumes (soccer_2d_env.py:190).
-template <bool NOISE, bool HAS_CMD>
-S2D_DEV void sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
-                       int cmd, float power, float dir) {
-  U4 nz{0, 0, 0, 0};
-  if (NOISE) nz = s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_NOISE, 0);
-  if (HAS_CMD) {
-    float ax = 0.0f, ay = 0.0f;
-    if (cmd == S2D_CMD_DASH) {
-      cmd_dash(p, e, power, dir, ax, ay);
-      float a2 = sq2(ax, ay);
-      if (a2 > p.player_accel_max2) { float k = rp->player_accel_max / sqrtf(a2); ax *= k; ay *= k; }   // rare
-      e.vx += ax; e.vy += ay;
-    } else if (cmd == S2D_CMD_TURN) {
-      float nu = 0.0f;
-      if (NOISE) nu = rnd_u01(s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_NOISE, 1).x);
-      cmd_turn(p, e, dir, NOISE, nu);
-    }
+// MPObject::_inc for player and ball + Stadium::collisions for the single pair, in rcssserver's
+// order: accel clamp, vel += accel, speed clamp, noise, pos += vel (player, then ball), collision.
+// Returns |ball - player|^2 of the final positions.
+template <bool NOISE>
+S2D_DEV float move_sequential(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, bool accel, float ax, float ay,
+                              const U4& nz) {
+  if (accel) {
+    float a2 = sq2(ax, ay);
+    if (a2 > p.player_accel_max2) { float k = rp->player_accel_max / sqrtf(a2); ax *= k; ay *= k; }
+    e.vx += ax; e.vy += ay;
   }
   float s2 = sq2(e.vx, e.vy);
-  if (s2 > p.player_speed_max2) { float k = rp->player_speed_max / sqrtf(s2); e.vx *= k; e.vy *= k; }     // rare
+  if (s2 > p.player_speed_max2) { float k = rp->player_speed_max / sqrtf(s2); e.vx *= k; e.vy *= k; }
   if (NOISE) add_noise(e.vx, e.vy, p.player_rand, rnd_u01(nz.x), rnd_u01(nz.y));
   e.px += e.vx; e.py += e.vy;
   float b2 = sq2(e.bvx, e.bvy);
-  if (b2 > p.ball_speed_max2) { float k = rp->ball_speed_max / sqrtf(b2); e.bvx *= k; e.bvy *= k; }        // rare
+  if (b2 > p.ball_speed_max2) { float k = rp->ball_speed_max / sqrtf(b2); e.bvx *= k; e.bvy *= k; }
   if (NOISE) add_noise(e.bvx, e.bvy, p.ball_rand, rnd_u01(nz.z), rnd_u01(nz.w));
   e.bx += e.bvx; e.by += e.bvy;
-  {                                                      // Stadium::collisions, single pair
-    float dx = e.bx - e.px, dy = e.by - e.py;
-    float d2 = sq2(dx, dy);
-    if (d2 < p.rsum2) {                                  // rare
-      float d = sqrtf(d2);
-      float ux, uy;
-      if (d > 0.0f) { ux = dx / d; uy = dy / d; } else { ux = 1.0f; uy = 0.0f; }
-      float mx = (e.px + e.bx) * 0.5f, my = (e.py + e.by) * 0.5f;
-      float h = rp->rsum * 0.5f, cv = rp->collision_vel_rate;
-      e.px = mx - ux * h; e.py = my - uy * h;
-      e.bx = mx + ux * h; e.by = my + uy * h;
-      e.vx *= cv; e.vy *= cv; e.bvx *= cv; e.bvy *= cv;
+  float dx = e.bx - e.px, dy = e.by - e.py;
+  float d2 = sq2(dx, dy);
+  if (d2 < p.rsum2) {                          // Stadium::collisions, single pair
+    float d = sqrtf(d2);
+    float ux, uy;
+    if (d > 0.0f) { ux = dx / d; uy = dy / d; } else { ux = 1.0f; uy = 0.0f; }
+    float mx = (e.px + e.bx) * 0.5f, my = (e.py + e.by) * 0.5f;
+    float h = rp->rsum * 0.5f, cv = rp->collision_vel_rate;
+    e.px = mx - ux * h; e.py = my - uy * h;
+    e.bx = mx + ux * h; e.by = my + uy * h;
+    e.vx *= cv; e.vy *= cv; e.bvx *= cv; e.bvy *= cv;
+    d2 = sq2(e.bx - e.px, e.by - e.py);
+  }
+  return d2;
+}
+// one cycle, play_on, referee off (coach mode: soccer_2d_env.py:363-366).
+// HAS_CMD=false is the command-less cycle a reset consumes (soccer_2d_env.py:190).
+// The three clamps and the collision are rare events (with stock parameters a dashing player
+// never exceeds accel/speed max, the ball starts below its speed max, and a collision needs the
+// ball within 0.385 m).  Without noise the common path therefore evaluates all four conditions
+// on the unclamped values -- which are the sequential conditions as long as none fires -- and
+// only a wave with a lane that trips one re-runs those lanes through move_sequential: one
+// branch per cycle instead of four.  Returns |ball - player|^2 after the cycle (judge_sq).
+template <bool NOISE, bool HAS_CMD>
+S2D_DEV float sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
+                        int cmd, const CmdPrep& c) {
+  U4 nz{0, 0, 0, 0};
+  if (NOISE) nz = s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_NOISE, 0);
+  float ax = 0.0f, ay = 0.0f;
+  bool accel = false;
+  if (HAS_CMD) {
+    if (cmd == S2D_CMD_DASH) {
+      dash_apply(p, e, c, ax, ay);
+      accel = true;
+    } else if (cmd == S2D_CMD_TURN) {
+      float nu = 0.0f;
+      if (NOISE) nu = rnd_u01(s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_NOISE, 1).x);
+      cmd_turn(p, e, c.dir, NOISE, nu);
+    }
+  }
+  float d2;
+  if (NOISE) {
+    d2 = move_sequential<true>(p, rp, e, accel, ax, ay, nz);
+  } else {
+    const float vx0 = e.vx, vy0 = e.vy, px0 = e.px, py0 = e.py, bx0 = e.bx, by0 = e.by;
+    const float a2 = sq2(ax, ay);
+    if (accel) { e.vx += ax; e.vy += ay; }
+    const float s2 = sq2(e.vx, e.vy);
+    e.px += e.vx; e.py += e.vy;
+    const float b2 = sq2(e.bvx, e.bvy);
+    e.bx += e.bvx; e.by += e.bvy;
+    d2 = sq2(e.bx - e.px, e.by - e.py);
+    const bool rare = (accel && a2 > p.player_accel_max2) || s2 > p.player_speed_max2 || b2 > p.ball_speed_max2 ||
+                      d2 < p.rsum2;
+    if (rare) {
+      e.vx = vx0; e.vy = vy0; e.px = px0; e.py = py0; e.bx = bx0; e.by = by0;
+      d2 = move_sequential<false>(p, rp, e, accel, ax, ay, nz);
     }
   }
   e.cycle += 1;
   e.vx *= p.player_decay; e.vy *= p.player_decay;
   e.bvx *= p.ball_decay; e.bvy *= p.ball_decay;
   update_stamina(p, e);
+  return d2;
 }
 
 // ------------------------------------------------------------------ A5 + A6 reset
@@ -479,19 +542,19 @@ S2D_DEV ResetSample reset_sample(const S2DHot& p, const S2DRare& r, uint32_t gid
 }
 // trainer (move ball) (move player) (recover), then the command-less cycle (soccer_2d_env.py:186-197)
 template <bool NOISE>
-S2D_DEV void reset_apply(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
-                         const ResetSample& o, float recover_init) {
+S2D_DEV float reset_apply(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
+                          const ResetSample& o, float recover_init) {
   e.step_number = 0;                                     // :172
   e.bx = o.bx; e.by = o.by; e.bvx = o.bvx; e.bvy = o.bvy;
   e.px = o.px; e.py = o.py; e.body = o.body; e.vx = 0.0f; e.vy = 0.0f;
   e.stamina = p.stamina_max; e.recovery = recover_init;
   e.effort = p.effort_init; e.capacity = p.stamina_capacity;
-  sim_cycle<NOISE, false>(p, rp, e, gid_lo, gid_hi, S2D_CMD_NONE, 0.0f, 0.0f);
+  return sim_cycle<NOISE, false>(p, rp, e, gid_lo, gid_hi, S2D_CMD_NONE, CmdPrep{0.0f, 0.0f, 0.0f});
 }
 template <bool NOISE>
-S2D_DEV void env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo,
-                       uint32_t gid_hi) {
+S2D_DEV float env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo,
+                        uint32_t gid_hi) {
   const S2DRare r = *rp;                                 // one bulk scalar load for the whole path
   ResetSample o = reset_sample(p, r, gid_lo, gid_hi, reset_key(e));
-  reset_apply<NOISE>(p, rp, e, gid_lo, gid_hi, o, r.recover_init);
+  return reset_apply<NOISE>(p, rp, e, gid_lo, gid_hi, o, r.recover_init);
 }

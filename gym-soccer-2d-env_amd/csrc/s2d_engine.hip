@@ -1,7 +1,7 @@
 // s2d_engine.hip -- kernels and C ABI (include/s2d.h) of the MI355X-native reach_ball engine.
 //
-// Layout in HBM: one arena; the 17 state words of an env live in 17
-// struct-of-arrays planes of `stride` (= N rounded up to 256) 4-byte words, so a wave's 64
+// Layout in HBM: one arena; the 17 state words of an env (+ its policy_step
+// counter) live in 18 struct-of-arrays planes of `stride` (= N rounded up to 256) 4-byte words, so a wave's 64
 // lanes read/write 256 contiguous bytes per plane.  Observations are emitted row-major
 // [N][10] (what a PyTorch policy consumes): each wave transposes its 64x10 block through a
 // wave-private LDS tile and stores 2560 contiguous bytes with 16-byte-per-lane stores.
@@ -21,17 +21,28 @@
 
 #define S2D_API extern "C" __attribute__((visibility("default")))
 
-#ifndef S2D_HACK
-#define S2D_HACK 0   // timing-only ablation builds (profiles/experiments); 0 in the product
-#endif
 #ifndef S2D_BLOCK
 #define S2D_BLOCK 256
+#endif
+// S2D_PROFILE = 1 / 2 / 3: timing-only builds (profiles/experiments/ws_sections.py) that sum
+// s_memtime section timers of the policy / simulate / observe wave into statistics counters 4..7.
+#ifndef S2D_PROFILE
+#define S2D_PROFILE 0
+#endif
+#if S2D_PROFILE
+#define S2D_TICK_INIT(role_) unsigned long long tk_ = __builtin_readcyclecounter(), tacc_[4] = {0, 0, 0, 0}; const bool tick_on_ = (S2D_PROFILE == (role_))
+#define S2D_TICK(j) do { if (tick_on_) { unsigned long long now_ = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); tacc_[j] += now_ - tk_; tk_ = now_; } } while (0)
+#define S2D_TICK_FLUSH(stats_, lane_) do { if (tick_on_ && (lane_) == 0) { for (int j_ = 0; j_ < 4; ++j_) atomicAdd(&stats_stripe(stats_)[4 + j_], tacc_[j_]); } } while (0)
+#else
+#define S2D_TICK_INIT(role_) do { } while (0)
+#define S2D_TICK(j) do { } while (0)
+#define S2D_TICK_FLUSH(stats_, lane_) do { } while (0)
 #endif
 static constexpr int kBlock = S2D_BLOCK;
 static constexpr int kWave = 64;
 static constexpr int kWavesPerBlock = kBlock / kWave;
 static constexpr int kObsTile = kWave * S2D_OBS_DIM;  // 640 floats per wave
-static constexpr int64_t kWsMaxEnvs = 262144;         // <= 1 wave/SIMD-ish batches use the wave-specialised rollout
+static constexpr int64_t kWsMaxEnvs = 98304;          // up to ~1.5 env groups per SIMD the wave-specialised rollout wins (measured)
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -55,16 +66,17 @@ S2D_DEV void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Transpose this wave's [64][10] observation block through LDS and store it as one
-// contiguous run.  `dst` = address of the wave's first row (wave-uniform); `valid` = number
-// of floats of the run that exist (640, or fewer in the last wave).
-S2D_DEV void store_obs_tile(float* tile, const ObsOut& ob, int lane, bool active, float* __restrict__ dst,
-                            int valid) {
+// Transpose a wave's [64][10] observation block through LDS and store it as one contiguous
+// run.  `dst` = address of the block's first row (wave-uniform); `valid` = number of floats of
+// the run that exist (640, or fewer in the last wave).  The two halves may run in different
+// waves (tile_write by the observing wave, tile_flush by another one after an s_barrier).
+S2D_DEV void tile_write(float* tile, const ObsOut& ob, int lane, bool active) {
   if (active) {
 #pragma unroll
     for (int k = 0; k < S2D_OBS_DIM; ++k) tile[lane * S2D_OBS_DIM + k] = ob.o[k];
   }
-  wave_lds_fence();
+}
+S2D_DEV void tile_flush(const float* tile, int lane, float* __restrict__ dst, int valid) {
   const bool vec = (valid == kObsTile) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
   if (vec) {
     const float4* t4 = reinterpret_cast<const float4*>(tile);
@@ -79,17 +91,16 @@ S2D_DEV void store_obs_tile(float* tile, const ObsOut& ob, int lane, bool active
       if (idx < valid) dst[idx] = tile[idx];
     }
   }
+}
+S2D_DEV void store_obs_tile(float* tile, const ObsOut& ob, int lane, bool active, float* __restrict__ dst,
+                            int valid) {
+  tile_write(tile, ob, lane, active);
+  wave_lds_fence();
+  tile_flush(tile, lane, dst, valid);
   wave_lds_fence();
 }
 
 // episode counters: one popcount of a 64-lane ballot per label, one atomic per wave
-// S2D_HACK 8 / 9: section timers of the simulate / observe wave (s_memtime), summed into the
-// spare statistics counters 4..7 (profiles/experiments/ws_sections.py).  Timing builds only.
-#if S2D_HACK == 8 || S2D_HACK == 9
-#define S2D_TICK(acc) do { unsigned long long now_ = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); acc += now_ - tk_; tk_ = now_; } while (0)
-#else
-#define S2D_TICK(acc) do { } while (0)
-#endif
 S2D_DEV unsigned long long* stats_stripe(unsigned long long* stats) { return stats + (blockIdx.x % S2D_STATS_STRIPES) * 8; }
 S2D_DEV void wave_count_results(int res, bool active, int lane, unsigned long long* stats) {
   stats = stats_stripe(stats);
@@ -100,21 +111,11 @@ S2D_DEV void wave_count_results(int res, bool active, int lane, unsigned long lo
   }
 }
 
-// caller-provided action of env i at rollout step t (layouts of include/s2d.h), or the
-// in-kernel uniform random policy (Philox POLICY stream at (gid, cycle))
+// caller-provided action of env i at rollout step t (layouts of include/s2d.h)
 template <int MODE>
-S2D_DEV Action4 fetch_action(const S2DHot& p, const void* __restrict__ actions, int kind, int64_t idx,
-                             uint32_t gid_lo, uint32_t gid_hi, uint32_t cycle) {
+S2D_DEV Action4 load_action(const void* __restrict__ actions, int kind, int64_t idx) {
   Action4 a{0.0f, 0.0f, 0.0f, 0.0f};
-  if (kind == S2D_ACT_RANDOM) {
-    U4 w = s2d_draw(p, gid_lo, gid_hi, cycle, S2D_ST_POLICY, 0);
-    if (MODE == S2D_MODE_DISCRETE) a.a0 = (float)rnd_below(w.x, (uint32_t)p.n_actions);
-    else if (MODE == S2D_MODE_CONT1) a.a0 = rnd_u01(w.x) * 2.0f - 1.0f;
-    else {
-      a.a0 = rnd_u01(w.x) * 2.0f - 1.0f; a.a1 = rnd_u01(w.y) * 2.0f - 1.0f;
-      a.a2 = rnd_u01(w.z) * 2.0f - 1.0f; a.a3 = rnd_u01(w.w) * 2.0f - 1.0f;
-    }
-  } else if (MODE == S2D_MODE_DISCRETE) {
+  if (MODE == S2D_MODE_DISCRETE) {
     a.a0 = (kind == S2D_ACT_DISCRETE_I64) ? (float)static_cast<const long long*>(actions)[idx]
                                           : (float)static_cast<const int32_t*>(actions)[idx];
   } else if (MODE == S2D_MODE_CONT1) {
@@ -124,6 +125,53 @@ S2D_DEV Action4 fetch_action(const S2DHot& p, const void* __restrict__ actions, 
     a.a0 = v.x; a.a1 = v.y; a.a2 = v.z; a.a3 = v.w;
   }
   return a;
+}
+// in-kernel uniform random policy at policy step k (s2d_device.h: policy_quad).  `quad` caches
+// the POLICY block of counter k >> 2; `refresh` = it has to be drawn now.
+template <int MODE>
+S2D_DEV Action4 random_action(const S2DHot& p, uint32_t gid_lo, uint32_t gid_hi, uint32_t k, U4& quad, bool refresh) {
+  Action4 a{0.0f, 0.0f, 0.0f, 0.0f};
+  if (MODE == S2D_MODE_TURN4) {
+    U4 w = s2d_draw(p, gid_lo, gid_hi, k, S2D_ST_POLICY, 1);
+    a.a0 = rnd_u01(w.x) * 2.0f - 1.0f; a.a1 = rnd_u01(w.y) * 2.0f - 1.0f;
+    a.a2 = rnd_u01(w.z) * 2.0f - 1.0f; a.a3 = rnd_u01(w.w) * 2.0f - 1.0f;
+  } else {
+    if (refresh) quad = policy_quad(p, gid_lo, gid_hi, k, S2D_ST_POLICY);
+    uint32_t w = quad_word(quad, k);
+    if (MODE == S2D_MODE_DISCRETE) a.a0 = (float)rnd_below(w, (uint32_t)p.n_actions);
+    else a.a0 = rnd_u01(w) * 2.0f - 1.0f;
+  }
+  return a;
+}
+// does a launch of this mode / action kind consume the env's policy_step?  (wave-uniform)
+template <int MODE>
+S2D_DEV bool uses_policy_step(int kind) { return kind == S2D_ACT_RANDOM || MODE == S2D_MODE_TURN4; }
+
+template <int MODE>
+S2D_DEV void store_rollout_action(void* __restrict__ dst, int64_t idx, const Action4& a) {
+  if (MODE == S2D_MODE_DISCRETE) static_cast<int32_t*>(dst)[idx] = (int32_t)a.a0;
+  else if (MODE == S2D_MODE_CONT1) static_cast<float*>(dst)[idx] = a.a0;
+  else static_cast<float4*>(dst)[idx] = make_float4(a.a0, a.a1, a.a2, a.a3);
+}
+
+// action of one env for the step at policy step k -> decoded command (A2, reach_ball_env.py:53-85)
+// with the command-only part of the dash already evaluated.  `quad` / `squad` cache the POLICY /
+// SELECT blocks across the four steps they serve.
+template <int MODE>
+S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int kind, int64_t idx, uint32_t gid_lo,
+                       uint32_t gid_hi, uint32_t k, bool refresh, U4& quad, U4& squad, void* __restrict__ action_out,
+                       int& cmd, float& dir) {
+  Action4 a = (kind == S2D_ACT_RANDOM) ? random_action<MODE>(p, gid_lo, gid_hi, k, quad, refresh)
+                                       : load_action<MODE>(actions, kind, idx);
+  if (action_out) store_rollout_action<MODE>(action_out, idx, a);
+  float u = 0.0f;
+  if (MODE == S2D_MODE_TURN4) {                          // reach_ball_env.py:71
+    if (refresh) squad = policy_quad(p, gid_lo, gid_hi, k, S2D_ST_SELECT);
+    u = rnd_u01(quad_word(squad, k));
+  }
+  float power;
+  action_map<MODE>(p, a, u, cmd, power, dir);
+  return cmd_prepare(p, cmd, power, dir);
 }
 
 // Prepared reset samples of one wave (LDS, struct-of-arrays over the 64 lanes).  The sample of
@@ -146,32 +194,28 @@ S2D_DEV ResetSample prep_take(const PrepTile& t, int lane) {
                      t.v[6][lane]};
 }
 
-// A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269) for the env held in registers.
-// Returns the observation to hand back (post auto-reset), reward/done/result of the step.
+// A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269) for the env held in registers, given the
+// decoded command.  Returns the observation to hand back (post auto-reset), reward/done/result.
 // prep == nullptr: the reset sample is drawn on the spot (per-step API).
-template <int MODE, bool NOISE>
+template <bool NOISE>
 S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
-                      const Action4& a, ObsOut& ob, float& reward, int& done, int& result, int& cmd, float& dir,
+                      int cmd, const CmdPrep& c, ObsOut& ob, float& reward, int& done, int& result,
                       float* __restrict__ terminal_row, PrepTile* prep, int lane, bool& have_prep) {
   e.step_number += 1;                                    // reach_ball_env.py:55
-  float u = 0.0f;
-  if (MODE == S2D_MODE_TURN4) u = rnd_u01(s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_SELECT, 0).x);
-  float power;
-  action_map<MODE>(p, a, u, cmd, power, dir);
-  sim_cycle<NOISE, true>(p, rp, e, gid_lo, gid_hi, cmd, power, dir);   // trainer forces PlayOn each cycle (:242)
-  observe_and_check(p, e, ob, done, reward, result);
-  if (done && p.auto_reset) {                            // rare: SB3 VecEnv convention
+  float d2 = sim_cycle<NOISE, true>(p, rp, e, gid_lo, gid_hi, cmd, c);   // trainer forces PlayOn each cycle (:242)
+  observe_and_check(p, e, d2, ob, done, reward, result);
+  if (done && p.auto_reset) {                  // SB3 VecEnv convention
 #pragma unroll
     for (int k = 0; k < S2D_OBS_DIM; ++k) terminal_row[k] = ob.o[k];
     if (prep) {
       if (!have_prep) prep_fill(p, rp, *prep, lane, e, gid_lo, gid_hi);   // episode shorter than the refill cadence
-      reset_apply<NOISE>(p, rp, e, gid_lo, gid_hi, prep_take(*prep, lane), p.recover_init);
+      d2 = reset_apply<NOISE>(p, rp, e, gid_lo, gid_hi, prep_take(*prep, lane), p.recover_init);
       have_prep = false;
     } else {
-      env_reset<NOISE>(p, rp, e, gid_lo, gid_hi);
+      d2 = env_reset<NOISE>(p, rp, e, gid_lo, gid_hi);
     }
-    int d2, r2; float w2;
-    observe_and_check(p, e, ob, d2, w2, r2);             // reach_ball_env.py:166: carry seeded, outputs dropped
+    int dn2, r2; float w2;
+    observe_and_check(p, e, d2, ob, dn2, w2, r2);        // reach_ball_env.py:166: carry seeded, outputs dropped
   }
 }
 
@@ -206,9 +250,9 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_reset_kernel(S2DHot p, const
     env_load(e, S, stride, i);
     if (active) {
       uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
-      env_reset<NOISE>(p, rp, e, (uint32_t)gid, (uint32_t)(gid >> 32));
+      float d2 = env_reset<NOISE>(p, rp, e, (uint32_t)gid, (uint32_t)(gid >> 32));
       int d, r; float w;
-      observe_and_check(p, e, ob, d, w, r);
+      observe_and_check(p, e, d2, ob, d, w, r);
       env_store(e, S, stride, i);
       o.reward[i] = 0.0f; o.done[i] = 0; o.result[i] = 0;
     } else {                                             // keep the row this env already has
@@ -231,6 +275,8 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
   const int64_t wave_first = i - lane;
   if (wave_first >= n) return;                           // wave-uniform
   const bool active = i < n;
+  const bool use_k = uses_policy_step<MODE>(kind);
+  uint32_t* const kplane = reinterpret_cast<uint32_t*>(S + F_POLICY * stride);
   ObsOut ob;
   int res = 0;
   if (active) {
@@ -238,12 +284,16 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
     env_load(e, S, stride, i);
     uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
     uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
-    Action4 a = fetch_action<MODE>(p, actions, kind, i, gl, gh, (uint32_t)e.cycle);
+    uint32_t k = 0;
+    if (use_k) k = kplane[i];
+    U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
     float reward, dir; int done, cmd;
+    CmdPrep c = decide<MODE>(p, actions, kind, i, gl, gh, k, true, quad, squad, nullptr, cmd, dir);
     bool no_prep = false;
-    step_env<MODE, NOISE>(p, rp, e, gl, gh, a, ob, reward, done, res, cmd, dir, o.terminal_obs + i * S2D_OBS_DIM,
-                          nullptr, lane, no_prep);
+    step_env<NOISE>(p, rp, e, gl, gh, cmd, c, ob, reward, done, res, o.terminal_obs + i * S2D_OBS_DIM, nullptr, lane,
+                    no_prep);
     env_store(e, S, stride, i);
+    if (use_k) kplane[i] = k + 1u;
     o.reward[i] = reward;
     o.done[i] = (uint8_t)done;
     o.result[i] = (uint8_t)res;
@@ -277,23 +327,27 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
   const bool active = i < n;
   int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
   const int valid = (int)rows * S2D_OBS_DIM;
+  const bool use_k = uses_policy_step<MODE>(kind);
+  uint32_t* const kplane = reinterpret_cast<uint32_t*>(S + F_POLICY * stride);
   Env e;
-  uint32_t gl = 0, gh = 0;
+  uint32_t gl = 0, gh = 0, k0 = 0;
   if (active) {
     env_load(e, S, stride, i);
+    if (use_k) k0 = kplane[i];
     uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
     gl = (uint32_t)gid; gh = (uint32_t)(gid >> 32);
-    // Consume every loaded word once BEFORE the loop: the s_waitcnt for the 17 prologue loads
+    // Consume every loaded word once BEFORE the loop: the s_waitcnt for the prologue loads
     // is then placed here and not inside the loop body, where (vmcnt being in-order) it would
     // also wait for the previous iteration's stores to be acknowledged.
     asm volatile("" ::"v"(e.px), "v"(e.py), "v"(e.vx), "v"(e.vy), "v"(e.body), "v"(e.stamina), "v"(e.effort),
                  "v"(e.recovery), "v"(e.capacity), "v"(e.bx), "v"(e.by), "v"(e.bvx), "v"(e.bvy), "v"(e.prev_dist),
-                 "v"(e.prev_angle), "v"(e.step_number), "v"(e.cycle));
+                 "v"(e.prev_angle), "v"(e.step_number), "v"(e.cycle), "v"(k0));
   }
   ObsOut ob;
   float reward = 0.0f, dir = 0.0f; int done = 0, res = 0, cmd = 0;
   unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
   float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
+  U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
   bool have_prep = false;
   if (active && p.auto_reset) { prep_fill(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }   // full wave
   int64_t row = 0;
@@ -303,14 +357,10 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
       if (active && !have_prep) { prep_fill(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }
     }
     if (active) {
-      Action4 a = fetch_action<MODE>(p, actions, kind, row + i, gl, gh, (uint32_t)e.cycle);
-      if (ro.action) {
-        if (MODE == S2D_MODE_DISCRETE) static_cast<int32_t*>(ro.action)[row + i] = (int32_t)a.a0;
-        else if (MODE == S2D_MODE_CONT1) static_cast<float*>(ro.action)[row + i] = a.a0;
-        else static_cast<float4*>(ro.action)[row + i] = make_float4(a.a0, a.a1, a.a2, a.a3);
-      }
-      step_env<MODE, NOISE>(p, rp, e, gl, gh, a, ob, reward, done, res, cmd, dir, term_row, &prep[wv], lane,
-                            have_prep);
+      const uint32_t k = k0 + (uint32_t)t;
+      CmdPrep c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, t == 0 || (k & 3u) == 0u, quad, squad,
+                               ro.action, cmd, dir);
+      step_env<NOISE>(p, rp, e, gl, gh, cmd, c, ob, reward, done, res, term_row, &prep[wv], lane, have_prep);
       if (ro.reward) ro.reward[row + i] = reward;
       if (ro.done) ro.done[row + i] = (uint8_t)done;
       if (ro.result) ro.result[row + i] = (uint8_t)res;
@@ -320,6 +370,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
   }
   if (active) {
     env_store(e, S, stride, i);
+    if (use_k) kplane[i] = k0 + (uint32_t)n_steps;
     o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
     o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
   }
@@ -339,48 +390,90 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 }
 
 // ------------------------------------------------------------------------------------------
-// Wave-specialised rollout (producer / consumer through LDS).
+// Wave-specialised rollout: a three-stage software pipeline through LDS.
 //
-// At N = 65 536 the unified kernel leaves ONE wave per SIMD and is bound by its own VALU issue
-// (a lone wave issues one VALU per 4 cycles, a SIMD can take two waves' VALUs in that time).
-// Here every group of 64 envs is served by two waves of one workgroup:
-//   S-wave (simulate): action -> dash/turn -> integrate -> stamina -> done test -> reset
-//   O-wave (observe):  observation, reward, labels, LDS transposition, all rollout stores
-// The S-wave publishes a snapshot of step t in LDS (double-buffered) and goes on with step
-// t+1 while the O-wave processes step t: one s_barrier per cycle, no feedback edge (the
-// S-wave evaluates the done conditions itself, the O-wave owns the reward carry).  The
-// arithmetic is the same functions in the same order, so results stay bit-identical.
-// Used for small batches (resident waves double); at >= 4 waves per SIMD the unified kernel
-// is already issue-bound and is kept.
-enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_DIST, WS_FLAGS, WS_WORDS };
-static constexpr int kWsGroups = kBlock / (2 * kWave);   // env groups (of 64) per workgroup
+// At N = 65 536 the unified kernel leaves ONE wave per SIMD, and a lone wave issues one
+// instruction per ~4 cycles while the SIMD could take twice that (profiles/r01/instr_rate_gfx950.txt).
+// Here every group of 64 envs is a workgroup of three waves, each one stage of the cycle:
+//   P-wave (policy):   action of step t (caller's, or Philox policy) -> decoded command, the
+//                      command-only half of the dash (clamps, direction rate), action record
+//   S-wave (simulate): command -> dash/turn -> integrate -> stamina -> done test -> reset
+//   O-wave (observe):  observation, reward, labels, LDS transposition, rollout stores
+// In iteration s the P-wave works on step s, the S-wave on step s-1, the O-wave on step s-2;
+// the hand-offs are double-buffered in LDS and ONE s_barrier per iteration separates them.  There
+// is no feedback edge: policy draws are keyed by policy_step (not by the cycle, which resets
+// advance), the S-wave evaluates the done conditions itself, the O-wave owns the reward carry.
+// The arithmetic is the same functions in the same order as in the unified kernel, so the
+// results are bit-identical.  Used for small batches; from ~4 waves per SIMD on the unified
+// kernel is issue-bound by itself and is kept.
+enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_FLAGS, WS_WORDS };
+enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_WORDS };
+static constexpr int kWsBlock = 3 * kWave;
 
 template <int MODE, bool NOISE>
-__global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
-                                                                      float* __restrict__ S, int64_t stride,
-                                                                      int64_t n, int n_steps,
-                                                                      const void* __restrict__ actions, int kind,
-                                                                      RolloutOut ro, StepOut o) {
-  __shared__ float snap[kWsGroups][2][WS_WORDS][kWave];            // step-t snapshot, double-buffered
-  __shared__ float post[kWsGroups][2][WS_DIST][kWave];             // post-reset state of finished envs
-  __shared__ __attribute__((aligned(16))) float tile[kWsGroups][kObsTile];
-  __shared__ PrepTile prep[kWsGroups];
-  const S2DHot p = hot_in_vgprs(p_sgpr);
+__global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
+                                                                        float* __restrict__ S, int64_t stride,
+                                                                        int64_t n, int n_steps,
+                                                                        const void* __restrict__ actions, int kind,
+                                                                        RolloutOut ro, StepOut o) {
+  __shared__ float act[2][WA_WORDS][kWave];                // decoded command of step t, double-buffered
+  __shared__ float snap[2][WS_WORDS][kWave];               // post-cycle snapshot of step t, double-buffered
+  __shared__ float post[2][WS_FLAGS][kWave];               // post-reset state of the envs that finished
+  __shared__ __attribute__((aligned(16))) float tile[kObsTile];
+  __shared__ PrepTile prep;
   const int lane = threadIdx.x & (kWave - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const bool sim_role = wv < kWsGroups;
-  const int g = sim_role ? wv : wv - kWsGroups;
-  const int64_t wave_first = ((int64_t)blockIdx.x * kWsGroups + g) * kWave;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 observe
+  const int64_t wave_first = (int64_t)blockIdx.x * kWave;
   const int64_t i = wave_first + lane;
   const bool active = i < n;
-  int64_t rows = n - wave_first; rows = rows > kWave ? kWave : (rows < 0 ? 0 : rows);
+  int64_t rows = n - wave_first; rows = rows > kWave ? kWave : rows;
   const int valid = (int)rows * S2D_OBS_DIM;
+  const int n_iter = n_steps + 2;
 
-  if (sim_role) {
+  if (role == 0) {
+    // ------------------------------------------------------------------ P-wave
+    const S2DHot& p = p_sgpr;
+    const bool use_k = uses_policy_step<MODE>(kind);
+    uint32_t* const kplane = reinterpret_cast<uint32_t*>(S + F_POLICY * stride);
+    uint32_t gl = 0, gh = 0, k0 = 0;
+    if (active) {
+      if (use_k) k0 = kplane[i];
+      uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
+      gl = (uint32_t)gid; gh = (uint32_t)(gid >> 32);
+    }
+    U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
+    float dir = 0.0f; int cmd = 0;
+    int64_t row = 0;
+    S2D_TICK_INIT(1);
+    for (int s = 0; s < n_iter; ++s) {
+      if (s < n_steps && active) {
+        const uint32_t k = k0 + (uint32_t)s;
+        CmdPrep c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, s == 0 || (k & 3u) == 0u, quad, squad,
+                                 ro.action, cmd, dir);
+        const int b = s & 1;
+        if (MODE == S2D_MODE_TURN4) act[b][WA_CMD][lane] = __int_as_float(cmd);
+        act[b][WA_POWER][lane] = c.power;
+        act[b][WA_DIR][lane] = c.dir; act[b][WA_RATE][lane] = c.dir_rate;
+        row += n;
+      }
+#if S2D_PROFILE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      S2D_TICK(0);                                         // policy + command decode
+      __syncthreads();
+      S2D_TICK(3);                                         // barrier
+    }
+    S2D_TICK_FLUSH(o.stats, lane);
+    if (active) {
+      if (use_k) kplane[i] = k0 + (uint32_t)n_steps;
+      o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
+    }
+  } else if (role == 1) {
     // ------------------------------------------------------------------ S-wave
 #ifdef S2D_WS_PRIO
-    __builtin_amdgcn_s_setprio(S2D_WS_PRIO);               // the simulate wave is the critical path
+    __builtin_amdgcn_s_setprio(S2D_WS_PRIO);               // experiment: the simulate wave is the critical path
 #endif
+    const S2DHot p = hot_in_vgprs(p_sgpr);
     Env e;
     uint32_t gl = 0, gh = 0;
     if (active) {
@@ -391,83 +484,52 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
                    "v"(e.recovery), "v"(e.capacity), "v"(e.bx), "v"(e.by), "v"(e.bvx), "v"(e.bvy),
                    "v"(e.step_number), "v"(e.cycle));
     }
-    float dir = 0.0f; int cmd = 0;
     bool have_prep = false;
-    if (active && p.auto_reset) { prep_fill(p, rp, prep[g], lane, e, gl, gh); have_prep = true; }   // full wave
-    int64_t row = 0;
-#if S2D_HACK == 8
-    unsigned long long tk_ = __builtin_readcyclecounter(), ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0;
-#elif S2D_HACK == 9
-    unsigned long long tk_ = 0, ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0;
-#endif
-    for (int t = 0; t < n_steps; ++t, row += n) {
-      const int b = t & 1;
-      if (p.auto_reset && __popcll(__ballot(active && !have_prep)) >= kRefillMin) {   // batched refill
-#if S2D_HACK == 5
-        if (lane == 0) atomicAdd(&stats_stripe(o.stats)[4], 1ull);
-#endif
-        if (active && !have_prep) { prep_fill(p, rp, prep[g], lane, e, gl, gh); have_prep = true; }
-      }
-      if (active) {
-        Action4 a = fetch_action<MODE>(p, actions, kind, row + i, gl, gh, (uint32_t)e.cycle);
-        if (ro.action) {
-          if (MODE == S2D_MODE_DISCRETE) static_cast<int32_t*>(ro.action)[row + i] = (int32_t)a.a0;
-          else if (MODE == S2D_MODE_CONT1) static_cast<float*>(ro.action)[row + i] = a.a0;
-          else static_cast<float4*>(ro.action)[row + i] = make_float4(a.a0, a.a1, a.a2, a.a3);
+    if (active && p.auto_reset) { prep_fill(p, rp, prep, lane, e, gl, gh); have_prep = true; }   // full wave
+    S2D_TICK_INIT(2);
+    for (int s = 0; s < n_iter; ++s) {
+      if (s >= 1 && s <= n_steps) {                        // step s - 1
+        const int b = (s - 1) & 1;
+        if (p.auto_reset && __popcll(__ballot(active && !have_prep)) >= kRefillMin) {   // batched refill
+          if (active && !have_prep) { prep_fill(p, rp, prep, lane, e, gl, gh); have_prep = true; }
         }
-#if S2D_HACK == 8
-        asm volatile("" :: "v"(a.a0));
-        S2D_TICK(ta_);                                     // refill check + policy draw
+        if (active) {
+          // only the turning action space ever decodes to something other than a dash
+          const int cmd = MODE == S2D_MODE_TURN4 ? __float_as_int(act[b][WA_CMD][lane]) : (int)S2D_CMD_DASH;
+          const CmdPrep c{act[b][WA_POWER][lane], act[b][WA_DIR][lane], act[b][WA_RATE][lane]};
+#if S2D_PROFILE
+          asm volatile("" ::"v"(cmd), "v"(c.power), "v"(c.dir), "v"(c.dir_rate));
+          S2D_TICK(0);                                     // refill check + command read
 #endif
-        e.step_number += 1;                                // reach_ball_env.py:55
-        float u = 0.0f;
-        if (MODE == S2D_MODE_TURN4) u = rnd_u01(s2d_draw(p, gl, gh, (uint32_t)e.cycle, S2D_ST_SELECT, 0).x);
-        float power;
-        action_map<MODE>(p, a, u, cmd, power, dir);
-#if S2D_HACK != 7
-        sim_cycle<NOISE, true>(p, rp, e, gl, gh, cmd, power, dir);
-#else
-        e.cycle += 1; e.px += dir * 1e-3f;
+          e.step_number += 1;                              // reach_ball_env.py:55
+          const float d2 = sim_cycle<NOISE, true>(p, rp, e, gl, gh, cmd, c);
+#if S2D_PROFILE
+          asm volatile("" ::"v"(e.px), "v"(e.py), "v"(e.bx), "v"(e.by), "v"(e.stamina), "v"(e.effort), "v"(e.vx), "v"(e.vy));
+          S2D_TICK(1);                                     // simulator cycle
 #endif
-#if S2D_HACK == 8
-        asm volatile("" :: "v"(e.px), "v"(e.py), "v"(e.bx), "v"(e.by), "v"(e.stamina), "v"(e.effort), "v"(e.vx), "v"(e.vy));
-        S2D_TICK(tb_);                                     // action map + simulator cycle
-#endif
-        int flags = judge_sq(p, e.px, e.py, e.bx, e.by, e.step_number);
-        snap[g][b][WS_PX][lane] = e.px; snap[g][b][WS_PY][lane] = e.py; snap[g][b][WS_BODY][lane] = e.body;
-        snap[g][b][WS_BX][lane] = e.bx; snap[g][b][WS_BY][lane] = e.by;
-        snap[g][b][WS_BVX][lane] = e.bvx; snap[g][b][WS_BVY][lane] = e.bvy;
-        snap[g][b][WS_FLAGS][lane] = __int_as_float(flags);
-        if (flags && p.auto_reset) {                       // rare
-#if S2D_HACK == 5
-          if (!have_prep) atomicAdd(&stats_stripe(o.stats)[5], 1ull);
-          atomicAdd(&stats_stripe(o.stats)[6], 1ull);
-#endif
-#if S2D_HACK != 2
-          if (!have_prep) prep_fill(p, rp, prep[g], lane, e, gl, gh);
-          reset_apply<NOISE>(p, rp, e, gl, gh, prep_take(prep[g], lane), p.recover_init);
-#endif
-          have_prep = false;
-          post[g][b][WS_PX][lane] = e.px; post[g][b][WS_PY][lane] = e.py; post[g][b][WS_BODY][lane] = e.body;
-          post[g][b][WS_BX][lane] = e.bx; post[g][b][WS_BY][lane] = e.by;
-          post[g][b][WS_BVX][lane] = e.bvx; post[g][b][WS_BVY][lane] = e.bvy;
+          int flags = judge_sq(p, e.px, e.py, d2, e.step_number);
+          snap[b][WS_PX][lane] = e.px; snap[b][WS_PY][lane] = e.py; snap[b][WS_BODY][lane] = e.body;
+          snap[b][WS_BX][lane] = e.bx; snap[b][WS_BY][lane] = e.by;
+          snap[b][WS_BVX][lane] = e.bvx; snap[b][WS_BVY][lane] = e.bvy;
+          snap[b][WS_FLAGS][lane] = __int_as_float(flags);
+          if (flags && p.auto_reset) {
+            if (!have_prep) prep_fill(p, rp, prep, lane, e, gl, gh);
+            reset_apply<NOISE>(p, rp, e, gl, gh, prep_take(prep, lane), p.recover_init);
+            have_prep = false;
+            post[b][WS_PX][lane] = e.px; post[b][WS_PY][lane] = e.py; post[b][WS_BODY][lane] = e.body;
+            post[b][WS_BX][lane] = e.bx; post[b][WS_BY][lane] = e.by;
+            post[b][WS_BVX][lane] = e.bvx; post[b][WS_BVY][lane] = e.bvy;
+          }
         }
       }
-#if S2D_HACK == 8
+#if S2D_PROFILE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      S2D_TICK(tc_);                                       // done test + snapshot + reset
 #endif
-      __syncthreads();                                     // snapshot t published
-#if S2D_HACK == 8
-      S2D_TICK(td_);                                       // barrier
-#endif
+      S2D_TICK(2);                                         // done test + snapshot + reset
+      __syncthreads();
+      S2D_TICK(3);                                         // barrier
     }
-#if S2D_HACK == 8
-    if (lane == 0) {
-      atomicAdd(&stats_stripe(o.stats)[4], ta_); atomicAdd(&stats_stripe(o.stats)[5], tb_);
-      atomicAdd(&stats_stripe(o.stats)[6], tc_); atomicAdd(&stats_stripe(o.stats)[7], td_);
-    }
-#endif
+    S2D_TICK_FLUSH(o.stats, lane);
     if (active) {                                          // prev_dist / prev_angle belong to the O-wave
       S[F_PX * stride + i] = e.px; S[F_PY * stride + i] = e.py;
       S[F_VX * stride + i] = e.vx; S[F_VY * stride + i] = e.vy;
@@ -478,10 +540,10 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
       S[F_BVX * stride + i] = e.bvx; S[F_BVY * stride + i] = e.bvy;
       S[F_STEP * stride + i] = __int_as_float(e.step_number);
       S[F_CYCLE * stride + i] = __int_as_float(e.cycle);
-      o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
     }
   } else {
     // ------------------------------------------------------------------ O-wave
+    const S2DHot p = hot_in_vgprs(p_sgpr);
     float prev_dist = 0.0f, prev_angle = 0.0f;
     if (active) {
       prev_dist = S[F_PREV_DIST * stride + i]; prev_angle = S[F_PREV_ANGLE * stride + i];
@@ -492,76 +554,56 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
     unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
     int64_t row = 0;
-#if S2D_HACK == 9
-    unsigned long long tk_ = __builtin_readcyclecounter(), ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0;
+    S2D_TICK_INIT(3);
+    for (int s = 0; s < n_iter; ++s) {
+      if (s >= 2) {                                        // step s - 2
+        const int b = s & 1;
+        res = 0;
+        if (active) {
+          float px = snap[b][WS_PX][lane], py = snap[b][WS_PY][lane], body = snap[b][WS_BODY][lane];
+          float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
+          float bvx = snap[b][WS_BVX][lane], bvy = snap[b][WS_BVY][lane];
+          float dist = hypot2(bx - px, by - py);
+          int flags = __float_as_int(snap[b][WS_FLAGS][lane]);
+          float rel = observe(p, px, py, body, bx, by, bvx, bvy, ob);
+          reward = reward_of(prev_dist, prev_angle, dist, rel, flags, res);
+          prev_dist = dist; prev_angle = rel;
+          done = flags ? 1 : 0;
+#if S2D_PROFILE
+          asm volatile("" ::"v"(reward), "v"(ob.o[0]), "v"(ob.o[6]), "v"(ob.o[7]), "v"(res));
+          S2D_TICK(0);                                     // snapshot read + observe + reward
 #endif
-    for (int t = 0; t < n_steps; ++t, row += n) {
-      const int b = t & 1;
-      __syncthreads();                                     // wait for snapshot t
-#if S2D_HACK == 9
-      S2D_TICK(ta_);                                       // barrier
-#endif
-      res = 0;
-#if S2D_HACK == 6
-      if (false) {
-#else
-      if (active) {
-#endif
-        float px = snap[g][b][WS_PX][lane], py = snap[g][b][WS_PY][lane], body = snap[g][b][WS_BODY][lane];
-        float bx = snap[g][b][WS_BX][lane], by = snap[g][b][WS_BY][lane];
-        float bvx = snap[g][b][WS_BVX][lane], bvy = snap[g][b][WS_BVY][lane];
-        float dist = hypot2(bx - px, by - py);
-        int flags = __float_as_int(snap[g][b][WS_FLAGS][lane]);
-        float rel = observe(p, px, py, body, bx, by, bvx, bvy, ob);
-        reward = reward_of(prev_dist, prev_angle, dist, rel, flags, res);
-        prev_dist = dist; prev_angle = rel;
-        done = flags ? 1 : 0;
-#if S2D_HACK == 9
-        asm volatile("" :: "v"(reward), "v"(ob.o[0]), "v"(ob.o[6]), "v"(ob.o[7]), "v"(res));
-        S2D_TICK(tb_);                                     // snapshot read + observe + reward
-#endif
-#if S2D_HACK == 1
-        if (false) {
-#else
-        if (flags && p.auto_reset) {                       // rare: terminal row, then the new episode's first obs
-#endif
-#if S2D_HACK != 3
+          if (flags && p.auto_reset) {           // terminal row, then the new episode's first obs
 #pragma unroll
-          for (int k = 0; k < S2D_OBS_DIM; ++k) term_row[k] = ob.o[k];
-#endif
-          px = post[g][b][WS_PX][lane]; py = post[g][b][WS_PY][lane]; body = post[g][b][WS_BODY][lane];
-          bx = post[g][b][WS_BX][lane]; by = post[g][b][WS_BY][lane];
-          bvx = post[g][b][WS_BVX][lane]; bvy = post[g][b][WS_BVY][lane];
-          prev_angle = observe(p, px, py, body, bx, by, bvx, bvy, ob);    // reach_ball_env.py:166 carry seeded
-          prev_dist = hypot2(bx - px, by - py);
+            for (int k = 0; k < S2D_OBS_DIM; ++k) term_row[k] = ob.o[k];
+            px = post[b][WS_PX][lane]; py = post[b][WS_PY][lane]; body = post[b][WS_BODY][lane];
+            bx = post[b][WS_BX][lane]; by = post[b][WS_BY][lane];
+            bvx = post[b][WS_BVX][lane]; bvy = post[b][WS_BVY][lane];
+            prev_angle = observe(p, px, py, body, bx, by, bvx, bvy, ob);    // reach_ball_env.py:166 carry seeded
+            prev_dist = hypot2(bx - px, by - py);
+          }
+          if (ro.reward) ro.reward[row + i] = reward;
+          if (ro.done) ro.done[row + i] = (uint8_t)done;
+          if (ro.result) ro.result[row + i] = (uint8_t)res;
+          cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
         }
-        if (ro.reward) ro.reward[row + i] = reward;
-        if (ro.done) ro.done[row + i] = (uint8_t)done;
-        if (ro.result) ro.result[row + i] = (uint8_t)res;
-        cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
+        S2D_TICK(1);                                       // reset branch + reward/done/result stores
+        if (ro.obs) store_obs_tile(tile, ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
+        row += n;
       }
-#if S2D_HACK == 9
-      S2D_TICK(tc_);                                       // reset branch + reward/done/result stores
-#endif
-#if S2D_HACK != 6
-      if (ro.obs && rows > 0) store_obs_tile(tile[g], ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
-#endif
-#if S2D_HACK == 9
+#if S2D_PROFILE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      S2D_TICK(td_);                                       // observation tile
 #endif
+      S2D_TICK(2);                                         // observation tile
+      __syncthreads();
+      S2D_TICK(3);                                         // barrier
     }
-#if S2D_HACK == 9
-    if (lane == 0) {
-      atomicAdd(&stats_stripe(o.stats)[4], ta_); atomicAdd(&stats_stripe(o.stats)[5], tb_);
-      atomicAdd(&stats_stripe(o.stats)[6], tc_); atomicAdd(&stats_stripe(o.stats)[7], td_);
-    }
-#endif
+    S2D_TICK_FLUSH(o.stats, lane);
     if (active) {
       S[F_PREV_DIST * stride + i] = prev_dist; S[F_PREV_ANGLE * stride + i] = prev_angle;
       o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
     }
-    if (rows > 0) store_obs_tile(tile[g], ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, valid);
+    store_obs_tile(tile, ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, valid);
     if (!active) { cnt1 = cnt2 = cnt3 = 0; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -572,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_s
       if (cnt2) atomicAdd(&stats_stripe(o.stats)[2], (unsigned long long)cnt2);
       if (cnt3) atomicAdd(&stats_stripe(o.stats)[3], (unsigned long long)cnt3);
     }
-    if (blockIdx.x == 0 && g == 0 && lane == 0)
+    if (blockIdx.x == 0 && lane == 0)
       atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n * (unsigned long long)n_steps);
   }
 }
@@ -838,6 +880,7 @@ S2D_API int s2d_create(const S2DConfig* cfg, int64_t n_envs, int device, void* a
   for (int f = 0; f < 15; ++f) *planes[f] = S + (size_t)f * h->stride;
   b.step_number = reinterpret_cast<int32_t*>(S + (size_t)F_STEP * h->stride);
   b.cycle = reinterpret_cast<int32_t*>(S + (size_t)F_CYCLE * h->stride);
+  b.policy_step = reinterpret_cast<int32_t*>(S + (size_t)F_POLICY * h->stride);
   b.obs = reinterpret_cast<float*>(h->arena + L.obs);
   b.reward = reinterpret_cast<float*>(h->arena + L.reward);
   b.done = reinterpret_cast<uint8_t*>(h->arena + L.done);
@@ -887,10 +930,10 @@ S2D_API int s2d_buffer_offsets(S2DHandle h, int64_t* offsets, int n_offsets) {
   const void* ptrs[] = {h->buf.player_x, h->buf.player_y, h->buf.player_vx, h->buf.player_vy, h->buf.player_body,
                         h->buf.stamina, h->buf.effort, h->buf.recovery, h->buf.stamina_capacity, h->buf.ball_x,
                         h->buf.ball_y, h->buf.ball_vx, h->buf.ball_vy, h->buf.prev_dist, h->buf.prev_angle,
-                        h->buf.step_number, h->buf.cycle, h->buf.obs, h->buf.reward, h->buf.done, h->buf.result,
+                        h->buf.step_number, h->buf.cycle, h->buf.policy_step, h->buf.obs, h->buf.reward, h->buf.done, h->buf.result,
                         h->buf.terminal_obs, h->buf.action_dir, h->buf.action_cmd, h->buf.stats};
   const int count = 1 + (int)(sizeof ptrs / sizeof ptrs[0]);
-  if (n_offsets < count) return fail(S2D_EINVAL, "offsets array too small (need 26)");
+  if (n_offsets < count) return fail(S2D_EINVAL, "offsets array too small (need 27)");
   offsets[0] = (int64_t)h->arena_bytes;
   for (int k = 1; k < count; ++k) offsets[k] = (int64_t)(static_cast<const char*>(ptrs[k - 1]) - h->arena);
   return S2D_OK;
@@ -972,12 +1015,11 @@ S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int a
       {s2d_reach_rollout_ws_kernel<S2D_MODE_DISCRETE, false>, s2d_reach_rollout_ws_kernel<S2D_MODE_DISCRETE, true>},
       {s2d_reach_rollout_ws_kernel<S2D_MODE_CONT1, false>, s2d_reach_rollout_ws_kernel<S2D_MODE_CONT1, true>},
       {s2d_reach_rollout_ws_kernel<S2D_MODE_TURN4, false>, s2d_reach_rollout_ws_kernel<S2D_MODE_TURN4, true>}};
-  // small batches: two waves per env group (simulate || observe) keep every SIMD at >= 2 waves
+  // small batches: three waves per env group (policy | simulate | observe) keep every SIMD at >= 3 waves
   const bool ws = h->rollout_ws < 0 ? (h->n <= kWsMaxEnvs) : (h->rollout_ws != 0);
   if (ws) {
-    const int per_block = kWsGroups * kWave;
-    hipLaunchKernelGGL(table_ws[h->mode][h->noise ? 1 : 0], dim3((unsigned)((h->n + per_block - 1) / per_block)),
-                       dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->hot, h->rare_dev,
+    hipLaunchKernelGGL(table_ws[h->mode][h->noise ? 1 : 0], dim3((unsigned)((h->n + kWave - 1) / kWave)),
+                       dim3(kWsBlock), 0, static_cast<hipStream_t>(stream), h->hot, h->rare_dev,
                        reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, n_steps, actions_dev, action_kind,
                        ro, h->out);
     HIP_TRY(hipGetLastError());

@@ -78,13 +78,14 @@ BUFFER_FIELDS = (
     ('ball_vx', _F, 'float32', ()), ('ball_vy', _F, 'float32', ()),
     ('prev_dist', _F, 'float32', ()), ('prev_angle', _F, 'float32', ()),
     ('step_number', _I32, 'int32', ()), ('cycle', _I32, 'int32', ()),
+    ('policy_step', _I32, 'int32', ()),
     ('obs', _F, 'float32', (S2D_OBS_DIM,)), ('reward', _F, 'float32', ()),
     ('done', _U8, 'uint8', ()), ('result', _U8, 'uint8', ()),
     ('terminal_obs', _F, 'float32', (S2D_OBS_DIM,)),
     ('action_dir', _F, 'float32', ()), ('action_cmd', _U8, 'uint8', ()),
     ('stats', C.POINTER(C.c_ulonglong), 'int64', None),   # [8], not per-env
 )
-STATE_FIELDS = tuple(f[0] for f in BUFFER_FIELDS[:17])
+STATE_FIELDS = tuple(f[0] for f in BUFFER_FIELDS[:18])
 
 
 class S2DBuffers(C.Structure):

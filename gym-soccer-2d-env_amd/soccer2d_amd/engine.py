@@ -82,8 +82,8 @@ class Engine:
 
     def _make_views(self, nbytes):
         n = self.num_envs
-        off = (C.c_int64 * 26)()
-        _capi.check(self.lib, self.lib.s2d_buffer_offsets(self._h, off, 26), 's2d_buffer_offsets')
+        off = (C.c_int64 * 27)()
+        _capi.check(self.lib, self.lib.s2d_buffer_offsets(self._h, off, 27), 's2d_buffer_offsets')
         assert off[0] == nbytes
         self.buffers = {}
         for k, (name, _ct, dt, trail) in enumerate(BUFFER_FIELDS):

@@ -122,13 +122,16 @@ typedef struct S2DConfig {
 #define S2D_STATS_STRIPES 64
 typedef struct S2DBuffers {
   int64_t n_envs;
-  /* state, row S of SURVEY.md 8(a): 15 float + 2 int32 words per env */
+  /* state, row S of SURVEY.md 8(a): 15 float + 2 int32 words per env (+ policy_step, which only
+   * launches that draw in-engine policy randomness read or write) */
   float *player_x, *player_y, *player_vx, *player_vy, *player_body; /* body in degrees [-180,180] */
   float *stamina, *effort, *recovery, *stamina_capacity;
   float *ball_x, *ball_y, *ball_vx, *ball_vy;
   float *prev_dist, *prev_angle;  /* carry of check_trainer_observation, reach_ball_env.py:158-159 */
   int32_t *step_number;           /* reach_ball_env.py:55, 172 */
   int32_t *cycle;                 /* WorldModel.cycle, idl/service.proto:326 */
+  int32_t *policy_step;           /* steps that consumed an in-engine policy / select draw (S2D_ACT_RANDOM,
+                                   * or any step of a use_turning env): the Philox counter of those draws */
   /* per-step outputs */
   float *obs;            /* [N][10]  reach_ball_env.py:98-107 */
   float *reward;         /* [N] */

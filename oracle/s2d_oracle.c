@@ -299,6 +299,7 @@ typedef struct Env {
   REAL px, py, vx, vy, body, stamina, effort, recovery, capacity;
   REAL bx, by, bvx, bvy, prev_dist, prev_angle;
   int32_t step_number, cycle;
+  uint32_t policy_step;   /* steps that consumed an in-engine POLICY / SELECT draw */
 } Env;
 
 static REAL clampr(REAL v, REAL lo, REAL hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -486,9 +487,21 @@ API void s2do_reset(S2DOEngine *h, const uint8_t *mask) {
   }
 }
 
+/* In-engine policy randomness (not part of the reference: its policies live in the caller).
+ * Keyed by the env's `policy_step` k, NOT by the cycle, so that the draws of step t do not depend
+ * on whether an episode ended before t:  discrete / 1-D continuous policies use word k&3 of the
+ * POLICY block at counter k>>2 (one Philox call serves four steps), the 4-D turning policy uses
+ * the four words of POLICY block 1 at counter k; the turn/dash selection uniform of
+ * reach_ball_env.py:71 is word k&3 of the SELECT block at counter k>>2. */
+static uint32_t quad_word(uint64_t seed, uint64_t gid, uint32_t k, uint32_t stream) {
+  uint32_t w[4];
+  draw(seed, gid, k >> 2, stream, 0, w);
+  return w[k & 3u];
+}
+
 /* decode the action of env i for this cycle (caller layouts of include/s2d.h, or the
  * in-engine random policy) */
-static void fetch_action(const S2DOEngine *h, int64_t i, const void *actions, int kind, uint32_t cycle,
+static void fetch_action(const S2DOEngine *h, int64_t i, const void *actions, int kind, uint32_t k,
                          REAL a[4], void *rollout_action_out) {
   const P *p = &h->p;
   uint64_t gid = (uint64_t)(p->env_id_offset + i);
@@ -497,19 +510,21 @@ static void fetch_action(const S2DOEngine *h, int64_t i, const void *actions, in
     case S2D_ACT_DISCRETE_I32: a[0] = (REAL)((const int32_t *)actions)[i]; break;
     case S2D_ACT_DISCRETE_I64: a[0] = (REAL)((const int64_t *)actions)[i]; break;
     case S2D_ACT_CONTINUOUS: a[0] = (REAL)((const float *)actions)[i]; break;
-    case S2D_ACT_TURNING: for (int k = 0; k < 4; ++k) a[k] = (REAL)((const float *)actions)[i * 4 + k]; break;
+    case S2D_ACT_TURNING: for (int j = 0; j < 4; ++j) a[j] = (REAL)((const float *)actions)[i * 4 + j]; break;
     default: {
-      uint32_t w[4];
-      draw(p->seed, gid, cycle, ST_POLICY, 0, w);
-      if (!p->use_continuous) a[0] = (REAL)rnd_below(w[0], (uint32_t)p->n_actions);
-      else if (!p->use_turning) a[0] = rnd_u01(w[0]) * R(2.0) - R(1.0);
-      else for (int k = 0; k < 4; ++k) a[k] = rnd_u01(w[k]) * R(2.0) - R(1.0);
+      if (!p->use_continuous) a[0] = (REAL)rnd_below(quad_word(p->seed, gid, k, ST_POLICY), (uint32_t)p->n_actions);
+      else if (!p->use_turning) a[0] = rnd_u01(quad_word(p->seed, gid, k, ST_POLICY)) * R(2.0) - R(1.0);
+      else {
+        uint32_t w[4];
+        draw(p->seed, gid, k, ST_POLICY, 1, w);
+        for (int j = 0; j < 4; ++j) a[j] = rnd_u01(w[j]) * R(2.0) - R(1.0);
+      }
     }
   }
   if (rollout_action_out) {
     if (!p->use_continuous) ((int32_t *)rollout_action_out)[i] = (int32_t)a[0];
     else if (!p->use_turning) ((float *)rollout_action_out)[i] = (float)a[0];
-    else for (int k = 0; k < 4; ++k) ((float *)rollout_action_out)[i * 4 + k] = (float)a[k];
+    else for (int j = 0; j < 4; ++j) ((float *)rollout_action_out)[i * 4 + j] = (float)a[j];
   }
 }
 
@@ -520,14 +535,12 @@ static void step_one(S2DOEngine *h, int64_t i, const void *actions, int kind, vo
   Env *e = &h->env[i];
   uint64_t gid = (uint64_t)(p->env_id_offset + i);
   REAL a[4];
-  fetch_action(h, i, actions, kind, (uint32_t)e->cycle, a, rollout_action_out);
+  const int turning = p->use_continuous && p->use_turning;
+  fetch_action(h, i, actions, kind, e->policy_step, a, rollout_action_out);
   e->step_number += 1;                                   /* reach_ball_env.py:55 */
   REAL u = R(0.0);
-  if (p->use_continuous && p->use_turning) {
-    uint32_t w[4];
-    draw(p->seed, gid, (uint32_t)e->cycle, ST_SELECT, 0, w);
-    u = rnd_u01(w[0]);
-  }
+  if (turning) u = rnd_u01(quad_word(p->seed, gid, e->policy_step, ST_SELECT));
+  if (turning || kind == S2D_ACT_RANDOM) e->policy_step += 1u;
   int cmd; REAL power, dir;
   action_map(p, a, u, &cmd, &power, &dir);               /* :238 */
   h->action_cmd[i] = (uint8_t)cmd; h->action_dir[i] = dir;
@@ -591,14 +604,14 @@ API int s2do_get_state(const S2DOEngine *h, int field, double *out) {
       case 7: v = e->recovery; break; case 8: v = e->capacity; break; case 9: v = e->bx; break;
       case 10: v = e->by; break; case 11: v = e->bvx; break; case 12: v = e->bvy; break;
       case 13: v = e->prev_dist; break; case 14: v = e->prev_angle; break;
-      case 15: v = e->step_number; break; case 16: v = e->cycle; break;
+      case 15: v = e->step_number; break; case 16: v = e->cycle; break; case 17: v = e->policy_step; break;
       default: return -1;
     }
     out[i] = v;
   }
   return 0;
 }
-/* overwrite one env's state (tests: hand-placed scenarios) -- 17 values in field order */
+/* overwrite one env's state (tests: hand-placed scenarios) -- 18 values in field order */
 API int s2do_set_env(S2DOEngine *h, int64_t i, const double *v17) {
   if (i < 0 || i >= h->n) return -1;
   Env *e = &h->env[i];
@@ -606,7 +619,7 @@ API int s2do_set_env(S2DOEngine *h, int64_t i, const double *v17) {
   e->stamina = (REAL)v17[5]; e->effort = (REAL)v17[6]; e->recovery = (REAL)v17[7]; e->capacity = (REAL)v17[8];
   e->bx = (REAL)v17[9]; e->by = (REAL)v17[10]; e->bvx = (REAL)v17[11]; e->bvy = (REAL)v17[12];
   e->prev_dist = (REAL)v17[13]; e->prev_angle = (REAL)v17[14];
-  e->step_number = (int32_t)v17[15]; e->cycle = (int32_t)v17[16];
+  e->step_number = (int32_t)v17[15]; e->cycle = (int32_t)v17[16]; e->policy_step = (uint32_t)v17[17];
   return 0;
 }
 API const REAL *s2do_obs(const S2DOEngine *h) { return h->obs; }

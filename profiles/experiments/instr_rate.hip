@@ -121,6 +121,52 @@ __global__ void k_rcp_half(uint32_t* out, uint32_t seed) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
 }
 
+// a never-taken guarded region as the compiler emits it for a rare per-lane event:
+//   v_cmp -> s_and_saveexec -> s_cbranch_execz -> (skipped body) -> s_or exec ; one v_fma between regions
+__global__ void k_guard(uint32_t* out, uint32_t seed) {
+  float a0 = seed, m = 1.0001f, c = 0.5f, big = 1e30f;
+  for (int it = 0; it < ITERS; ++it) {
+    REP8(asm volatile("v_fma_f32 %0, %0, %1, %2\n"
+                      "v_cmp_gt_f32 vcc, %0, %3\n"
+                      "s_and_saveexec_b64 s[10:11], vcc\n"
+                      "s_cbranch_execz 1f\n"
+                      "v_mov_b32 %0, 0\n"
+                      "1: s_or_b64 exec, exec, s[10:11]\n" : "+v"(a0) : "v"(m), "v"(c), "v"(big) : "vcc", "s10", "s11");)
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)a0;
+}
+// the same decision as a select (no branch): v_cmp + v_cndmask
+__global__ void k_select(uint32_t* out, uint32_t seed) {
+  float a0 = seed, m = 1.0001f, c = 0.5f, big = 1e30f;
+  for (int it = 0; it < ITERS; ++it) {
+    REP8(asm volatile("v_fma_f32 %0, %0, %1, %2\n"
+                      "v_cmp_gt_f32 vcc, %0, %3\n"
+                      "v_cndmask_b32 %0, %0, %1, vcc\n" : "+v"(a0) : "v"(m), "v"(c), "v"(big) : "vcc");)
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)a0;
+}
+// wave-uniform scalar branch, never taken: s_cmp + s_cbranch_scc1
+__global__ void k_sbranch(uint32_t* out, uint32_t seed) {
+  float a0 = seed, m = 1.0001f, c = 0.5f;
+  for (int it = 0; it < ITERS; ++it) {
+    REP8(asm volatile("v_fma_f32 %0, %0, %1, %2\n"
+                      "s_cmp_eq_u32 %3, 12345\n"
+                      "s_cbranch_scc1 1f\n"
+                      "v_fma_f32 %0, %0, %1, %2\n"
+                      "1:\n" : "+v"(a0) : "v"(m), "v"(c), "s"(seed) : "scc");)
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)a0;
+}
+// LDS round trip: ds_write_b32 + ds_read_b32 + s_waitcnt
+__global__ void k_lds_rt(uint32_t* out, uint32_t seed) {
+  __shared__ float buf[256];
+  float a0 = seed; uint32_t addr = threadIdx.x * 4;
+  for (int it = 0; it < ITERS; ++it) {
+    REP8(asm volatile("ds_write_b32 %1, %0\nds_read_b32 %0, %1\ns_waitcnt lgkmcnt(0)\n" : "+v"(a0) : "v"(addr) : "memory");)
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)a0 + (uint32_t)buf[0];
+}
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 static double run(kern_t k, uint32_t* out, int blocks, int threads) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -140,7 +186,9 @@ int main() {
     {"v_mul_u32_u24", k_mul_u24}, {"v_mul_lo_u32", k_mul_lo}, {"v_mul_hi_u32", k_mul_hi},
     {"v_mad_u64_u32", k_mad_u64}, {"v_rcp_f32", k_rcp}, {"v_sqrt_f32", k_sqrt},
     {"dep v_fma_f32", k_fma_dep}, {"dep v_xor_b32", k_xor_dep}, {"dep v_mad_u64_u32", k_mad_u64_dep},
-    {"dep v_rcp_f32", k_rcp_dep}, {"half-wave v_fma_f32", k_fma_half}, {"half-wave v_xor_b32", k_xor_half}, {"half-wave v_rcp_f32", k_rcp_half}, {"philox round (per 1/64 it)", k_philox_dep}};
+    {"dep v_rcp_f32", k_rcp_dep}, {"guarded region (fma+cmp+saveexec+branch+or)/8", k_guard}, {"select (fma+cmp+cndmask)/8", k_select},
+    {"scalar branch (fma+s_cmp+s_cbranch+fma)/8", k_sbranch}, {"LDS write+read+wait /8", k_lds_rt},
+    {"half-wave v_fma_f32", k_fma_half}, {"half-wave v_xor_b32", k_xor_half}, {"half-wave v_rcp_f32", k_rcp_half}, {"philox round (per 1/64 it)", k_philox_dep}};
   // 1024 SIMDs; W waves per SIMD
   for (int W = 1; W <= 8; W *= 2) {
     int threads = 256, blocks = 256 * W;   // 256 CUs x W blocks of 4 waves -> W waves per SIMD

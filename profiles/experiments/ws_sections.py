@@ -1,4 +1,4 @@
-"""Section timers of the wave-specialised rollout kernel (S2D_HACK=8: simulate wave, 9: observe wave).
+"""Section timers of the wave-specialised rollout kernel (-DS2D_PROFILE=1/2/3: policy / simulate / observe wave).
 Run with S2D_LIB pointing at the instrumented build; prints ticks per wave-step per section."""
 import os, sys
 sys.path.insert(0, 'gym-soccer-2d-env_amd'); sys.path.insert(0, 'profiles/experiments')
@@ -16,8 +16,9 @@ for _ in range(L): eng.rollout(T, out=out)
 e1.record(); torch.cuda.synchronize()
 s = eng.stats.cpu().tolist()
 ws = (N // 64) * T * L
-names = {'8': ['refill+policy', 'action_map+sim_cycle', 'judge+snapshot+reset', 'barrier'],
-         '9': ['barrier', 'read+observe+reward', 'reset+small stores', 'obs tile']}[os.environ.get('S2D_SECTIONS', '8')]
+names = {'1': ['policy+decode', '-', '-', 'barrier'],
+         '2': ['refill check + command read', 'simulator cycle', 'done test+snapshot+reset', 'barrier'],
+         '3': ['read+observe+reward', 'reset+small stores', 'obs tile', 'barrier']}[os.environ.get('S2D_SECTIONS', '2')]
 tot = sum(s[4:8])
 print(eng.kernel_name(), 'launch us', e0.elapsed_time(e1) * 1e3 / L, 'per cycle ns', e0.elapsed_time(e1) * 1e6 / L / T)
 for nm, v in zip(names, s[4:8]):
