@@ -89,10 +89,30 @@ def cpu_baseline(n_envs, sample_steps):
     tN = run(threads, sN) if threads > 1 else t1
     vN = n_envs * sN / tN if threads > 1 else v1
     return {'value': vN, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-            'value_1thread': v1,
+            'value_1thread': v1, 'numpy': numpy_baseline(n_envs),
             'sample': f'{n_envs} envs x {sN} steps ({threads} OpenMP threads, {tN:.2f} s) and x {s1} steps '
                       f'(1 thread, {t1:.2f} s); oracle/s2d_oracle.c fp32 build, gcc -O2, same kwargs/seed; '
                       f'reference rcssserver+proxy+gRPC chain not measurable (binaries absent offline)'}
+
+
+def numpy_baseline(n_envs):
+    """the NumPy-vectorised restatement (oracle/s2d_oracle_numpy.py,
+    float64) -- what a Python user could do on the host -- on a ~3 s sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import oracle as O
+    from s2d_oracle_numpy import NumpyReachBall
+    task = dict(O.TASK_DEFAULTS); task.update(DQN_KWARGS)
+    eng = NumpyReachBall(n_envs, O.SERVER_DEFAULTS, task)
+    eng.reset()
+    eng.step(None)
+    t0 = time.perf_counter(); eng.step(None); eng.step(None); per = (time.perf_counter() - t0) / 2
+    steps = max(4, min(512, int(3.0 / per)))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step(None)
+    dt = time.perf_counter() - t0
+    return {'value': n_envs * steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port-numpy',
+            'sample': f'{n_envs} envs x {steps} steps ({dt:.2f} s), float64 NumPy, same kwargs/seed'}
 
 
 def init_distributed(rank, local_rank, world):
