@@ -208,14 +208,14 @@ def bench_match(args):
     if dist is not None:
         dist.barrier()
     elapsed = max_over_ranks(dist, dev, time.perf_counter() - t0)
-    state_b, rec_b = 23 * 10 * 4 + 11 * 4, 24 * 5 * 4 + 4 + 4 + 1
+    state_b, rec_b = 23 * 11 * 4 + 11 * 4, 24 * 5 * 4 + 4 + 4 + 1   # 23 objects x 11 words + 11 game ints; rollout record
     per_launch_steps = T if args.mode == 'rollout' else 1
     alg = n * (2 * state_b + (per_launch_steps * rec_b if args.mode == 'rollout' else 5))
     launch_s = e0.elapsed_time(e1) * 1e-3 / launches
     achieved = alg / launch_s / 1e9
     st = eng.stats.cpu().tolist()
     if rank == 0:
-        line = {'metric': 'env-steps/sec, 11v11 full-match engine (22 players, kick/tackle/offside/stamina)',
+        line = {'metric': 'env-steps/sec, 11v11 full-match engine (22 players, kick/tackle/catch/offside/stamina, player types)',
                 'value': world * n * K / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
                 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                 'dtype': 'f32', 'data': 'synthetic',

@@ -38,31 +38,38 @@ static constexpr int NP = S2D_MATCH_PLAYERS;
 static constexpr int BALL = S2D_MATCH_BALL;
 static constexpr int SLOTS = S2D_MATCH_SLOTS;
 
-enum { S2D_ST_TACKLE = 4 };
+enum { S2D_ST_TACKLE = 4, S2D_ST_CATCH = 5, S2D_ST_TYPES = 6 };
 enum { SIDE_NONE = 0, SIDE_LEFT = 1, SIDE_RIGHT = 2 };
-enum { MF_X, MF_Y, MF_VX, MF_VY, MF_BODY, MF_STAMINA, MF_EFFORT, MF_RECOVERY, MF_CAPACITY, MF_TACKLE, MF_OBJ_PLANES };
+enum { MF_X, MF_Y, MF_VX, MF_VY, MF_BODY, MF_STAMINA, MF_EFFORT, MF_RECOVERY, MF_CAPACITY, MF_TACKLE, MF_CATCH_BAN, MF_OBJ_PLANES };
+// Per-slot parameters (heterogeneous PlayerTypes, idl/service.proto:1697-1732): a [PT_WORDS][32] table,
+// one column per lane of the half-wave.  Column 22 (the ball) holds ball_size / ball_decay in the
+// size / decay rows, so the collision scan and the decay treat players and ball alike.
+enum { PT_SPEED_MAX, PT_SPEED_MAX2, PT_STAMINA_INC, PT_DECAY, PT_INERTIA, PT_DASH_RATE, PT_SIZE, PT_INV_KICK_MARGIN,
+       PT_KICKABLE_AREA, PT_KICK_RAND, PT_EXTRA_STAMINA, PT_EFFORT_MAX, PT_EFFORT_MIN, PT_KICK_RATE, PT_CATCH_LEN, PT_WORDS };
 enum { ME_CYCLE, ME_MODE, ME_MODE_SIDE, ME_SCORE_L, ME_SCORE_R, ME_LAST_TOUCH, ME_TIMER, ME_OFFSIDE, ME_REWARD, ME_NEAREST_L,
        ME_NEAREST_R, ME_ENV_PLANES };
 
-struct MParams {   // every field rounded once on the host (double -> float)
-  float half_l, half_w, player_size, ball_size, player_decay, ball_decay, player_rand, ball_rand;
-  float player_speed_max, player_speed_max2, player_accel_max, player_accel_max2, ball_speed_max, ball_speed_max2;
-  float ball_accel_max, ball_accel_max2, inertia_moment;
-  float stamina_max, stamina_inc_max, stamina_capacity, extra_stamina;
+struct MParams {   // every field rounded once on the host (double -> float); per-PlayerType values live in the PT table
+  float half_l, half_w, ball_size, player_rand, ball_rand;
+  float player_accel_max, player_accel_max2, ball_speed_max, ball_speed_max2;
+  float ball_accel_max, ball_accel_max2;
+  float stamina_max, stamina_capacity;
   float recover_init, recover_dec_thr_value, recover_min, recover_dec;
-  float effort_init, effort_dec_thr_value, effort_min, effort_dec, effort_inc_thr_value, effort_inc;
-  float dash_power_rate, max_dash_power, min_dash_power, max_dash_angle, min_dash_angle;
+  float effort_dec_thr_value, effort_dec, effort_inc_thr_value, effort_inc;
+  float max_dash_power, min_dash_power, max_dash_angle, min_dash_angle;
   float dash_angle_step, inv_dash_angle_step, side_dash_rate, back_dash_rate, max_moment, min_moment;
   float collision_vel_rate;
-  float kick_power_rate, kickable_area, kickable_margin, inv_kickable_margin, kick_rand, max_power, min_power, inv_max_power;
+  float max_power, min_power, inv_max_power;
   float tackle_dist, tackle_back_dist, tackle_width, tackle_power_rate, max_tackle_power, max_back_tackle_power;
   float goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
-  int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside;
+  float catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
+  int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle;
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
 };
+typedef float PTab[kHalf];   // one row of the per-slot table
 
-struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int tackle; };
+struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int tackle, catch_ban; };
 struct MGame { int cycle, mode, mode_side, score_l, score_r, last_touch, timer, offside; float reward; int done, nearest_l, nearest_r; };
 
 __constant__ float kFormX[11] = {-50.0f, -35.0f, -35.0f, -35.0f, -35.0f, -20.0f, -20.0f, -20.0f, -20.0f, -10.5f, -10.5f};
@@ -83,30 +90,30 @@ S2D_DEV void m_place(MObj& o, int l, int kickoff_side) {   // place_formation() 
   if (l < NP) {
     int k = l % 11; bool left = l < 11;
     o.x = left ? kFormX[k] : -kFormX[k]; o.y = kFormY[k];
-    o.vx = 0.0f; o.vy = 0.0f; o.body = left ? 0.0f : 180.0f; o.tackle = 0;
+    o.vx = 0.0f; o.vy = 0.0f; o.body = left ? 0.0f : 180.0f; o.tackle = 0; o.catch_ban = 0;
     if (kickoff_side == SIDE_LEFT && l == 10) { o.x = -0.4f; o.y = 0.0f; }
     if (kickoff_side == SIDE_RIGHT && l == 21) { o.x = 0.4f; o.y = 0.0f; }
   } else if (l == BALL) {
     o.x = 0.0f; o.y = 0.0f; o.vx = 0.0f; o.vy = 0.0f;
   }
 }
-S2D_DEV void m_recover(const MParams& p, MObj& o, bool with_capacity) {
-  o.stamina = p.stamina_max; o.effort = p.effort_init; o.recovery = p.recover_init;
+S2D_DEV void m_recover(const MParams& p, float effort_max, MObj& o, bool with_capacity) {
+  o.stamina = p.stamina_max; o.effort = effort_max; o.recovery = p.recover_init;
   if (with_capacity) o.capacity = p.stamina_capacity;
 }
-S2D_DEV void m_reset(const MParams& p, MObj& o, MGame& g, int l) {
-  o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+S2D_DEV void m_reset(const MParams& p, float effort_max, MObj& o, MGame& g, int l) {
+  o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   g = MGame{0, S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0, 0, 0, 0.0f, 0, 10, 20};
-  if (l < NP) m_recover(p, o, true);
+  if (l < NP) m_recover(p, effort_max, o, true);
   m_place(o, l, SIDE_LEFT);
 }
-S2D_DEV void m_dash(const MParams& p, MObj& o, float power, float dir, float& ax, float& ay) {
+S2D_DEV void m_dash(const MParams& p, const PTab* pt, int l, MObj& o, float power, float dir, float& ax, float& ay) {
   power = clampf(power, p.min_dash_power, p.max_dash_power);
   dir = clampf(dir, p.min_dash_angle, p.max_dash_angle);
   if (p.dash_angle_step > 0.0f) dir = p.dash_angle_step * rintf(dir * p.inv_dash_angle_step);
   bool back = power < 0.0f;
   float need = back ? power * -2.0f : power;
-  float avail = o.stamina + p.extra_stamina;
+  float avail = o.stamina + pt[PT_EXTRA_STAMINA][l];
   if (need > avail) need = avail;
   float st = o.stamina - need;
   o.stamina = st > 0.0f ? st : 0.0f;
@@ -116,37 +123,38 @@ S2D_DEV void m_dash(const MParams& p, MObj& o, float power, float dir, float& ax
       ? p.back_dash_rate - ((p.back_dash_rate - p.side_dash_rate) * (1.0f - (ad - 90.0f) * 0.011111111111111112f))
       : p.side_dash_rate + ((1.0f - p.side_dash_rate) * (1.0f - ad * 0.011111111111111112f));
   dir_rate = clampf(dir_rate, 0.0f, 1.0f);
-  float acc = fabsf(o.effort * power * dir_rate * p.dash_power_rate);
+  float acc = fabsf(o.effort * power * dir_rate * pt[PT_DASH_RATE][l]);
   if (back) dir += 180.0f;
   float sn, cs;
   sincos_deg(norm_deg_any(o.body + dir), sn, cs);
   ax = acc * cs; ay = acc * sn;
 }
-S2D_DEV void m_turn(const MParams& p, MObj& o, float moment, float noise_u) {
+S2D_DEV void m_turn(const MParams& p, float inertia_moment, MObj& o, float moment, float noise_u) {
   moment = clampf(moment, p.min_moment, p.max_moment);
   float speed = hypot2(o.vx, o.vy);
   float f = 1.0f;
   if (p.noise) f = 1.0f + (noise_u * 2.0f - 1.0f) * p.player_rand;
-  o.body = norm_deg_any(o.body + f * moment / (1.0f + p.inertia_moment * speed));
+  o.body = norm_deg_any(o.body + f * moment / (1.0f + inertia_moment * speed));
 }
-S2D_DEV bool m_kick(const MParams& p, const MObj& o, float bx, float by, float bvx, float bvy, float power, float dir,
-                    float u_mag, float u_ang, float& kx, float& ky) {
+S2D_DEV bool m_kick(const MParams& p, const PTab* pt, int l, const MObj& o, float bx, float by, float bvx, float bvy,
+                    float power, float dir, float u_mag, float u_ang, float& kx, float& ky) {
   float dx = bx - o.x, dy = by - o.y;
   float dist = hypot2(dx, dy);
-  if (!(dist <= p.kickable_area)) return false;
+  if (!(dist <= pt[PT_KICKABLE_AREA][l])) return false;
+  const float inv_margin = pt[PT_INV_KICK_MARGIN][l];
   power = clampf(power, p.min_power, p.max_power);
   dir = clampf(dir, -180.0f, 180.0f);
   float dir_diff = fabsf(norm_deg_any(atan2_deg(dy, dx) - o.body));
-  float dist_ball = dist - p.player_size - p.ball_size;
-  float eff = power * p.kick_power_rate * (1.0f - 0.25f * (dir_diff * 0.005555555555555556f)
-                                           - 0.25f * (dist_ball * p.inv_kickable_margin));
+  float dist_ball = dist - pt[PT_SIZE][l] - p.ball_size;
+  float eff = power * pt[PT_KICK_RATE][l] * (1.0f - 0.25f * (dir_diff * 0.005555555555555556f)
+                                             - 0.25f * (dist_ball * inv_margin));
   float sn, cs;
   sincos_deg(norm_deg_any(o.body + dir), sn, cs);
   float ax = eff * cs, ay = eff * sn;
   if (p.noise) {
-    float pos_rate = 0.5f + 0.25f * (dir_diff * 0.005555555555555556f + dist_ball * p.inv_kickable_margin);
+    float pos_rate = 0.5f + 0.25f * (dir_diff * 0.005555555555555556f + dist_ball * inv_margin);
     float speed_rate = 0.5f + 0.5f * (hypot2(bvx, bvy) * p.inv_speed_decay);
-    float max_rand = p.kick_rand * (power * p.inv_max_power) * (pos_rate + speed_rate);
+    float max_rand = pt[PT_KICK_RAND][l] * (power * p.inv_max_power) * (pos_rate + speed_rate);
     float mag = u_mag * max_rand;
     float s2, c2;
     sincos_deg(u_ang * 360.0f - 180.0f, s2, c2);
@@ -176,17 +184,29 @@ S2D_DEV bool m_tackle(const MParams& p, const MObj& o, float bx, float by, float
   kx = eff * c2; ky = eff * s2;
   return true;
 }
-S2D_DEV void m_update_stamina(const MParams& p, MObj& e) {
+// Player::goalieCatch: the ball must lie in the catch rectangle (catch_len long, catch_area_w wide) rooted
+// at the goalie and turned to body + dir; u = uniform draw (used when catch_probability < 1)
+S2D_DEV bool m_catch(const MParams& p, float catch_len, const MObj& o, float bx, float by, float dir, float u) {
+  dir = clampf(dir, p.min_catch_angle, p.max_catch_angle);
+  float sn, cs;
+  sincos_deg(norm_deg_any(o.body + dir), sn, cs);
+  float dx = bx - o.x, dy = by - o.y;
+  float rx = dx * cs + dy * sn, ry = dy * cs - dx * sn;
+  if (!(rx >= 0.0f && rx <= catch_len && fabsf(ry) <= p.catch_half_w)) return false;
+  return u < p.catch_probability;
+}
+S2D_DEV void m_update_stamina(const MParams& p, const PTab* pt, int l, MObj& e) {
+  const float effort_min = pt[PT_EFFORT_MIN][l], effort_max = pt[PT_EFFORT_MAX][l];
   if (e.stamina <= p.recover_dec_thr_value) {
     if (e.recovery > p.recover_min) { float r = e.recovery - p.recover_dec; e.recovery = r > p.recover_min ? r : p.recover_min; }
   }
   if (e.stamina <= p.effort_dec_thr_value) {
-    if (e.effort > p.effort_min) { float f = e.effort - p.effort_dec; e.effort = f > p.effort_min ? f : p.effort_min; }
+    if (e.effort > effort_min) { float f = e.effort - p.effort_dec; e.effort = f > effort_min ? f : effort_min; }
   }
   if (e.stamina >= p.effort_inc_thr_value) {
-    if (e.effort < p.effort_init) { float f = e.effort + p.effort_inc; e.effort = f < p.effort_init ? f : p.effort_init; }
+    if (e.effort < effort_max) { float f = e.effort + p.effort_inc; e.effort = f < effort_max ? f : effort_max; }
   }
-  float inc = e.recovery * p.stamina_inc_max;
+  float inc = e.recovery * pt[PT_STAMINA_INC][l];
   float room = p.stamina_max - e.stamina;
   if (inc > room) inc = room;
   if (p.stamina_capacity >= 0.0f) { if (inc > e.capacity) inc = e.capacity; }
@@ -211,8 +231,8 @@ S2D_DEV void wave_fence() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, uint32_t gl, uint32_t gh, int cmd,
-                         float a, float bb, MCounts& cnt, float2* pos) {
+S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, int l, int half, uint32_t gl, uint32_t gh,
+                         int cmd, float a, float bb, MCounts& cnt, float2* pos) {
   const bool is_player = l < NP, is_ball = l == BALL;
   const uint32_t cyc = (uint32_t)g.cycle;
   const int mode0 = g.mode, side0 = g.mode_side;
@@ -227,10 +247,19 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
   U4 nz{0, 0, 0, 0}, nk{0, 0, 0, 0};
   if (p.noise) { nz = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, (uint32_t)l); nk = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, 32u + (uint32_t)l); }
   const bool may_touch = !is_setplay(mode0) || side_of(l) == side0;
-  if (cmd == S2D_MCMD_DASH) m_dash(p, o, a, bb, ax, ay);
-  else if (cmd == S2D_MCMD_TURN) m_turn(p, o, a, rnd_u01(nz.z));
-  else if (cmd == S2D_MCMD_KICK) {
-    bool ok = m_kick(p, o, bx0, by0, bvx0, bvy0, a, bb, rnd_u01(nk.x), rnd_u01(nk.y), kx, ky);
+  bool caught = false;
+  if (cmd == S2D_MCMD_DASH) m_dash(p, pt, l, o, a, bb, ax, ay);
+  else if (cmd == S2D_MCMD_TURN) m_turn(p, pt[PT_INERTIA][l], o, a, rnd_u01(nz.z));
+  else if (cmd == S2D_MCMD_CATCH) {
+    // goalies only, play_on only, not while banned; every attempt starts the ban
+    if ((l == S2D_MATCH_GOALIE_LEFT || l == S2D_MATCH_GOALIE_RIGHT) && mode0 == S2D_GM_PLAY_ON && o.catch_ban == 0) {
+      float u = 0.0f;
+      if (p.catch_probability < 1.0f) u = rnd_u01(m_draw(p, gl, gh, cyc, S2D_ST_CATCH, (uint32_t)l).x);
+      o.catch_ban = p.catch_ban_cycle + 1;
+      caught = m_catch(p, pt[PT_CATCH_LEN][l], o, bx0, by0, a, u);
+    }
+  } else if (cmd == S2D_MCMD_KICK) {
+    bool ok = m_kick(p, pt, l, o, bx0, by0, bvx0, bvy0, a, bb, rnd_u01(nk.x), rnd_u01(nk.y), kx, ky);
     if (ok && may_touch) { kicked = true; cnt.kicks++; } else { kx = 0.0f; ky = 0.0f; }
   } else if (cmd == S2D_MCMD_TACKLE) {
     U4 w = m_draw(p, gl, gh, cyc, S2D_ST_TACKLE, (uint32_t)l);
@@ -246,10 +275,14 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
       o.vx += ax; o.vy += ay;
     }
     float s2 = sq2(o.vx, o.vy);
-    if (s2 > p.player_speed_max2) { float k = p.player_speed_max / sqrtf(s2); o.vx *= k; o.vy *= k; }
+    if (s2 > pt[PT_SPEED_MAX2][l]) { float k = pt[PT_SPEED_MAX][l] / sqrtf(s2); o.vx *= k; o.vy *= k; }
     if (p.noise) m_noise(o.vx, o.vy, p.player_rand, rnd_u01(nz.x), rnd_u01(nz.y));
     o.x += o.vx; o.y += o.vy;
   }
+  // a successful catch wins the cycle: every kick / tackle impulse of this cycle is dropped
+  const uint32_t cmask = hballot(caught, half) & ((1u << S2D_MATCH_GOALIE_LEFT) | (1u << S2D_MATCH_GOALIE_RIGHT));
+  const int caught_by = cmask ? __ffs((int)cmask) - 1 : -1;
+  if (caught_by >= 0) { kicked = false; kx = 0.0f; ky = 0.0f; if (l == caught_by) cnt.kicks++; }
   // ---- 2. ball: impulses summed in player order
   const uint32_t kmask = hballot(kicked, half) & 0x3FFFFFu;
   const bool any_kick = kmask != 0u;
@@ -264,7 +297,10 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
   }
   if (any_kick) g.last_touch = side_of(last_kicker);
   const bool ball_live = !is_setplay(mode0) || any_kick;
-  if (is_ball && ball_live) {
+  if (caught_by >= 0) {                                   // held: the ball rests where it was caught
+    g.last_touch = side_of(caught_by);
+    if (is_ball) { o.vx = 0.0f; o.vy = 0.0f; }
+  } else if (is_ball && ball_live) {
     if (any_kick) {
       float a2 = sq2(bax, bay);
       if (a2 > p.ball_accel_max2) { float k = p.ball_accel_max / sqrtf(a2); bax *= k; bay *= k; }
@@ -278,7 +314,7 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
   // ---- 3. collisions (Jacobi passes; loop bounds are wave-uniform)
   bool collided = false;
   int touch_player = -1;
-  const float ri = is_ball ? p.ball_size : p.player_size;
+  const float ri = pt[PT_SIZE][l];
   for (int pass = 0; pass < 10; ++pass) {
     float sx = 0.0f, sy = 0.0f; int c = 0; int tp = -1;
     pos[l] = make_float2(o.x, o.y);                       // wave-private tile: LDS ops of a wave are in order
@@ -286,7 +322,7 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
     for (int j = 0; j <= BALL; ++j) {
       const float2 pj = pos[j];                           // same address for the whole half: broadcast read
       float xj = pj.x, yj = pj.y;
-      float rj = j == BALL ? p.ball_size : p.player_size;
+      float rj = pt[PT_SIZE][j];                          // uniform address: broadcast read
       float dx = o.x - xj, dy = o.y - yj;
       float d2 = sq2(dx, dy), r = ri + rj;
       if (l <= BALL && j != l && d2 < r * r) {
@@ -359,7 +395,13 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
         int flagged_side = (g.offside & 0x7FF) ? SIDE_LEFT : SIDE_RIGHT;
         if (coll_touch_side != flagged_side) g.offside = 0;
       }
-      if (bx > p.half_l && fabsf(by) < p.goal_half_width) {
+      if (caught_by >= 0) {                                // goalie holds the ball
+        const int gs = side_of(caught_by);
+        const bool in_area = fabsf(by) <= p.pen_half_w && (gs == SIDE_LEFT ? bx <= -p.pen_x : bx >= p.pen_x);
+        // inside the own penalty area: free kick for the goalie's side; outside: catch fault
+        place_ball = true; pbx = bx; pby = by;
+        g.mode = S2D_GM_FREE_KICK; g.mode_side = in_area ? gs : other_side(gs); g.timer = 0; g.offside = 0;
+      } else if (bx > p.half_l && fabsf(by) < p.goal_half_width) {
         g.score_l += 1; g.reward = 1.0f; if (is_ball) cnt.goals_l++;
         restart_form = true; form_side = SIDE_RIGHT;
         g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_RIGHT; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
@@ -415,16 +457,15 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
       g.offside = 0;
     }
   }
-  if (recover_half && is_player) m_recover(p, o, false);
+  if (recover_half && is_player) m_recover(p, pt[PT_EFFORT_MAX][l], o, false);
   if (restart_form) m_place(o, l, form_side);
   else if (place_ball && is_ball) { o.x = pbx; o.y = pby; o.vx = 0.0f; o.vy = 0.0f; }
   // ---- 6. decay, tackle timers, stamina
+  if (l <= BALL) { const float decay = pt[PT_DECAY][l]; o.vx *= decay; o.vy *= decay; }   // column 22 = ball_decay
   if (is_player) {
-    o.vx *= p.player_decay; o.vy *= p.player_decay;
     if (o.tackle > 0) o.tackle -= 1;
-    m_update_stamina(p, o);
-  } else if (is_ball) {
-    o.vx *= p.ball_decay; o.vy *= p.ball_decay;
+    if (o.catch_ban > 0) o.catch_ban -= 1;
+    m_update_stamina(p, pt, l, o);
   }
   // ---- 7. nearest player to the ball per team (ties -> lowest index): butterfly min-reduction over
   // the half-wave on the 64-bit key (bits(d2) << 8 | index); d2 >= 0, so its bit pattern orders like
@@ -444,7 +485,7 @@ S2D_DEV void match_cycle(const MParams& p, MObj& o, MGame& g, int l, int half, u
   }
   if (g.done && p.auto_reset) {
     int d = g.done; float rw = g.reward;
-    m_reset(p, o, g, l);
+    m_reset(p, pt[PT_EFFORT_MAX][l], o, g, l);
     g.done = d; g.reward = rw;
   }
 }
@@ -462,12 +503,14 @@ S2D_DEV void m_random_action(const MParams& p, uint32_t gl, uint32_t gh, uint32_
 // ------------------------------------------------------------------------------------------
 // memory <-> registers
 // ------------------------------------------------------------------------------------------
-struct MPtrs { float* obj; int32_t* env; float* reward; uint8_t* done; unsigned long long* stats; int64_t obj_stride; int64_t env_stride; };
+struct MPtrs { float* obj; int32_t* env; float* reward; uint8_t* done; unsigned long long* stats; int64_t obj_stride; int64_t env_stride;
+               const float* ptab; /* [PT_WORDS][32] per-slot PlayerType parameters */ };
 
 S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g) {
-  o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (l < SLOTS) {
     int64_t k = e * SLOTS + l;
+    o.catch_ban = __float_as_int(q.obj[MF_CATCH_BAN * q.obj_stride + k]);
     o.x = q.obj[MF_X * q.obj_stride + k]; o.y = q.obj[MF_Y * q.obj_stride + k];
     o.vx = q.obj[MF_VX * q.obj_stride + k]; o.vy = q.obj[MF_VY * q.obj_stride + k];
     o.body = q.obj[MF_BODY * q.obj_stride + k];
@@ -490,6 +533,7 @@ S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGam
     q.obj[MF_STAMINA * q.obj_stride + k] = o.stamina; q.obj[MF_EFFORT * q.obj_stride + k] = o.effort;
     q.obj[MF_RECOVERY * q.obj_stride + k] = o.recovery; q.obj[MF_CAPACITY * q.obj_stride + k] = o.capacity;
     q.obj[MF_TACKLE * q.obj_stride + k] = __int_as_float(o.tackle);
+    q.obj[MF_CATCH_BAN * q.obj_stride + k] = __int_as_float(o.catch_ban);
   }
   if (l == BALL) {
     q.env[ME_CYCLE * q.env_stride + e] = g.cycle; q.env[ME_MODE * q.env_stride + e] = g.mode;
@@ -524,7 +568,7 @@ __global__ __launch_bounds__(kMBlock) void s2d_match_reset_kernel(MParams p, MPt
   if (e >= n) return;
   if (mask && !mask[e]) return;
   MObj o; MGame g;
-  m_reset(p, o, g, l);
+  m_reset(p, q.ptab[PT_EFFORT_MAX * kHalf + l], o, g, l);
   m_store(q, e, l, o, g);
 }
 
@@ -534,7 +578,10 @@ struct MRoll { float* obs; float* reward; int32_t* mode; uint8_t* done; };
 __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p, MPtrs q, int64_t n, int n_steps,
                                                                      const float* __restrict__ actions, MRoll ro) {
   __shared__ float2 pos_tile[kEnvsPerBlock][kHalf];
+  __shared__ PTab pt[PT_WORDS];                       // per-slot PlayerType parameters, shared by the 8 matches
   __shared__ unsigned int lds_cnt[8];
+  for (int k = threadIdx.x; k < PT_WORDS * kHalf; k += kMBlock) (&pt[0][0])[k] = q.ptab[k];
+  __syncthreads();
   const int l = threadIdx.x & (kHalf - 1);
   const int half = (threadIdx.x >> 5) & 1;
   const int64_t e = (int64_t)blockIdx.x * kEnvsPerBlock + threadIdx.x / kHalf;
@@ -555,7 +602,7 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
         m_random_action(p, gl, gh, (uint32_t)g.cycle, l, cmd, a, b);
       }
     }
-    match_cycle(p, o, g, l, half, gl, gh, cmd, a, b, cnt, pos_tile[threadIdx.x / kHalf]);
+    match_cycle(p, pt, o, g, l, half, gl, gh, cmd, a, b, cnt, pos_tile[threadIdx.x / kHalf]);
     if (valid) {
       const int64_t row = (int64_t)t * n + e;
       if (ro.obs && l < SLOTS) {
@@ -604,7 +651,7 @@ __global__ __launch_bounds__(kMBlock) void s2d_match_relative_kernel(MPtrs q, in
 // host side
 // ------------------------------------------------------------------------------------------
 struct S2DMatchEngine {
-  S2DMatchConfig cfg; MParams mp; int64_t n, stride; int device;
+  S2DMatchConfig cfg; MParams mp; float ptab[PT_WORDS][kHalf]; int64_t n, stride; int device;
   char* arena; size_t arena_bytes; bool owns_arena;
   S2DMatchBuffers buf; MPtrs ptrs;
 };
@@ -619,7 +666,7 @@ static int mfail(int code, const std::string& msg) { s2d_internal_set_error(msg.
   } while (0)
 
 static size_t m_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
-struct MLayout { size_t obj, env, reward, done, stats, total; int64_t stride; };
+struct MLayout { size_t obj, env, reward, done, stats, ptab, total; int64_t stride; };
 static MLayout m_layout(int64_t n) {
   MLayout L; L.stride = (int64_t)m_align((size_t)n, 64);
   size_t off = 0;
@@ -628,8 +675,94 @@ static MLayout m_layout(int64_t n) {
   L.reward = off; off += m_align((size_t)L.stride * 4, 256);
   L.done = off; off += m_align((size_t)L.stride, 256);
   L.stats = off; off += (size_t)S2D_STATS_STRIPES * 8 * sizeof(unsigned long long);
+  L.ptab = off; off += m_align((size_t)PT_WORDS * kHalf * 4, 256);
   L.total = off;
   return L;
+}
+
+// PlayerType 0 = the ServerParam values
+static S2DPlayerType m_default_type(const S2DServerParams& s, const S2DMatchParams& m) {
+  S2DPlayerType t;
+  t.player_speed_max = s.player_speed_max; t.stamina_inc_max = s.stamina_inc_max; t.player_decay = s.player_decay;
+  t.inertia_moment = s.inertia_moment; t.dash_power_rate = s.dash_power_rate; t.player_size = s.player_size;
+  t.kickable_margin = m.kickable_margin; t.kick_rand = m.kick_rand; t.extra_stamina = s.extra_stamina;
+  t.effort_max = s.effort_init; t.effort_min = s.effort_min; t.kick_power_rate = m.kick_power_rate;
+  t.catchable_area_l_stretch = 1.0;
+  return t;
+}
+
+S2D_API void s2d_match_default_player_params(S2DPlayerParams* q) {   // rcssserver stock player.conf (EXT)
+  if (!q) return;
+  std::memset(q, 0, sizeof *q);
+  q->player_speed_max_delta_min = 0.0; q->player_speed_max_delta_max = 0.0; q->stamina_inc_max_delta_factor = 0.0;
+  q->player_decay_delta_min = -0.1; q->player_decay_delta_max = 0.1; q->inertia_moment_delta_factor = 25.0;
+  q->dash_power_rate_delta_min = 0.0; q->dash_power_rate_delta_max = 0.0; q->player_size_delta_factor = -100.0;
+  q->kickable_margin_delta_min = -0.1; q->kickable_margin_delta_max = 0.1; q->kick_rand_delta_factor = 1.0;
+  q->extra_stamina_delta_min = 0.0; q->extra_stamina_delta_max = 50.0;
+  q->effort_max_delta_factor = -0.004; q->effort_min_delta_factor = -0.004;
+  q->new_dash_power_rate_delta_min = -0.0012; q->new_dash_power_rate_delta_max = 0.0008;
+  q->new_stamina_inc_max_delta_factor = -6000.0;
+  q->kick_power_rate_delta_min = 0.0; q->kick_power_rate_delta_max = 0.0;
+  q->catchable_area_l_stretch_min = 1.0; q->catchable_area_l_stretch_max = 1.3;
+}
+
+// host-side Philox (same function as the device's) for the type generator
+static void h_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// rcssserver's HeteroPlayer recipe (EXT, as published): each non-default type draws one delta per
+// trade-off pair from the PlayerParam ranges -- faster decay <-> more inertia, stronger dash <-> less
+// stamina income, wider kickable margin <-> noisier kicks, more extra stamina <-> lower effort range --
+// and is re-drawn until its top speed (effort_max * dash_power_rate * max_dash_power / (1 - decay))
+// lies in (0.75, player_speed_max].  Uniforms: Philox stream S2D_ST_TYPES at counter (type id, try).
+S2D_API int s2d_match_generate_player_types(S2DMatchConfig* c, const S2DPlayerParams* pp, uint64_t seed) {
+  if (!c) return mfail(S2D_EINVAL, "config is NULL");
+  S2DPlayerParams stock;
+  if (!pp) { s2d_match_default_player_params(&stock); pp = &stock; }
+  const S2DServerParams& s = c->sp; const S2DMatchParams& m = c->mp;
+  const S2DPlayerType base = m_default_type(s, m);
+  c->player_types[0] = base;
+  for (int id = 1; id < S2D_MATCH_PLAYER_TYPES; ++id) {
+    S2DPlayerType t = base;
+    for (int attempt = 0; attempt < 1000; ++attempt) {
+      double u[12];
+      for (int b = 0; b < 3; ++b) {
+        uint32_t w[4];
+        h_philox((uint32_t)id, (uint32_t)attempt, 0u, (S2D_ST_TYPES << 16) | (uint32_t)b, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        for (int k = 0; k < 4; ++k) u[b * 4 + k] = (double)(w[k] >> 8) * 5.9604644775390625e-8;
+      }
+      auto U = [&](int k, double lo, double hi) { return lo + u[k] * (hi - lo); };
+      t = base;
+      double d = U(0, pp->player_speed_max_delta_min, pp->player_speed_max_delta_max);
+      t.player_speed_max += d; t.stamina_inc_max += d * pp->stamina_inc_max_delta_factor;
+      d = U(1, pp->player_decay_delta_min, pp->player_decay_delta_max);
+      t.player_decay += d; t.inertia_moment += d * pp->inertia_moment_delta_factor;
+      d = U(2, pp->dash_power_rate_delta_min, pp->dash_power_rate_delta_max);
+      t.dash_power_rate += d; t.player_size += d * pp->player_size_delta_factor;
+      d = U(3, pp->new_dash_power_rate_delta_min, pp->new_dash_power_rate_delta_max);
+      t.dash_power_rate += d; t.stamina_inc_max += d * pp->new_stamina_inc_max_delta_factor;
+      d = U(4, pp->kickable_margin_delta_min, pp->kickable_margin_delta_max);
+      t.kickable_margin += d; t.kick_rand += d * pp->kick_rand_delta_factor;
+      d = U(5, pp->extra_stamina_delta_min, pp->extra_stamina_delta_max);
+      t.extra_stamina += d; t.effort_max += d * pp->effort_max_delta_factor; t.effort_min += d * pp->effort_min_delta_factor;
+      d = U(6, pp->kick_power_rate_delta_min, pp->kick_power_rate_delta_max);
+      t.kick_power_rate += d;
+      t.catchable_area_l_stretch = U(7, pp->catchable_area_l_stretch_min, pp->catchable_area_l_stretch_max);
+      if (!(t.player_decay > 0.0 && t.player_decay < 1.0) || !(t.kickable_margin > 0.0) || !(t.player_size > 0.0)) continue;
+      const double real_speed_max = t.effort_max * t.dash_power_rate * s.max_dash_power / (1.0 - t.player_decay);
+      if (real_speed_max > 0.75 && real_speed_max <= t.player_speed_max) break;
+      t = base;                                           // exhausted tries fall back to the default type
+    }
+    c->player_types[id] = t;
+  }
+  return S2D_OK;
 }
 
 S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
@@ -644,7 +777,10 @@ S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
   m.max_tackle_power = 100.0; m.max_back_tackle_power = 0.0;
   m.goal_width = 14.02; m.offside_active_area_size = 2.5; m.free_kick_distance = 9.15;
   m.tackle_cycles = 10; m.half_time_cycles = 3000; m.nr_normal_halfs = 2; m.drop_ball_time = 100; m.use_offside = 1;
+  m.catch_ban_cycle = 5; m.catchable_area_l = 1.2; m.catch_area_w = 1.0; m.catch_probability = 1.0;
+  m.max_catch_angle = 90.0; m.min_catch_angle = -90.0; m.penalty_area_length = 16.5; m.penalty_area_half_width = 20.16;
   c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
+  for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) c->player_types[t] = m_default_type(c->sp, m);   // homogeneous
 }
 
 S2D_API int s2d_match_validate_config(const S2DMatchConfig* c) {
@@ -657,39 +793,42 @@ S2D_API int s2d_match_validate_config(const S2DMatchConfig* c) {
   if (c->mp.half_time_cycles < 1 || c->mp.nr_normal_halfs < 1) return mfail(S2D_EINVAL, "half_time_cycles and nr_normal_halfs must be >= 1");
   if (c->mp.tackle_cycles < 0 || c->mp.drop_ball_time < 0) return mfail(S2D_EINVAL, "tackle_cycles / drop_ball_time must be >= 0");
   if (c->env_id_offset < 0) return mfail(S2D_EINVAL, "env_id_offset must be >= 0");
+  if (c->mp.catch_ban_cycle < 0 || !(c->mp.catch_area_w > 0) || !(c->mp.catchable_area_l > 0))
+    return mfail(S2D_EINVAL, "catch_ban_cycle must be >= 0, catch_area_w and catchable_area_l > 0");
+  for (int i = 0; i < S2D_MATCH_PLAYERS; ++i)
+    if (c->player_type_id[i] < 0 || c->player_type_id[i] >= S2D_MATCH_PLAYER_TYPES)
+      return mfail(S2D_EINVAL, "player_type_id entries must be in [0, 18)");
+  for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) {
+    const S2DPlayerType& y = c->player_types[t];
+    if (!(y.player_decay >= 0 && y.player_decay <= 1) || !(y.kickable_margin > 0) || !(y.player_size > 0) ||
+        !(y.player_speed_max > 0))
+      return mfail(S2D_EINVAL, "player_types: decay must be in [0,1], kickable_margin / player_size / player_speed_max > 0");
+  }
   return S2D_OK;
 }
 
-static void mparams_from_config(const S2DMatchConfig& c, MParams& p) {
+static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*ptab)[kHalf]) {
   const S2DServerParams& s = c.sp; const S2DMatchParams& m = c.mp;
   std::memset(&p, 0, sizeof p);
   p.half_l = (float)s.pitch_half_length; p.half_w = (float)s.pitch_half_width;
-  p.player_size = (float)s.player_size; p.ball_size = (float)s.ball_size;
-  p.player_decay = (float)s.player_decay; p.ball_decay = (float)s.ball_decay;
+  p.ball_size = (float)s.ball_size;
   p.player_rand = (float)s.player_rand; p.ball_rand = (float)s.ball_rand;
-  p.player_speed_max = (float)s.player_speed_max; p.player_speed_max2 = p.player_speed_max * p.player_speed_max;
   p.player_accel_max = (float)s.player_accel_max; p.player_accel_max2 = p.player_accel_max * p.player_accel_max;
   p.ball_speed_max = (float)s.ball_speed_max; p.ball_speed_max2 = p.ball_speed_max * p.ball_speed_max;
   p.ball_accel_max = (float)s.ball_accel_max; p.ball_accel_max2 = p.ball_accel_max * p.ball_accel_max;
-  p.inertia_moment = (float)s.inertia_moment;
-  p.stamina_max = (float)s.stamina_max; p.stamina_inc_max = (float)s.stamina_inc_max;
-  p.stamina_capacity = (float)s.stamina_capacity; p.extra_stamina = (float)s.extra_stamina;
+  p.stamina_max = (float)s.stamina_max; p.stamina_capacity = (float)s.stamina_capacity;
   p.recover_init = (float)s.recover_init; p.recover_dec_thr_value = (float)(s.recover_dec_thr * s.stamina_max);
   p.recover_min = (float)s.recover_min; p.recover_dec = (float)s.recover_dec;
-  p.effort_init = (float)s.effort_init; p.effort_dec_thr_value = (float)(s.effort_dec_thr * s.stamina_max);
-  p.effort_min = (float)s.effort_min; p.effort_dec = (float)s.effort_dec;
+  p.effort_dec_thr_value = (float)(s.effort_dec_thr * s.stamina_max); p.effort_dec = (float)s.effort_dec;
   p.effort_inc_thr_value = (float)(s.effort_inc_thr * s.stamina_max); p.effort_inc = (float)s.effort_inc;
-  p.dash_power_rate = (float)s.dash_power_rate; p.max_dash_power = (float)s.max_dash_power;
+  p.max_dash_power = (float)s.max_dash_power;
   p.min_dash_power = (float)s.min_dash_power; p.max_dash_angle = (float)s.max_dash_angle;
   p.min_dash_angle = (float)s.min_dash_angle; p.dash_angle_step = (float)s.dash_angle_step;
   p.inv_dash_angle_step = s.dash_angle_step > 0 ? (float)(1.0 / s.dash_angle_step) : 0.0f;
   p.side_dash_rate = (float)s.side_dash_rate; p.back_dash_rate = (float)s.back_dash_rate;
   p.max_moment = (float)s.max_moment; p.min_moment = (float)s.min_moment;
   p.collision_vel_rate = (float)s.collision_vel_rate;
-  p.kick_power_rate = (float)m.kick_power_rate; p.kickable_margin = (float)m.kickable_margin;
-  p.inv_kickable_margin = (float)(1.0 / m.kickable_margin);
-  p.kickable_area = p.player_size + p.ball_size + p.kickable_margin;
-  p.kick_rand = (float)m.kick_rand; p.max_power = (float)m.max_power; p.min_power = (float)m.min_power;
+  p.max_power = (float)m.max_power; p.min_power = (float)m.min_power;
   p.inv_max_power = (float)(1.0 / m.max_power);
   p.tackle_dist = (float)m.tackle_dist; p.tackle_back_dist = (float)m.tackle_back_dist;
   p.tackle_width = (float)m.tackle_width; p.tackle_power_rate = (float)m.tackle_power_rate;
@@ -698,11 +837,31 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p) {
   p.offside_area2 = (float)(m.offside_active_area_size * m.offside_active_area_size);
   p.free_kick_distance = (float)m.free_kick_distance;
   p.inv_speed_decay = (float)(1.0 / (s.ball_speed_max * s.ball_decay));
+  p.catch_half_w = (float)(m.catch_area_w * 0.5); p.catch_probability = (float)m.catch_probability;
+  p.max_catch_angle = (float)m.max_catch_angle; p.min_catch_angle = (float)m.min_catch_angle;
+  p.pen_x = (float)(s.pitch_half_length - m.penalty_area_length); p.pen_half_w = (float)m.penalty_area_half_width;
   p.tackle_cycles = m.tackle_cycles; p.half_time_cycles = m.half_time_cycles;
   p.nr_normal_halfs = m.nr_normal_halfs; p.drop_ball_time = m.drop_ball_time; p.use_offside = m.use_offside;
+  p.catch_ban_cycle = m.catch_ban_cycle;
   p.auto_reset = c.auto_reset; p.noise = c.noise;
   p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
   p.gid_lo = (uint32_t)(uint64_t)c.env_id_offset; p.gid_hi = (uint32_t)((uint64_t)c.env_id_offset >> 32);
+  // per-slot table: column i = the PlayerType of player i, column 22 = the ball (size / decay rows)
+  std::memset(ptab, 0, sizeof(float) * PT_WORDS * kHalf);
+  for (int i = 0; i < NP; ++i) {
+    const S2DPlayerType& t = c.player_types[c.player_type_id[i]];
+    const float size = (float)t.player_size, margin = (float)t.kickable_margin;
+    ptab[PT_SPEED_MAX][i] = (float)t.player_speed_max; ptab[PT_SPEED_MAX2][i] = ptab[PT_SPEED_MAX][i] * ptab[PT_SPEED_MAX][i];
+    ptab[PT_STAMINA_INC][i] = (float)t.stamina_inc_max; ptab[PT_DECAY][i] = (float)t.player_decay;
+    ptab[PT_INERTIA][i] = (float)t.inertia_moment; ptab[PT_DASH_RATE][i] = (float)t.dash_power_rate;
+    ptab[PT_SIZE][i] = size; ptab[PT_INV_KICK_MARGIN][i] = (float)(1.0 / t.kickable_margin);
+    ptab[PT_KICKABLE_AREA][i] = size + p.ball_size + margin;
+    ptab[PT_KICK_RAND][i] = (float)t.kick_rand; ptab[PT_EXTRA_STAMINA][i] = (float)t.extra_stamina;
+    ptab[PT_EFFORT_MAX][i] = (float)t.effort_max; ptab[PT_EFFORT_MIN][i] = (float)t.effort_min;
+    ptab[PT_KICK_RATE][i] = (float)t.kick_power_rate;
+    ptab[PT_CATCH_LEN][i] = (float)(m.catchable_area_l * t.catchable_area_l_stretch);
+  }
+  ptab[PT_SIZE][BALL] = p.ball_size; ptab[PT_DECAY][BALL] = (float)s.ball_decay;
 }
 
 S2D_API size_t s2d_match_arena_bytes(const S2DMatchConfig* cfg, int64_t n_envs) {
@@ -742,7 +901,7 @@ S2D_API int s2d_match_create(const S2DMatchConfig* cfg, int64_t n_envs, int devi
   S2DMatchEngine* h = new (std::nothrow) S2DMatchEngine();
   if (!h) return mfail(S2D_ENOMEM, "host allocation failed");
   h->cfg = *cfg; h->n = n_envs; h->stride = L.stride; h->device = device;
-  mparams_from_config(*cfg, h->mp);
+  mparams_from_config(*cfg, h->mp, h->ptab);
   if (arena_dev) {
     if (arena_bytes < L.total) { delete h; return mfail(S2D_ENOMEM, "arena smaller than s2d_match_arena_bytes()"); }
     if (reinterpret_cast<uintptr_t>(arena_dev) & 255u) { delete h; return mfail(S2D_EINVAL, "arena must be 256-byte aligned"); }
@@ -761,6 +920,7 @@ S2D_API int s2d_match_create(const S2DMatchConfig* cfg, int64_t n_envs, int devi
   b.x = obj + MF_X * os; b.y = obj + MF_Y * os; b.vx = obj + MF_VX * os; b.vy = obj + MF_VY * os; b.body = obj + MF_BODY * os;
   b.stamina = obj + MF_STAMINA * os; b.effort = obj + MF_EFFORT * os; b.recovery = obj + MF_RECOVERY * os;
   b.stamina_capacity = obj + MF_CAPACITY * os; b.tackle_cycles = reinterpret_cast<int32_t*>(obj + MF_TACKLE * os);
+  b.catch_ban = reinterpret_cast<int32_t*>(obj + MF_CATCH_BAN * os);
   b.cycle = env + ME_CYCLE * es; b.mode = env + ME_MODE * es; b.mode_side = env + ME_MODE_SIDE * es;
   b.score_left = env + ME_SCORE_L * es; b.score_right = env + ME_SCORE_R * es; b.last_touch_side = env + ME_LAST_TOUCH * es;
   b.setplay_timer = env + ME_TIMER * es; b.offside_mask = env + ME_OFFSIDE * es;
@@ -768,9 +928,12 @@ S2D_API int s2d_match_create(const S2DMatchConfig* cfg, int64_t n_envs, int devi
   b.done = reinterpret_cast<uint8_t*>(h->arena + L.done);
   b.nearest_left = env + ME_NEAREST_L * es; b.nearest_right = env + ME_NEAREST_R * es;
   b.stats = reinterpret_cast<unsigned long long*>(h->arena + L.stats);
-  h->ptrs = MPtrs{obj, env, b.reward_left, b.done, b.stats, (int64_t)os, (int64_t)es};
+  h->ptrs = MPtrs{obj, env, b.reward_left, b.done, b.stats, (int64_t)os, (int64_t)es,
+                  reinterpret_cast<const float*>(h->arena + L.ptab)};
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipError_t e = hipMemsetAsync(h->arena, 0, L.total, st);
+  // h->ptab lives as long as the handle, so the (possibly staged) copy may complete later
+  if (e == hipSuccess) e = hipMemcpyAsync(h->arena + L.ptab, h->ptab, sizeof h->ptab, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(s2d_match_reset_kernel, dim3(m_grid(n_envs)), dim3(kMBlock), 0, st, h->mp, h->ptrs, h->n,
                        (const uint8_t*)nullptr);
@@ -800,10 +963,10 @@ S2D_API int s2d_match_buffer_offsets(S2DMatchHandle h, int64_t* offsets, int n_o
   if (!h || !offsets) return mfail(S2D_EINVAL, "NULL argument");
   const S2DMatchBuffers& b = h->buf;
   const void* ptrs[] = {b.x, b.y, b.vx, b.vy, b.body, b.stamina, b.effort, b.recovery, b.stamina_capacity, b.tackle_cycles,
-                        b.cycle, b.mode, b.mode_side, b.score_left, b.score_right, b.last_touch_side, b.setplay_timer,
+                        b.catch_ban, b.cycle, b.mode, b.mode_side, b.score_left, b.score_right, b.last_touch_side, b.setplay_timer,
                         b.offside_mask, b.reward_left, b.done, b.nearest_left, b.nearest_right, b.stats};
   const int count = 1 + (int)(sizeof ptrs / sizeof ptrs[0]);
-  if (n_offsets < count) return mfail(S2D_EINVAL, "offsets array too small (need 24)");
+  if (n_offsets < count) return mfail(S2D_EINVAL, "offsets array too small (need 25)");
   offsets[0] = (int64_t)h->arena_bytes;
   for (int k = 1; k < count; ++k) offsets[k] = (int64_t)(static_cast<const char*>(ptrs[k - 1]) - h->arena);
   return S2D_OK;

@@ -4,7 +4,8 @@ import ctypes as C
 from . import _capi
 
 MATCH_PLAYERS, MATCH_SLOTS, MATCH_BALL, MATCH_OBJ_WORDS = 22, 24, 22, 5
-MCMD_NONE, MCMD_DASH, MCMD_TURN, MCMD_KICK, MCMD_TACKLE = 0, 1, 2, 3, 4
+MCMD_NONE, MCMD_DASH, MCMD_TURN, MCMD_KICK, MCMD_TACKLE, MCMD_CATCH = 0, 1, 2, 3, 4, 5
+MATCH_PLAYER_TYPES, GOALIE_LEFT, GOALIE_RIGHT = 18, 0, 11
 GM_TIME_OVER, GM_PLAY_ON, GM_KICK_OFF, GM_KICK_IN, GM_FREE_KICK, GM_CORNER_KICK, GM_GOAL_KICK, GM_OFF_SIDE = 1, 2, 3, 4, 5, 6, 7, 9
 GM_NAMES = {1: 'TimeOver', 2: 'PlayOn', 3: 'KickOff_', 4: 'KickIn_', 5: 'FreeKick_', 6: 'CornerKick_', 7: 'GoalKick_', 9: 'OffSide_'}
 
@@ -15,21 +16,45 @@ class S2DMatchParams(C.Structure):
         'tackle_dist', 'tackle_back_dist', 'tackle_width', 'tackle_power_rate',
         'max_tackle_power', 'max_back_tackle_power',
         'goal_width', 'offside_active_area_size', 'free_kick_distance')] + [(n, C.c_int32) for n in (
-            'tackle_cycles', 'half_time_cycles', 'nr_normal_halfs', 'drop_ball_time', 'use_offside', 'reserved0')]
+            'tackle_cycles', 'half_time_cycles', 'nr_normal_halfs', 'drop_ball_time', 'use_offside', 'catch_ban_cycle')] + [
+                (n, C.c_double) for n in ('catchable_area_l', 'catch_area_w', 'catch_probability', 'max_catch_angle',
+                                          'min_catch_angle', 'penalty_area_length', 'penalty_area_half_width')]
+
+
+PLAYER_TYPE_FIELDS = ('player_speed_max', 'stamina_inc_max', 'player_decay', 'inertia_moment', 'dash_power_rate',
+                      'player_size', 'kickable_margin', 'kick_rand', 'extra_stamina', 'effort_max', 'effort_min',
+                      'kick_power_rate', 'catchable_area_l_stretch')
+
+
+class S2DPlayerType(C.Structure):          # idl/service.proto:1697-1732 (members that enter the dynamics)
+    _fields_ = [(n, C.c_double) for n in PLAYER_TYPE_FIELDS]
+
+
+class S2DPlayerParams(C.Structure):        # idl/service.proto:1664-1695
+    _fields_ = [(n, C.c_double) for n in (
+        'player_speed_max_delta_min', 'player_speed_max_delta_max', 'stamina_inc_max_delta_factor',
+        'player_decay_delta_min', 'player_decay_delta_max', 'inertia_moment_delta_factor',
+        'dash_power_rate_delta_min', 'dash_power_rate_delta_max', 'player_size_delta_factor',
+        'kickable_margin_delta_min', 'kickable_margin_delta_max', 'kick_rand_delta_factor',
+        'extra_stamina_delta_min', 'extra_stamina_delta_max', 'effort_max_delta_factor', 'effort_min_delta_factor',
+        'new_dash_power_rate_delta_min', 'new_dash_power_rate_delta_max', 'new_stamina_inc_max_delta_factor',
+        'kick_power_rate_delta_min', 'kick_power_rate_delta_max',
+        'catchable_area_l_stretch_min', 'catchable_area_l_stretch_max')]
 
 
 class S2DMatchConfig(C.Structure):
     _fields_ = [('abi_version', C.c_uint32), ('struct_bytes', C.c_uint32),
                 ('sp', _capi.S2DServerParams), ('mp', S2DMatchParams),
                 ('seed', C.c_uint64), ('env_id_offset', C.c_int64),
-                ('auto_reset', C.c_int32), ('noise', C.c_int32), ('reserved', C.c_int32 * 4)]
+                ('auto_reset', C.c_int32), ('noise', C.c_int32), ('reserved', C.c_int32 * 4),
+                ('player_types', S2DPlayerType * MATCH_PLAYER_TYPES), ('player_type_id', C.c_int32 * MATCH_SLOTS)]
 
 
 _F, _I, _U8 = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 # (name, ctypes type, torch dtype, per-env trailing shape; None = stats[8])
 MATCH_BUFFER_FIELDS = tuple(
     [(n, _F, 'float32', (MATCH_SLOTS,)) for n in ('x', 'y', 'vx', 'vy', 'body', 'stamina', 'effort', 'recovery', 'stamina_capacity')]
-    + [('tackle_cycles', _I, 'int32', (MATCH_SLOTS,))]
+    + [('tackle_cycles', _I, 'int32', (MATCH_SLOTS,)), ('catch_ban', _I, 'int32', (MATCH_SLOTS,))]
     + [(n, _I, 'int32', ()) for n in ('cycle', 'mode', 'mode_side', 'score_left', 'score_right', 'last_touch_side',
                                       'setplay_timer', 'offside_mask')]
     + [('reward_left', _F, 'float32', ()), ('done', _U8, 'uint8', ()),
@@ -47,6 +72,8 @@ class S2DMatchRollout(C.Structure):
 
 MATCH_PROTOTYPES = (
     ('s2d_match_default_config', None, (C.POINTER(S2DMatchConfig),)),
+    ('s2d_match_default_player_params', None, (C.POINTER(S2DPlayerParams),)),
+    ('s2d_match_generate_player_types', C.c_int, (C.POINTER(S2DMatchConfig), C.POINTER(S2DPlayerParams), C.c_uint64)),
     ('s2d_match_validate_config', C.c_int, (C.POINTER(S2DMatchConfig),)),
     ('s2d_match_arena_bytes', C.c_size_t, (C.POINTER(S2DMatchConfig), C.c_int64)),
     ('s2d_match_create', C.c_int, (C.POINTER(S2DMatchConfig), C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,

@@ -16,18 +16,48 @@ _TD = {'float32': torch.float32, 'int32': torch.int32, 'uint8': torch.uint8, 'in
 _ITEM = {'float32': 4, 'int32': 4, 'uint8': 1, 'int64': 8}
 
 
-def make_match_config(seed=0x5EED, env_id_offset=0, auto_reset=True, noise=False, server_params=None, **match_params):
+def make_match_config(seed=0x5EED, env_id_offset=0, auto_reset=True, noise=False, server_params=None,
+                      hetero_seed=None, player_type_id=None, player_types=None, **match_params):
+    """S2DMatchConfig.  Heterogeneous players: `hetero_seed` draws the 17 non-default PlayerTypes the way
+    rcssserver does (s2d_match_generate_player_types); `player_types` = {type id: {field: value}} overrides;
+    `player_type_id` = 22 type ids, one per player slot (DoChangePlayerType, idl/service.proto:1393-1433;
+    default all 0 = homogeneous)."""
     lib = M.bind(_capi.load_library())
     cfg = M.S2DMatchConfig()
     lib.s2d_match_default_config(C.byref(cfg))
-    for k, v in (server_params or {}).items():
-        if not hasattr(cfg.sp, k):
-            raise ValueError(f"unknown ServerParam field {k!r}")
-        setattr(cfg.sp, k, float(v))
-    for k, v in match_params.items():
-        if not hasattr(cfg.mp, k):
-            raise ValueError(f"unknown match parameter {k!r}")
-        setattr(cfg.mp, k, type(getattr(cfg.mp, k))(v))
+    if server_params or match_params:
+        for k, v in (server_params or {}).items():
+            if not hasattr(cfg.sp, k):
+                raise ValueError(f"unknown ServerParam field {k!r}")
+            setattr(cfg.sp, k, float(v))
+        for k, v in match_params.items():
+            if not hasattr(cfg.mp, k):
+                raise ValueError(f"unknown match parameter {k!r}")
+            setattr(cfg.mp, k, type(getattr(cfg.mp, k))(v))
+        # the default type follows the (possibly overridden) server parameters
+        sp, mp = cfg.sp, cfg.mp
+        base = dict(player_speed_max=sp.player_speed_max, stamina_inc_max=sp.stamina_inc_max, player_decay=sp.player_decay,
+                    inertia_moment=sp.inertia_moment, dash_power_rate=sp.dash_power_rate, player_size=sp.player_size,
+                    kickable_margin=mp.kickable_margin, kick_rand=mp.kick_rand, extra_stamina=sp.extra_stamina,
+                    effort_max=sp.effort_init, effort_min=sp.effort_min, kick_power_rate=mp.kick_power_rate,
+                    catchable_area_l_stretch=1.0)
+        for t in range(M.MATCH_PLAYER_TYPES):
+            for k, v in base.items():
+                setattr(cfg.player_types[t], k, float(v))
+    if hetero_seed is not None:
+        _capi.check(lib, lib.s2d_match_generate_player_types(C.byref(cfg), None, int(hetero_seed) & 0xFFFFFFFFFFFFFFFF),
+                    's2d_match_generate_player_types')
+    for t, vals in (player_types or {}).items():
+        for k, v in vals.items():
+            if k not in M.PLAYER_TYPE_FIELDS:
+                raise ValueError(f"unknown PlayerType field {k!r}")
+            setattr(cfg.player_types[int(t)], k, float(v))
+    if player_type_id is not None:
+        ids = [int(v) for v in player_type_id]
+        if len(ids) != M.MATCH_PLAYERS:
+            raise ValueError("player_type_id needs 22 entries")
+        for i, v in enumerate(ids):
+            cfg.player_type_id[i] = v
     cfg.seed, cfg.env_id_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(env_id_offset)
     cfg.auto_reset, cfg.noise = int(bool(auto_reset)), int(bool(noise))
     _capi.check(lib, lib.s2d_match_validate_config(C.byref(cfg)), 's2d_match_validate_config')
@@ -56,8 +86,8 @@ class MatchEngine:
                                            self._stream(), C.byref(h))
         _capi.check(self.lib, rc, 's2d_match_create')
         self._h = h
-        off = (C.c_int64 * 24)()
-        _capi.check(self.lib, self.lib.s2d_match_buffer_offsets(self._h, off, 24), 's2d_match_buffer_offsets')
+        off = (C.c_int64 * 25)()
+        _capi.check(self.lib, self.lib.s2d_match_buffer_offsets(self._h, off, 25), 's2d_match_buffer_offsets')
         n = self.num_envs
         for k, (name, _ct, dt, trail) in enumerate(M.MATCH_BUFFER_FIELDS):
             o = off[k + 1]

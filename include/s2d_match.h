@@ -1,6 +1,7 @@
 /*
  * s2d_match.h -- C ABI of the 11v11 full-match engine (BASELINE.json
- * configs[3]: 22 players, kick / tackle / offside / stamina, thousands of lockstep matches).
+ * configs[3]: 22 players, kick / tackle / catch / offside / stamina, heterogeneous player
+ * types, thousands of lockstep matches).
  * Same library (libs2d_hip.so), same conventions as s2d.h: plain C, device pointers,
  * hipStream_t as void*, stream-ordered asynchronous launches, 0 / negative error codes.
  *
@@ -26,8 +27,13 @@ extern "C" {
 #define S2D_MATCH_BALL 22
 #define S2D_MATCH_OBJ_WORDS 5     /* observation row of one object: x, y, vx, vy, body */
 
-/* body commands, PlayerAction oneof members idl/service.proto:380-402 (catch/move: later) */
-enum { S2D_MCMD_NONE = 0, S2D_MCMD_DASH = 1, S2D_MCMD_TURN = 2, S2D_MCMD_KICK = 3, S2D_MCMD_TACKLE = 4 };
+#define S2D_MATCH_PLAYER_TYPES 18 /* PlayerParam.player_types, idl/service.proto:1666 */
+#define S2D_MATCH_GOALIE_LEFT 0   /* the goalie is the first player of each team */
+#define S2D_MATCH_GOALIE_RIGHT 11
+
+/* body commands, PlayerAction oneof members idl/service.proto:380-406, 1291-1298 (move: later) */
+enum { S2D_MCMD_NONE = 0, S2D_MCMD_DASH = 1, S2D_MCMD_TURN = 2, S2D_MCMD_KICK = 3, S2D_MCMD_TACKLE = 4,
+       S2D_MCMD_CATCH = 5 };
 /* GameModeType values used (idl/service.proto:267-301); the taking side is in mode_side */
 enum {
   S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4, S2D_GM_FREE_KICK = 5,
@@ -42,8 +48,33 @@ typedef struct S2DMatchParams {
   double max_tackle_power, max_back_tackle_power;                                  /* 100 0 */
   double goal_width, offside_active_area_size, free_kick_distance;                 /* 14.02 2.5 9.15 */
   int32_t tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time;        /* 10 3000 2 100 */
-  int32_t use_offside, reserved0;                                                  /* 1 */
+  int32_t use_offside, catch_ban_cycle;                                            /* 1 5 */
+  /* goalie catch (idl/service.proto:1488-1490, 1643-1644); the catch rectangle is catchable_area_l *
+   * PlayerType.catchable_area_l_stretch long, catch_area_w wide, rooted at the goalie */
+  double catchable_area_l, catch_area_w, catch_probability, max_catch_angle, min_catch_angle;  /* 1.2 1 1 90 -90 */
+  double penalty_area_length, penalty_area_half_width;                             /* 16.5 20.16 */
 } S2DMatchParams;
+
+/* PlayerType (idl/service.proto:1697-1732): the members that enter the dynamics.  Type 0 is the
+ * default type (= the ServerParam / S2DMatchParams values). */
+typedef struct S2DPlayerType {
+  double player_speed_max, stamina_inc_max, player_decay, inertia_moment, dash_power_rate, player_size;
+  double kickable_margin, kick_rand, extra_stamina, effort_max, effort_min, kick_power_rate;
+  double catchable_area_l_stretch;
+} S2DPlayerType;
+
+/* PlayerParam (idl/service.proto:1664-1695): the ranges rcssserver draws its heterogeneous types
+ * from (stock values in s2d_match_default_player_params). */
+typedef struct S2DPlayerParams {
+  double player_speed_max_delta_min, player_speed_max_delta_max, stamina_inc_max_delta_factor;
+  double player_decay_delta_min, player_decay_delta_max, inertia_moment_delta_factor;
+  double dash_power_rate_delta_min, dash_power_rate_delta_max, player_size_delta_factor;
+  double kickable_margin_delta_min, kickable_margin_delta_max, kick_rand_delta_factor;
+  double extra_stamina_delta_min, extra_stamina_delta_max, effort_max_delta_factor, effort_min_delta_factor;
+  double new_dash_power_rate_delta_min, new_dash_power_rate_delta_max, new_stamina_inc_max_delta_factor;
+  double kick_power_rate_delta_min, kick_power_rate_delta_max;
+  double catchable_area_l_stretch_min, catchable_area_l_stretch_max;
+} S2DPlayerParams;
 
 typedef struct S2DMatchConfig {
   uint32_t abi_version;   /* S2D_ABI_VERSION */
@@ -55,6 +86,10 @@ typedef struct S2DMatchConfig {
   int32_t auto_reset;     /* 1: a finished match (TimeOver) restarts inside the same step */
   int32_t noise;          /* 0: player_rand/ball_rand/kick_rand off; tackle success is always drawn */
   int32_t reserved[4];
+  /* heterogeneous players: the type table and the type of every player slot (DoChangePlayerType,
+   * idl/service.proto:1393-1433).  s2d_match_default_config: 18 copies of the default type, all ids 0. */
+  S2DPlayerType player_types[S2D_MATCH_PLAYER_TYPES];
+  int32_t player_type_id[S2D_MATCH_SLOTS];   /* [0..21]; the goalies (0, 11) keep type 0 in rcssserver */
 } S2DMatchConfig;
 
 /* Device buffers.  Per-object planes are [N][24] (slot = lane of the env's half-wave);
@@ -64,14 +99,15 @@ typedef struct S2DMatchBuffers {
   float *x, *y, *vx, *vy, *body;                      /* players + ball (ball: body unused) */
   float *stamina, *effort, *recovery, *stamina_capacity;
   int32_t *tackle_cycles;                             /* >0: player frozen after a tackle */
+  int32_t *catch_ban;                                 /* >0: goalie may not catch (catch_ban_cycle after every attempt) */
   int32_t *cycle, *mode, *mode_side, *score_left, *score_right;
   int32_t *last_touch_side, *setplay_timer, *offside_mask;     /* bit i = player i flagged */
   float *reward_left;      /* [N] +1 left goal, -1 right goal this cycle */
   uint8_t *done;           /* [N] 1 when the match reached TimeOver this cycle */
   int32_t *nearest_left, *nearest_right;              /* [N] index of the player closest to the ball, per team */
   unsigned long long *stats;  /* [S2D_STATS_STRIPES][8], sum over stripes: [0] env-steps [1] goals left
-                                 [2] goals right [3] matches finished [4] kicks [5] tackles [6] offsides
-                                 [7] ball-outs */
+                                 [2] goals right [3] matches finished [4] kicks + catches [5] tackles
+                                 [6] offsides [7] ball-outs */
 } S2DMatchBuffers;
 
 typedef struct S2DMatchRollout {
@@ -84,6 +120,11 @@ typedef struct S2DMatchRollout {
 typedef struct S2DMatchEngine *S2DMatchHandle;
 
 void s2d_match_default_config(S2DMatchConfig *cfg);
+void s2d_match_default_player_params(S2DPlayerParams *pp);
+/* Fill cfg->player_types[1..17] the way rcssserver's HeteroPlayer does (trade-off pairs drawn from
+ * the PlayerParam ranges; EXT), deterministically from `seed` (Philox).
+ * pp == NULL: stock ranges.  Type 0 stays the default type; player_type_id is not touched. */
+int s2d_match_generate_player_types(S2DMatchConfig *cfg, const S2DPlayerParams *pp, uint64_t seed);
 int s2d_match_validate_config(const S2DMatchConfig *cfg);
 size_t s2d_match_arena_bytes(const S2DMatchConfig *cfg, int64_t n_envs);
 int s2d_match_create(const S2DMatchConfig *cfg, int64_t n_envs, int device, void *arena_dev, size_t arena_bytes,
@@ -95,7 +136,7 @@ int s2d_match_buffer_offsets(S2DMatchHandle h, int64_t *offsets, int n_offsets);
 /* kick-off formation, full stamina, score 0-0, cycle 0, KickOff for the left side */
 int s2d_match_reset(S2DMatchHandle h, const uint8_t *mask_dev, void *stream);
 /* actions_dev: float[N][22][3] = {command, a, b}: Dash(power=a, dir=b) Turn(moment=a)
- * Kick(power=a, dir=b) Tackle(dir=a); NULL = uniform random policy drawn in-kernel */
+ * Kick(power=a, dir=b) Tackle(dir=a) Catch(dir=a, goalies only); NULL = uniform random policy drawn in-kernel */
 int s2d_match_step(S2DMatchHandle h, const float *actions_dev, void *stream);
 int s2d_match_rollout(S2DMatchHandle h, int n_steps, const float *actions_dev /* [T][N][22][3] or NULL */,
                       const S2DMatchRollout *out, void *stream);

@@ -21,7 +21,7 @@
 #define NOBJ (NP + 1)
 #define BALL S2D_MATCH_BALL
 
-enum { ST_TACKLE = 4 };
+enum { ST_TACKLE = 4, ST_CATCH = 5, ST_TYPES = 6 };
 enum { SIDE_NONE = 0, SIDE_LEFT = 1, SIDE_RIGHT = 2 };
 
 typedef struct MP {
@@ -37,9 +37,17 @@ typedef struct MP {
   REAL kick_power_rate, kickable_area, kickable_margin, inv_kickable_margin, kick_rand, max_power, min_power, inv_max_power;
   REAL tackle_dist, tackle_back_dist, tackle_width, tackle_power_rate, max_tackle_power, max_back_tackle_power;
   REAL goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
-  int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside;
+  int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle;
+  REAL catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
+  /* heterogeneous players: the parameters of every player slot's PlayerType (idl/service.proto:1697-1732) */
+  struct PT {
+    REAL player_speed_max, player_speed_max2, stamina_inc_max, player_decay, inertia_moment, dash_power_rate, player_size;
+    REAL kickable_margin, inv_kickable_margin, kickable_area, kick_rand, extra_stamina, effort_max, effort_min;
+    REAL kick_power_rate, catch_len;
+  } pt[S2D_MATCH_PLAYERS];
 } MP;
+typedef struct PT PT;
 
 static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   const S2DServerParams *s = &c->sp; const S2DMatchParams *m = &c->mp;
@@ -80,10 +88,30 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   p->inv_speed_decay = (REAL)(1.0 / (s->ball_speed_max * s->ball_decay));
   p->tackle_cycles = m->tackle_cycles; p->half_time_cycles = m->half_time_cycles;
   p->nr_normal_halfs = m->nr_normal_halfs; p->drop_ball_time = m->drop_ball_time; p->use_offside = m->use_offside;
+  p->catch_ban_cycle = m->catch_ban_cycle;
+  p->catch_half_w = (REAL)(m->catch_area_w * 0.5); p->catch_probability = (REAL)m->catch_probability;
+  p->max_catch_angle = (REAL)m->max_catch_angle; p->min_catch_angle = (REAL)m->min_catch_angle;
+  p->pen_x = (REAL)(s->pitch_half_length - m->penalty_area_length); p->pen_half_w = (REAL)m->penalty_area_half_width;
   p->seed = c->seed; p->env_id_offset = c->env_id_offset; p->auto_reset = c->auto_reset; p->noise = c->noise;
+  for (int i = 0; i < S2D_MATCH_PLAYERS; ++i) {
+    int id = c->player_type_id[i];
+    if (id < 0 || id >= S2D_MATCH_PLAYER_TYPES) id = 0;
+    const S2DPlayerType *t = &c->player_types[id];
+    PT *q = &p->pt[i];
+    q->player_speed_max = (REAL)t->player_speed_max; q->player_speed_max2 = q->player_speed_max * q->player_speed_max;
+    q->stamina_inc_max = (REAL)t->stamina_inc_max; q->player_decay = (REAL)t->player_decay;
+    q->inertia_moment = (REAL)t->inertia_moment; q->dash_power_rate = (REAL)t->dash_power_rate;
+    q->player_size = (REAL)t->player_size; q->kickable_margin = (REAL)t->kickable_margin;
+    q->inv_kickable_margin = (REAL)(1.0 / t->kickable_margin);
+    q->kickable_area = q->player_size + p->ball_size + q->kickable_margin;
+    q->kick_rand = (REAL)t->kick_rand; q->extra_stamina = (REAL)t->extra_stamina;
+    q->effort_max = (REAL)t->effort_max; q->effort_min = (REAL)t->effort_min;
+    q->kick_power_rate = (REAL)t->kick_power_rate;
+    q->catch_len = (REAL)(m->catchable_area_l * t->catchable_area_l_stretch);
+  }
 }
 
-typedef struct Obj { REAL x, y, vx, vy, body, stamina, effort, recovery, capacity; int32_t tackle; } Obj;
+typedef struct Obj { REAL x, y, vx, vy, body, stamina, effort, recovery, capacity; int32_t tackle, catch_ban; } Obj;
 typedef struct Match {
   Obj o[NOBJ];
   int32_t cycle, mode, mode_side, score_left, score_right, last_touch_side, setplay_timer, offside_mask;
@@ -103,7 +131,7 @@ static void place_formation(Match *m, int kickoff_side) {
     int k = i % 11; int left = i < 11;
     Obj *o = &m->o[i];
     o->x = left ? FORM_X[k] : -FORM_X[k]; o->y = FORM_Y[k];
-    o->vx = R(0.0); o->vy = R(0.0); o->body = left ? R(0.0) : R(180.0); o->tackle = 0;
+    o->vx = R(0.0); o->vy = R(0.0); o->body = left ? R(0.0) : R(180.0); o->tackle = 0; o->catch_ban = 0;
   }
   /* the taker stands at the ball */
   if (kickoff_side == SIDE_LEFT) { m->o[10].x = R(-0.4); m->o[10].y = R(0.0); }
@@ -113,7 +141,7 @@ static void place_formation(Match *m, int kickoff_side) {
 static void recover_all(const MP *p, Match *m, int with_capacity) {
   for (int i = 0; i < NP; ++i) {
     Obj *o = &m->o[i];
-    o->stamina = p->stamina_max; o->effort = p->effort_init; o->recovery = p->recover_init;
+    o->stamina = p->stamina_max; o->effort = p->pt[i].effort_max; o->recovery = p->recover_init;
     if (with_capacity) o->capacity = p->stamina_capacity;
   }
 }
@@ -128,13 +156,13 @@ static void match_reset(const MP *p, Match *m) {
 static REAL clampr(REAL v, REAL lo, REAL hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 /* Player::dash / Player::turn -- identical arithmetic to s2d_oracle.c (appendix A) */
-static void m_dash(const MP *p, Obj *o, REAL power, REAL dir, REAL *ax, REAL *ay) {
+static void m_dash(const MP *p, const PT *t, Obj *o, REAL power, REAL dir, REAL *ax, REAL *ay) {
   power = clampr(power, p->min_dash_power, p->max_dash_power);
   dir = clampr(dir, p->min_dash_angle, p->max_dash_angle);
   if (p->dash_angle_step > R(0.0)) dir = p->dash_angle_step * R(rint)(DIVC(dir, p->dash_angle_step, p->inv_dash_angle_step));
   int back = power < R(0.0);
   REAL need = back ? power * R(-2.0) : power;
-  REAL avail = o->stamina + p->extra_stamina;
+  REAL avail = o->stamina + t->extra_stamina;
   if (need > avail) need = avail;
   REAL st = o->stamina - need;
   o->stamina = st > R(0.0) ? st : R(0.0);
@@ -144,37 +172,37 @@ static void m_dash(const MP *p, Obj *o, REAL power, REAL dir, REAL *ax, REAL *ay
       ? p->back_dash_rate - ((p->back_dash_rate - p->side_dash_rate) * (R(1.0) - DIVC(ad - R(90.0), R(90.0), 0.011111111111111112f)))
       : p->side_dash_rate + ((R(1.0) - p->side_dash_rate) * (R(1.0) - DIVC(ad, R(90.0), 0.011111111111111112f)));
   dir_rate = clampr(dir_rate, R(0.0), R(1.0));
-  REAL acc = R(fabs)(o->effort * power * dir_rate * p->dash_power_rate);
+  REAL acc = R(fabs)(o->effort * power * dir_rate * t->dash_power_rate);
   if (back) dir += R(180.0);
   REAL sn, cs;
   sincos_deg(norm_deg(o->body + dir), &sn, &cs);
   *ax = acc * cs; *ay = acc * sn;
 }
-static void m_turn(const MP *p, Obj *o, REAL moment, REAL noise_u) {
+static void m_turn(const MP *p, const PT *t, Obj *o, REAL moment, REAL noise_u) {
   moment = clampr(moment, p->min_moment, p->max_moment);
   REAL speed = hypot2(o->vx, o->vy);
   REAL f = R(1.0);
   if (p->noise) f = R(1.0) + (noise_u * R(2.0) - R(1.0)) * p->player_rand;
-  o->body = norm_deg(o->body + f * moment / (R(1.0) + p->inertia_moment * speed));
+  o->body = norm_deg(o->body + f * moment / (R(1.0) + t->inertia_moment * speed));
 }
 /* Player::kick -- appendix A "Kick(power, dir)".  Returns 1 if the ball was kickable. */
-static int m_kick(const MP *p, const Obj *o, const Obj *b, REAL power, REAL dir, REAL u_mag, REAL u_ang, REAL *kx, REAL *ky) {
+static int m_kick(const MP *p, const PT *t, const Obj *o, const Obj *b, REAL power, REAL dir, REAL u_mag, REAL u_ang, REAL *kx, REAL *ky) {
   REAL dx = b->x - o->x, dy = b->y - o->y;
   REAL dist = hypot2(dx, dy);
-  if (!(dist <= p->kickable_area)) return 0;
+  if (!(dist <= t->kickable_area)) return 0;
   power = clampr(power, p->min_power, p->max_power);
   dir = clampr(dir, R(-180.0), R(180.0));
   REAL dir_diff = R(fabs)(norm_deg(atan2_deg(dy, dx) - o->body));
-  REAL dist_ball = dist - p->player_size - p->ball_size;
-  REAL eff = power * p->kick_power_rate * (R(1.0) - R(0.25) * DIVC(dir_diff, R(180.0), 0.005555555555555556f)
-                                            - R(0.25) * DIVC(dist_ball, p->kickable_margin, p->inv_kickable_margin));
+  REAL dist_ball = dist - t->player_size - p->ball_size;
+  REAL eff = power * t->kick_power_rate * (R(1.0) - R(0.25) * DIVC(dir_diff, R(180.0), 0.005555555555555556f)
+                                            - R(0.25) * DIVC(dist_ball, t->kickable_margin, t->inv_kickable_margin));
   REAL sn, cs;
   sincos_deg(norm_deg(o->body + dir), &sn, &cs);
   REAL ax = eff * cs, ay = eff * sn;
   if (p->noise) {
-    REAL pos_rate = R(0.5) + R(0.25) * (DIVC(dir_diff, R(180.0), 0.005555555555555556f) + DIVC(dist_ball, p->kickable_margin, p->inv_kickable_margin));
+    REAL pos_rate = R(0.5) + R(0.25) * (DIVC(dir_diff, R(180.0), 0.005555555555555556f) + DIVC(dist_ball, t->kickable_margin, t->inv_kickable_margin));
     REAL speed_rate = R(0.5) + R(0.5) * (hypot2(b->vx, b->vy) * p->inv_speed_decay);
-    REAL max_rand = p->kick_rand * (power * p->inv_max_power) * (pos_rate + speed_rate);
+    REAL max_rand = t->kick_rand * (power * p->inv_max_power) * (pos_rate + speed_rate);
     REAL mag = u_mag * max_rand;
     REAL s2, c2;
     sincos_deg(u_ang * R(360.0) - R(180.0), &s2, &c2);
@@ -205,17 +233,29 @@ static int m_tackle(const MP *p, const Obj *o, const Obj *b, REAL dir, REAL u, R
   *kx = eff * c2; *ky = eff * s2;
   return 1;
 }
-static void m_update_stamina(const MP *p, Obj *e) {
+/* Player::goalieCatch -- the ball must lie in the catch rectangle (catchable_area_l * stretch long,
+ * catch_area_w wide) rooted at the goalie and turned to body + dir; `u` = uniform draw (used when
+ * catch_probability < 1).  Returns 1 if the goalie holds the ball. */
+static int m_catch(const MP *p, const PT *t, const Obj *o, const Obj *b, REAL dir, REAL u) {
+  dir = clampr(dir, p->min_catch_angle, p->max_catch_angle);
+  REAL sn, cs;
+  sincos_deg(norm_deg(o->body + dir), &sn, &cs);
+  REAL dx = b->x - o->x, dy = b->y - o->y;
+  REAL rx = dx * cs + dy * sn, ry = dy * cs - dx * sn;
+  if (!(rx >= R(0.0) && rx <= t->catch_len && R(fabs)(ry) <= p->catch_half_w)) return 0;
+  return u < p->catch_probability;
+}
+static void m_update_stamina(const MP *p, const PT *t, Obj *e) {
   if (e->stamina <= p->recover_dec_thr_value) {
     if (e->recovery > p->recover_min) { REAL r = e->recovery - p->recover_dec; e->recovery = r > p->recover_min ? r : p->recover_min; }
   }
   if (e->stamina <= p->effort_dec_thr_value) {
-    if (e->effort > p->effort_min) { REAL f = e->effort - p->effort_dec; e->effort = f > p->effort_min ? f : p->effort_min; }
+    if (e->effort > t->effort_min) { REAL f = e->effort - p->effort_dec; e->effort = f > t->effort_min ? f : t->effort_min; }
   }
   if (e->stamina >= p->effort_inc_thr_value) {
-    if (e->effort < p->effort_init) { REAL f = e->effort + p->effort_inc; e->effort = f < p->effort_init ? f : p->effort_init; }
+    if (e->effort < t->effort_max) { REAL f = e->effort + p->effort_inc; e->effort = f < t->effort_max ? f : t->effort_max; }
   }
-  REAL inc = e->recovery * p->stamina_inc_max;
+  REAL inc = e->recovery * t->stamina_inc_max;
   REAL room = p->stamina_max - e->stamina;
   if (inc > room) inc = room;
   if (p->stamina_capacity >= R(0.0)) { if (inc > e->capacity) inc = e->capacity; }
@@ -251,10 +291,12 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   /* 1. commands */
   REAL ax[NP], ay[NP], kx[NP], ky[NP];
   int kicked[NP];
+  int caught_by = -1;
   uint32_t nzb[4] = {0, 0, 0, 0};
   if (p->noise) draw(p->seed, gid, cyc, ST_NOISE, BALL, nzb);
   for (int i = 0; i < NP; ++i) {
     Obj *o = &m->o[i];
+    const PT *t = &p->pt[i];
     ax[i] = ay[i] = kx[i] = ky[i] = R(0.0); kicked[i] = 0;
     int cmd = (int)act[i * 3 + 0];
     REAL a = (REAL)act[i * 3 + 1], bb = (REAL)act[i * 3 + 2];
@@ -262,10 +304,18 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     uint32_t nz[4] = {0, 0, 0, 0}, nk[4] = {0, 0, 0, 0};
     if (p->noise) { draw(p->seed, gid, cyc, ST_NOISE, (uint32_t)i, nz); draw(p->seed, gid, cyc, ST_NOISE, 32u + (uint32_t)i, nk); }
     int may_touch = !is_setplay(mode0) || side_of(i) == side0;      /* set play: only the taking side plays the ball */
-    if (cmd == S2D_MCMD_DASH) m_dash(p, o, a, bb, &ax[i], &ay[i]);
-    else if (cmd == S2D_MCMD_TURN) m_turn(p, o, a, rnd_u01(nz[2]));
-    else if (cmd == S2D_MCMD_KICK) {
-      int ok = m_kick(p, o, b, a, bb, rnd_u01(nk[0]), rnd_u01(nk[1]), &kx[i], &ky[i]);
+    if (cmd == S2D_MCMD_DASH) m_dash(p, t, o, a, bb, &ax[i], &ay[i]);
+    else if (cmd == S2D_MCMD_TURN) m_turn(p, t, o, a, rnd_u01(nz[2]));
+    else if (cmd == S2D_MCMD_CATCH) {
+      /* goalies only, play_on only, not while banned; every attempt starts the ban */
+      if ((i == S2D_MATCH_GOALIE_LEFT || i == S2D_MATCH_GOALIE_RIGHT) && mode0 == S2D_GM_PLAY_ON && o->catch_ban == 0) {
+        REAL u = R(0.0);
+        if (p->catch_probability < R(1.0)) { uint32_t w[4]; draw(p->seed, gid, cyc, ST_CATCH, (uint32_t)i, w); u = rnd_u01(w[0]); }
+        o->catch_ban = p->catch_ban_cycle + 1;
+        if (m_catch(p, t, o, b, a, u) && caught_by < 0) caught_by = i;
+      }
+    } else if (cmd == S2D_MCMD_KICK) {
+      int ok = m_kick(p, t, o, b, a, bb, rnd_u01(nk[0]), rnd_u01(nk[1]), &kx[i], &ky[i]);
       if (ok && may_touch) { kicked[i] = 1; st->v[4]++; } else { kx[i] = ky[i] = R(0.0); }
     } else if (cmd == S2D_MCMD_TACKLE) {
       uint32_t w[4];
@@ -282,17 +332,20 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
       o->vx += ax[i]; o->vy += ay[i];
     }
     REAL s2 = sq2(o->vx, o->vy);
-    if (s2 > p->player_speed_max2) { REAL k = p->player_speed_max / R(sqrt)(s2); o->vx *= k; o->vy *= k; }
+    if (s2 > t->player_speed_max2) { REAL k = t->player_speed_max / R(sqrt)(s2); o->vx *= k; o->vy *= k; }
     if (p->noise) add_noise(&o->vx, &o->vy, p->player_rand, rnd_u01(nz[0]), rnd_u01(nz[1]));
     o->x += o->vx; o->y += o->vy;
   }
+  if (caught_by >= 0) { st->v[4]++; for (int i = 0; i < NP; ++i) { kicked[i] = 0; kx[i] = ky[i] = R(0.0); } }   /* the catch wins the cycle */
   /* 2. ball: accelerations summed in player order */
   REAL bax = R(0.0), bay = R(0.0);
   int any_kick = 0, last_kicker = -1;
   for (int i = 0; i < NP; ++i) if (kicked[i]) { bax += kx[i]; bay += ky[i]; any_kick = 1; last_kicker = i; }
   if (any_kick) m->last_touch_side = side_of(last_kicker);
   const int ball_live = !is_setplay(mode0) || any_kick;
-  if (ball_live) {
+  if (caught_by >= 0) {                                   /* held: the ball rests where it was caught */
+    b->vx = R(0.0); b->vy = R(0.0); m->last_touch_side = side_of(caught_by);
+  } else if (ball_live) {
     if (any_kick) {
       REAL a2 = sq2(bax, bay);
       if (a2 > p->ball_accel_max2) { REAL k = p->ball_accel_max / R(sqrt)(a2); bax *= k; bay *= k; }
@@ -310,10 +363,10 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     REAL sx[NOBJ], sy[NOBJ]; int cnt[NOBJ]; int any = 0;
     for (int i = 0; i < NOBJ; ++i) {
       sx[i] = sy[i] = R(0.0); cnt[i] = 0;
-      REAL ri = i == BALL ? p->ball_size : p->player_size;
+      REAL ri = i == BALL ? p->ball_size : p->pt[i].player_size;
       for (int j = 0; j < NOBJ; ++j) {
         if (j == i) continue;
-        REAL rj = j == BALL ? p->ball_size : p->player_size;
+        REAL rj = j == BALL ? p->ball_size : p->pt[j].player_size;
         REAL dx = m->o[i].x - m->o[j].x, dy = m->o[i].y - m->o[j].y;
         REAL d2 = sq2(dx, dy), r = ri + rj;
         if (d2 < r * r) {
@@ -383,7 +436,12 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
         if (coll_touch_side != flagged_side) m->offside_mask = 0;
       }
       REAL bx = b->x, by = b->y;
-      if (bx > p->half_l && R(fabs)(by) < p->goal_half_width) {              /* goal for the left team */
+      if (caught_by >= 0) {                                                  /* goalie holds the ball */
+        int gs = side_of(caught_by);
+        int in_area = R(fabs)(by) <= p->pen_half_w && (gs == SIDE_LEFT ? bx <= -p->pen_x : bx >= p->pen_x);
+        /* inside the own penalty area: free kick for the goalie's side; outside: catch fault */
+        restart(m, S2D_GM_FREE_KICK, in_area ? gs : other_side(gs), bx, by);
+      } else if (bx > p->half_l && R(fabs)(by) < p->goal_half_width) {       /* goal for the left team */
         m->score_left += 1; m->reward_left = R(1.0); st->v[1]++;
         place_formation(m, SIDE_RIGHT);
         restart(m, S2D_GM_KICK_OFF, SIDE_RIGHT, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
@@ -428,9 +486,10 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   /* 6. decay, tackle timers, stamina */
   for (int i = 0; i < NP; ++i) {
     Obj *o = &m->o[i];
-    o->vx *= p->player_decay; o->vy *= p->player_decay;
+    o->vx *= p->pt[i].player_decay; o->vy *= p->pt[i].player_decay;
     if (o->tackle > 0) o->tackle -= 1;
-    m_update_stamina(p, o);
+    if (o->catch_ban > 0) o->catch_ban -= 1;
+    m_update_stamina(p, &p->pt[i], o);
   }
   b->vx *= p->ball_decay; b->vy *= p->ball_decay;
   /* 7. nearest player to the ball per team (ties: lowest index) */
@@ -502,12 +561,13 @@ API void s2dmo_step(S2DMOEngine *h, const float *actions) {
 API int s2dmo_get(const S2DMOEngine *h, int field, double *out) {
   for (int64_t e = 0; e < h->n; ++e) {
     const Match *m = &h->m[e];
-    if (field <= 9) {
+    if (field <= 9 || field == 22) {                     /* 22 = catch_ban (object plane) */
       for (int s = 0; s < S2D_MATCH_SLOTS; ++s) {
         double v = 0;
         if (s < NOBJ) {
           const Obj *o = &m->o[s];
           switch (field) {
+            case 22: v = o->catch_ban; break;
             case 0: v = o->x; break; case 1: v = o->y; break; case 2: v = o->vx; break; case 3: v = o->vy; break;
             case 4: v = o->body; break; case 5: v = o->stamina; break; case 6: v = o->effort; break;
             case 7: v = o->recovery; break; case 8: v = o->capacity; break; default: v = o->tackle; break;
@@ -535,7 +595,7 @@ API int s2dmo_set_obj(S2DMOEngine *h, int64_t e, int slot, const double *v10) {
   Obj *o = &h->m[e].o[slot];
   o->x = (REAL)v10[0]; o->y = (REAL)v10[1]; o->vx = (REAL)v10[2]; o->vy = (REAL)v10[3]; o->body = (REAL)v10[4];
   o->stamina = (REAL)v10[5]; o->effort = (REAL)v10[6]; o->recovery = (REAL)v10[7]; o->capacity = (REAL)v10[8];
-  o->tackle = (int32_t)v10[9];
+  o->tackle = (int32_t)v10[9]; o->catch_ban = 0;
   return 0;
 }
 API int s2dmo_set_game(S2DMOEngine *h, int64_t e, const int32_t *v8) {

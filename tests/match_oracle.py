@@ -13,14 +13,29 @@ MATCH_DEFAULTS = dict(
     tackle_dist=2.0, tackle_back_dist=0.0, tackle_width=1.25, tackle_power_rate=0.027,
     max_tackle_power=100.0, max_back_tackle_power=0.0,
     goal_width=14.02, offside_active_area_size=2.5, free_kick_distance=9.15,
-    tackle_cycles=10, half_time_cycles=3000, nr_normal_halfs=2, drop_ball_time=100, use_offside=1, reserved0=0)
+    tackle_cycles=10, half_time_cycles=3000, nr_normal_halfs=2, drop_ball_time=100, use_offside=1, catch_ban_cycle=5,
+    catchable_area_l=1.2, catch_area_w=1.0, catch_probability=1.0, max_catch_angle=90.0, min_catch_angle=-90.0,
+    penalty_area_length=16.5, penalty_area_half_width=20.16)
+
+
+def default_player_type(sp, mp):
+    """PlayerType 0 = the ServerParam values (the test suite's own statement of it)."""
+    return dict(player_speed_max=sp['player_speed_max'], stamina_inc_max=sp['stamina_inc_max'],
+                player_decay=sp['player_decay'], inertia_moment=sp['inertia_moment'],
+                dash_power_rate=sp['dash_power_rate'], player_size=sp['player_size'],
+                kickable_margin=mp['kickable_margin'], kick_rand=mp['kick_rand'], extra_stamina=sp['extra_stamina'],
+                effort_max=sp['effort_init'], effort_min=sp['effort_min'], kick_power_rate=mp['kick_power_rate'],
+                catchable_area_l_stretch=1.0)
 
 OBJ_FIELDS = ('x', 'y', 'vx', 'vy', 'body', 'stamina', 'effort', 'recovery', 'stamina_capacity', 'tackle_cycles')
+EXTRA_OBJ_FIELDS = {'catch_ban': 22}      # s2dmo_get field ids beyond the contiguous block
 ENV_FIELDS = ('cycle', 'mode', 'mode_side', 'score_left', 'score_right', 'last_touch_side', 'setplay_timer',
               'offside_mask', 'reward_left', 'done', 'nearest_left', 'nearest_right')
 
 
-def make_match_config(seed=0x5EED, env_id_offset=0, auto_reset=1, noise=0, server=None, **mp):
+def make_match_config(seed=0x5EED, env_id_offset=0, auto_reset=1, noise=0, server=None, player_types=None,
+                      player_type_id=None, **mp):
+    """player_types: {type id: {field: value}} overrides of the default type; player_type_id: 22 ints."""
     cfg = M.S2DMatchConfig()
     cfg.abi_version = _capi.S2D_ABI_VERSION
     cfg.struct_bytes = C.sizeof(M.S2DMatchConfig)
@@ -36,6 +51,14 @@ def make_match_config(seed=0x5EED, env_id_offset=0, auto_reset=1, noise=0, serve
     for k, v in d.items():
         setattr(cfg.mp, k, type(getattr(cfg.mp, k))(v))
     cfg.seed, cfg.env_id_offset, cfg.auto_reset, cfg.noise = seed, env_id_offset, auto_reset, noise
+    base = default_player_type(sp, d)
+    for t in range(M.MATCH_PLAYER_TYPES):
+        vals = dict(base)
+        vals.update((player_types or {}).get(t, {}))
+        for k, v in vals.items():
+            setattr(cfg.player_types[t], k, float(v))
+    for i in range(22):
+        cfg.player_type_id[i] = int(player_type_id[i]) if player_type_id is not None else 0
     return cfg
 
 
@@ -101,11 +124,11 @@ class MatchOracle:
         return a
 
     def get(self, name):
-        if name in OBJ_FIELDS:
-            idx = OBJ_FIELDS.index(name)
+        if name in OBJ_FIELDS or name in EXTRA_OBJ_FIELDS:
+            idx = OBJ_FIELDS.index(name) if name in OBJ_FIELDS else EXTRA_OBJ_FIELDS[name]
             out = np.zeros((self.n, 24))
             assert self.L.s2dmo_get(self.h, idx, out.ctypes.data_as(C.POINTER(C.c_double))) == 0
-            return out.astype(np.int32 if name == 'tackle_cycles' else np.float32)
+            return out.astype(np.int32 if name in ('tackle_cycles', 'catch_ban') else np.float32)
         idx = 10 + ENV_FIELDS.index(name)
         out = np.zeros(self.n)
         assert self.L.s2dmo_get(self.h, idx, out.ctypes.data_as(C.POINTER(C.c_double))) == 0

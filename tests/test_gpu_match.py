@@ -11,11 +11,17 @@ torch = pytest.importorskip('torch')
 def _pair(n, **kw):
     from soccer2d_amd.match import MatchEngine, make_match_config
     server = kw.pop('server', None)
-    eng = MatchEngine(n, 'cuda:0', cfg=make_match_config(server_params=server, **kw))
+    hetero = dict(hetero_seed=kw.pop('hetero_seed', None), player_type_id=kw.pop('player_type_id', None))
+    cfg = make_match_config(server_params=server, **hetero, **kw)
+    eng = MatchEngine(n, 'cuda:0', cfg=cfg)
     okw = dict(kw)
-    orc = MO.MatchOracle(MO.make_match_config(seed=okw.pop('seed', 0x5EED), env_id_offset=okw.pop('env_id_offset', 0),
-                                              auto_reset=int(okw.pop('auto_reset', True)), noise=int(okw.pop('noise', False)),
-                                              server=server, **okw), n)
+    ocfg = MO.make_match_config(seed=okw.pop('seed', 0x5EED), env_id_offset=okw.pop('env_id_offset', 0),
+                                auto_reset=int(okw.pop('auto_reset', True)), noise=int(okw.pop('noise', False)),
+                                server=server, player_type_id=hetero['player_type_id'], **okw)
+    if hetero['hetero_seed'] is not None:      # the type table is input data: the oracle gets the generated one
+        for t in range(18):
+            ocfg.player_types[t] = cfg.player_types[t]
+    orc = MO.MatchOracle(ocfg, n)
     return eng, orc
 
 
@@ -26,7 +32,7 @@ def _bits(a):
 
 def assert_match_same(eng, orc, tag):
     torch.cuda.synchronize()
-    for f in MO.OBJ_FIELDS + MO.ENV_FIELDS:
+    for f in MO.OBJ_FIELDS + ('catch_ban',) + MO.ENV_FIELDS:
         g = getattr(eng, f).cpu().numpy()
         c = orc.get(f)
         if not np.array_equal(_bits(g), _bits(c)):
@@ -166,3 +172,49 @@ def test_relative_tables_parity_and_nearest_k():
     assert torch.equal(d[:, 11:, 22].argmin(dim=1).int() + 11, eng.nearest_right)
     near3 = d[:, :11, 11:22].topk(3, dim=2, largest=False).indices      # 3 nearest opponents of each left player
     assert near3.shape == (n, 11, 3)
+
+
+def test_match_heterogeneous_types_and_catch_parity():
+    """18 generated PlayerTypes, a different one on every field player, goalies that catch whenever the
+    ball is close (caller actions: the random policy mixed with Catch commands), noise on: every word
+    equal after every cycle, and the catch / free-kick path does occur."""
+    from soccer2d_amd._capi_match import GM_FREE_KICK, MCMD_CATCH
+    n, T = 41, 260
+    ids = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0, 11, 12, 13, 14, 15, 16, 17, 1, 2, 3]
+    eng, orc = _pair(n, hetero_seed=7, player_type_id=ids, half_time_cycles=140, noise=True)
+    assert_match_same(eng, orc, 'hetero reset')
+    eff = eng.effort.cpu().numpy()[0]
+    assert len(set(np.round(eff[:22], 6))) > 5                       # effort_max differs by type
+    rs = np.random.RandomState(4)
+    free_kicks = 0
+    for t in range(T):
+        a = orc.random_actions()
+        bx, by = orc.get('x')[:, 22], orc.get('y')[:, 22]
+        for g, gx in ((0, -52.5), (11, 52.5)):                       # goalies: catch when the ball is within 2 m
+            gxs, gys = orc.get('x')[:, g], orc.get('y')[:, g]
+            near = np.hypot(bx - gxs, by - gys) < 2.0
+            a[near, g] = [MCMD_CATCH, rs.uniform(-90, 90), 0]
+        if t == 3:                                                   # make sure the path is exercised: drop the ball at a goalie
+            for e in range(0, n, 4):
+                gx, gy = float(orc.get('x')[e, 0]), float(orc.get('y')[e, 0])
+                orc.set_obj(e, 22, x=gx + 0.6, y=gy, vx=0.0, vy=0.0)
+                eng.x[e, 22] = gx + 0.6; eng.y[e, 22] = gy; eng.vx[e, 22] = 0.0; eng.vy[e, 22] = 0.0
+                orc.set_game(e, mode=2, mode_side=0); eng.mode[e] = 2; eng.mode_side[e] = 0
+                a[e, 0] = [MCMD_CATCH, 0, 0]
+        eng.step(torch.as_tensor(a, device='cuda:0')); orc.step(a)
+        free_kicks += int((orc.get('mode') == GM_FREE_KICK).sum())
+        if t % 7 == 0 or t < 8:
+            assert_match_same(eng, orc, f'hetero t={t}')
+    assert_match_same(eng, orc, 'hetero final')
+    assert list(eng.stats.cpu().numpy()) == list(orc.stats())
+    assert free_kicks > 0
+
+
+def test_match_hetero_rollout_random_policy_parity():
+    n, T = 64, 96
+    ids = [0] + list(range(1, 11)) + [0] + list(range(8, 18))
+    eng, orc = _pair(n, hetero_seed=123, player_type_id=ids, half_time_cycles=60)
+    out = eng.rollout(T)
+    for _ in range(T):
+        orc.step(None)
+    assert_match_same(eng, orc, 'hetero rollout')

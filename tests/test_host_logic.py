@@ -167,3 +167,39 @@ def test_league_table_stays_replicated_over_two_ranks():
     assert torch.allclose(ref.elo, got[0][1]) and int(got[0][2].sum()) == 2 * 3 * 24
     left, right = ref.pairing(0, 0, 1000)
     assert bool((left != right).all()) and int(left.min()) == 0 and int(left.max()) == 4
+
+
+def test_player_type_generator_is_deterministic_and_respects_the_trade_offs():
+    """s2d_match_generate_player_types is host code (no GPU): 17 heterogeneous types from the stock
+    PlayerParam ranges, the trade-off pairs move together, type 0 stays the default."""
+    import ctypes as C
+    from soccer2d_amd import _capi, _capi_match as M
+    lib = M.bind(_capi.load_library())
+    cfgs = []
+    for seed in (1, 1, 2):
+        cfg = M.S2DMatchConfig()
+        lib.s2d_match_default_config(C.byref(cfg))
+        assert lib.s2d_match_generate_player_types(C.byref(cfg), None, seed) == 0
+        cfgs.append(cfg)
+    a, b, c = cfgs
+    as_rows = lambda cfg: [[getattr(cfg.player_types[t], f) for f in M.PLAYER_TYPE_FIELDS] for t in range(18)]
+    assert as_rows(a) == as_rows(b) and as_rows(a) != as_rows(c)
+    t0 = a.player_types[0]
+    assert (t0.player_decay, t0.dash_power_rate, t0.kickable_margin, t0.effort_max) == (0.4, 0.006, 0.7, 1.0)
+    kinds = set()
+    for t in range(1, 18):
+        y = a.player_types[t]
+        assert 0.3 <= y.player_decay <= 0.5 and abs((y.inertia_moment - 5.0) - 25.0 * (y.player_decay - 0.4)) < 1e-9
+        assert 0.0048 <= y.dash_power_rate <= 0.0068
+        assert abs((y.stamina_inc_max - 45.0) + 6000.0 * (y.dash_power_rate - 0.006)) < 1e-9
+        assert 0.6 <= y.kickable_margin <= 0.8 and abs((y.kick_rand - 0.1) - (y.kickable_margin - 0.7)) < 1e-9
+        assert 50.0 <= y.extra_stamina <= 100.0 and abs((y.effort_max - 1.0) + 0.004 * (y.extra_stamina - 50.0)) < 1e-9
+        assert abs((y.effort_min - 0.6) + 0.004 * (y.extra_stamina - 50.0)) < 1e-9
+        assert 1.0 <= y.catchable_area_l_stretch <= 1.3 and y.player_speed_max == 1.05 and y.player_size == 0.3
+        top = y.effort_max * y.dash_power_rate * 100.0 / (1.0 - y.player_decay)
+        assert 0.75 < top <= 1.05
+        kinds.add(round(y.player_decay, 6))
+    assert len(kinds) == 17
+    assert lib.s2d_match_validate_config(C.byref(a)) == 0
+    a.player_type_id[3] = 18
+    assert lib.s2d_match_validate_config(C.byref(a)) != 0

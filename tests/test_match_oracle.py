@@ -207,3 +207,79 @@ def test_nearest_player_reduction():
     assert m.get('nearest_left')[0] == 3 and m.get('nearest_right')[0] in range(11, 22)
     d = np.hypot(m.get('x')[0][11:22] - m.get('x')[0][22], m.get('y')[0][11:22] - m.get('y')[0][22])
     assert m.get('nearest_right')[0] == 11 + int(np.argmin(d))
+
+
+# ------------------------------------------------------------------ goalie catch (Catch{}, idl/service.proto:404)
+def test_goalie_catch_gives_free_kick_and_bans_catching():
+    from soccer2d_amd._capi_match import GM_FREE_KICK, MCMD_CATCH
+    m = fresh(); play_on(m)
+    m.set_obj(0, 22, x=-49.2, y=0.3, vx=-1.0, vy=0.0)      # ball 0.8 m in front of the left goalie (-50, 0), moving in
+    m.step(acts(p0=[MCMD_CATCH, 0, 0]))
+    assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == LEFT and m.get('last_touch_side')[0] == LEFT
+    # held: the ball rests where it was caught, no goal is scored, the goalie is banned for 5 cycles
+    assert m.get('vx')[0][22] == 0 and m.get('x')[0][22] == pytest.approx(-49.2) and m.get('score_right')[0] == 0
+    assert m.get('catch_ban')[0][0] == 5 and m.stats()[4] == 1
+    # opponents are kept 9.15 m away during the free kick; the goalie's kick resumes play
+    m.set_obj(0, 21, x=-48.0, y=0.3)
+    m.step(acts())
+    assert np.hypot(m.get('x')[0][21] + 49.2, m.get('y')[0][21] - 0.3) == pytest.approx(9.15, rel=1e-6)
+    m.step(acts(p0=[MCMD_KICK, 100, 0]))
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('vx')[0][22] > 0
+
+
+def test_catch_needs_goalie_rectangle_and_no_ban():
+    from soccer2d_amd._capi_match import GM_FREE_KICK, MCMD_CATCH
+    m = fresh(); play_on(m)
+    m.set_obj(0, 22, x=-33.8, y=-20.0)                     # next to left #2 (index 1, a field player)
+    m.step(acts(p1=[MCMD_CATCH, 0, 0]))
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('catch_ban')[0][1] == 0
+    m = fresh(); play_on(m)
+    m.set_obj(0, 22, x=-48.5, y=0.0)                       # 1.5 m ahead: beyond catchable_area_l = 1.2
+    m.step(acts(p0=[MCMD_CATCH, 0, 0]))
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('catch_ban')[0][0] == 5   # the attempt still starts the ban
+    m.set_obj(0, 22, x=-49.5, y=0.0, vx=0.0, vy=0.0)
+    m.step(acts(p0=[MCMD_CATCH, 0, 0]))                    # banned: ignored although the ball is now in reach
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('catch_ban')[0][0] == 4
+    m = fresh(); play_on(m)
+    m.set_obj(0, 22, x=-50.0, y=0.9)                       # beside the goalie: needs the catch direction
+    m.step(acts(p0=[MCMD_CATCH, 0, 0]))
+    assert m.get('mode')[0] == GM_PLAY_ON
+    m = fresh(); play_on(m)
+    m.set_obj(0, 22, x=-50.0, y=0.9)
+    m.step(acts(p0=[MCMD_CATCH, 90, 0]))                   # dir = +90 deg turns the rectangle towards +y
+    assert m.get('mode')[0] == GM_FREE_KICK
+
+
+def test_catch_outside_the_penalty_area_is_a_fault():
+    from soccer2d_amd._capi_match import GM_FREE_KICK, MCMD_CATCH
+    m = fresh(); play_on(m)
+    m.set_obj(0, 0, x=-30.0, y=0.0)                        # goalie far out of his area (x > -36)
+    m.set_obj(0, 22, x=-29.2, y=0.0)
+    m.step(acts(p0=[MCMD_CATCH, 0, 0]))
+    assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == RIGHT
+
+
+# ------------------------------------------------------------------ heterogeneous PlayerTypes
+def test_player_types_change_the_dynamics_of_their_players_only():
+    fast = {3: dict(dash_power_rate=0.0068, player_decay=0.5, effort_max=0.9, effort_min=0.5, extra_stamina=80.0,
+                    stamina_inc_max=40.0, player_size=0.25, kickable_margin=0.8, kick_power_rate=0.03,
+                    inertia_moment=7.5, player_speed_max=1.2)}
+    ids = [0] * 22; ids[5] = 3
+    m = MO.MatchOracle(MO.make_match_config(player_types=fast, player_type_id=ids), 1)
+    play_on(m)
+    assert m.get('effort')[0][5] == pytest.approx(0.9) and m.get('effort')[0][6] == 1.0     # recover -> effort_max of the type
+    m.step(acts(p5=[MCMD_DASH, 100, 0], p6=[MCMD_DASH, 100, 0]))
+    # acc = effort * power * dash_power_rate ; vel after decay
+    assert m.get('vx')[0][5] == pytest.approx(0.9 * 100 * 0.0068 * 0.5, rel=1e-6)
+    assert m.get('vx')[0][6] == pytest.approx(1.0 * 100 * 0.006 * 0.4, rel=1e-6)
+    # stamina: 8000 - 100 + recovery * stamina_inc_max, clipped at stamina_max
+    assert m.get('stamina')[0][5] == pytest.approx(8000 - 100 + 40.0) and m.get('stamina')[0][6] == pytest.approx(8000 - 100 + 45.0)
+    # kickable area of the type: 0.25 + 0.085 + 0.8 = 1.135 (default 1.085)
+    m = MO.MatchOracle(MO.make_match_config(player_types=fast, player_type_id=ids), 1); play_on(m)
+    m.set_obj(0, 22, x=-20.0 + 1.12, y=-22.0)
+    m.step(acts(p5=[MCMD_KICK, 50, 0]))
+    assert m.get('vx')[0][22] > 0
+    m = MO.MatchOracle(MO.make_match_config(), 1); play_on(m)
+    m.set_obj(0, 22, x=-20.0 + 1.12, y=-22.0)
+    m.step(acts(p5=[MCMD_KICK, 50, 0]))
+    assert m.get('vx')[0][22] == 0
