@@ -575,11 +575,19 @@ __global__ __launch_bounds__(kMBlock) void s2d_match_reset_kernel(MParams p, MPt
 struct MRoll { float* obs; float* reward; int32_t* mode; uint8_t* done; };
 
 // n_steps cycles; actions = [T][N][22][3] or NULL (random policy).  n_steps = 1 with ro = {} is the per-step API.
-__global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p, MPtrs q, int64_t n, int n_steps,
+__global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p_arg, MPtrs q, int64_t n, int n_steps,
                                                                      const float* __restrict__ actions, MRoll ro) {
   __shared__ float2 pos_tile[kEnvsPerBlock][kHalf];
   __shared__ PTab pt[PT_WORDS];                       // per-slot PlayerType parameters, shared by the 8 matches
   __shared__ unsigned int lds_cnt[8];
+  // The ~60 uniform parameters are read from LDS (broadcast reads) where they are used instead of
+  // occupying SGPRs for the whole kernel: as kernargs they cost 142 SGPR spills and 48 B of scratch at
+  // the 128-VGPR cap (26 spills / 12 B this way, +14 % throughput).
+  __shared__ MParams p_lds;
+  static_assert(sizeof(MParams) / 4 <= kMBlock, "one thread per parameter word");
+  if (threadIdx.x < sizeof(MParams) / 4)
+    reinterpret_cast<uint32_t*>(&p_lds)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&p_arg)[threadIdx.x];
+  const MParams& p = p_lds;
   for (int k = threadIdx.x; k < PT_WORDS * kHalf; k += kMBlock) (&pt[0][0])[k] = q.ptab[k];
   __syncthreads();
   const int l = threadIdx.x & (kHalf - 1);
