@@ -45,7 +45,7 @@ enum { MF_X, MF_Y, MF_VX, MF_VY, MF_BODY, MF_STAMINA, MF_EFFORT, MF_RECOVERY, MF
 // one column per lane of the half-wave.  Column 22 (the ball) holds ball_size / ball_decay in the
 // size / decay rows, so the collision scan and the decay treat players and ball alike.
 enum { PT_SPEED_MAX, PT_SPEED_MAX2, PT_STAMINA_INC, PT_DECAY, PT_INERTIA, PT_DASH_RATE, PT_SIZE, PT_INV_KICK_MARGIN,
-       PT_KICKABLE_AREA, PT_KICK_RAND, PT_EXTRA_STAMINA, PT_EFFORT_MAX, PT_EFFORT_MIN, PT_KICK_RATE, PT_CATCH_LEN, PT_WORDS };
+       PT_KICKABLE_AREA2, PT_KICK_RAND, PT_EXTRA_STAMINA, PT_EFFORT_MAX, PT_EFFORT_MIN, PT_KICK_RATE, PT_CATCH_LEN, PT_WORDS };
 enum { ME_CYCLE, ME_MODE, ME_MODE_SIDE, ME_SCORE_L, ME_SCORE_R, ME_LAST_TOUCH, ME_TIMER, ME_OFFSIDE, ME_REWARD, ME_NEAREST_L,
        ME_NEAREST_R, ME_ENV_PLANES };
 
@@ -61,6 +61,7 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
   float collision_vel_rate;
   float max_power, min_power, inv_max_power;
   float tackle_dist, tackle_back_dist, tackle_width, tackle_power_rate, max_tackle_power, max_back_tackle_power;
+  float tackle_reach2;   // beyond this squared distance a tackle fails for certain (see m_tackle)
   float goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
   float catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle;
@@ -139,8 +140,11 @@ S2D_DEV void m_turn(const MParams& p, float inertia_moment, MObj& o, float momen
 S2D_DEV bool m_kick(const MParams& p, const PTab* pt, int l, const MObj& o, float bx, float by, float bvx, float bvy,
                     float power, float dir, float u_mag, float u_ang, float& kx, float& ky) {
   float dx = bx - o.x, dy = by - o.y;
-  float dist = hypot2(dx, dy);
-  if (!(dist <= pt[PT_KICKABLE_AREA][l])) return false;
+  // dist <= kickable_area decided on the square: sqrt is correctly rounded and monotone, and the table holds
+  // the largest float whose root does not exceed the kickable area (found on the host)
+  float d2 = sq2(dx, dy);
+  if (!(d2 <= pt[PT_KICKABLE_AREA2][l])) return false;
+  float dist = sqrtf(d2);
   const float inv_margin = pt[PT_INV_KICK_MARGIN][l];
   power = clampf(power, p.min_power, p.max_power);
   dir = clampf(dir, -180.0f, 180.0f);
@@ -162,6 +166,12 @@ S2D_DEV bool m_kick(const MParams& p, const PTab* pt, int l, const MObj& o, floa
   }
   kx = ax; ky = ay;
   return true;
+}
+// A ball farther away than sqrt(tackle_dist^2 + tackle_width^2) has |x| > tackle_dist or |y| > tackle_width in
+// the body frame, i.e. fail > 1 > u: tackle_reach2 is that bound with a 1 % margin (far more than the rounding
+// of the rotation), so those lanes skip the rotation and -- see the caller -- the Philox draw.
+S2D_DEV bool m_tackle_in_reach(const MParams& p, const MObj& o, float bx, float by) {
+  return sq2(bx - o.x, by - o.y) <= p.tackle_reach2;
 }
 S2D_DEV bool m_tackle(const MParams& p, const MObj& o, float bx, float by, float dir, float u, float& kx, float& ky) {
   float dx = bx - o.x, dy = by - o.y;
@@ -231,8 +241,10 @@ S2D_DEV void wave_fence() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// `last` = this is the final cycle of the launch: nearest_left / nearest_right are outputs only (nothing in
+// the dynamics reads them), so the reduction that produces them runs once per launch.
 S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, int l, int half, uint32_t gl, uint32_t gh,
-                         int cmd, float a, float bb, MCounts& cnt, float2* pos) {
+                         int cmd, float a, float bb, MCounts& cnt, float2* pos, bool last) {
   const bool is_player = l < NP, is_ball = l == BALL;
   const uint32_t cyc = (uint32_t)g.cycle;
   const int mode0 = g.mode, side0 = g.mode_side;
@@ -262,8 +274,11 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
     bool ok = m_kick(p, pt, l, o, bx0, by0, bvx0, bvy0, a, bb, rnd_u01(nk.x), rnd_u01(nk.y), kx, ky);
     if (ok && may_touch) { kicked = true; cnt.kicks++; } else { kx = 0.0f; ky = 0.0f; }
   } else if (cmd == S2D_MCMD_TACKLE) {
-    U4 w = m_draw(p, gl, gh, cyc, S2D_ST_TACKLE, (uint32_t)l);
-    bool ok = m_tackle(p, o, bx0, by0, a, rnd_u01(w.x), kx, ky);
+    bool ok = false;
+    if (m_tackle_in_reach(p, o, bx0, by0)) {               // rare: most tackles are nowhere near the ball
+      U4 w = m_draw(p, gl, gh, cyc, S2D_ST_TACKLE, (uint32_t)l);
+      ok = m_tackle(p, o, bx0, by0, a, rnd_u01(w.x), kx, ky);
+    }
     o.tackle = p.tackle_cycles + 1;
     cnt.tackles++;
     if (ok && may_touch) kicked = true; else { kx = 0.0f; ky = 0.0f; }
@@ -488,7 +503,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   // ---- 7. nearest player to the ball per team (ties -> lowest index): butterfly min-reduction over
   // the half-wave on the 64-bit key (bits(d2) << 8 | index); d2 >= 0, so its bit pattern orders like
   // the value and the key orders like (d2, index) -- the same winner as a scan in index order.
-  {
+  if (last) {
     float bxn = hbcast(o.x, BALL), byn = hbcast(o.y, BALL);
     float d2 = sq2(o.x - bxn, o.y - byn);
     const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 8) | (unsigned long long)l;
@@ -628,7 +643,7 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
         m_random_action(p, gl, gh, (uint32_t)g.cycle, l, cmd, a, b);
       }
     }
-    match_cycle(p, pt, o, g, l, half, gl, gh, cmd, a, b, cnt, pos_tile[threadIdx.x / kHalf]);
+    match_cycle(p, pt, o, g, l, half, gl, gh, cmd, a, b, cnt, pos_tile[threadIdx.x / kHalf], t == n_steps - 1);
     if (valid) {
       const int64_t row = (int64_t)t * n + e;
       if (ro.obs && l < SLOTS) {
@@ -859,6 +874,10 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   p.tackle_dist = (float)m.tackle_dist; p.tackle_back_dist = (float)m.tackle_back_dist;
   p.tackle_width = (float)m.tackle_width; p.tackle_power_rate = (float)m.tackle_power_rate;
   p.max_tackle_power = (float)m.max_tackle_power; p.max_back_tackle_power = (float)m.max_back_tackle_power;
+  {
+    const double td = m.tackle_dist > m.tackle_back_dist ? m.tackle_dist : m.tackle_back_dist;
+    p.tackle_reach2 = (float)(1.01 * (td * td + m.tackle_width * m.tackle_width));
+  }
   p.goal_half_width = (float)(m.goal_width * 0.5);
   p.offside_area2 = (float)(m.offside_active_area_size * m.offside_active_area_size);
   p.free_kick_distance = (float)m.free_kick_distance;
@@ -881,7 +900,13 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
     ptab[PT_STAMINA_INC][i] = (float)t.stamina_inc_max; ptab[PT_DECAY][i] = (float)t.player_decay;
     ptab[PT_INERTIA][i] = (float)t.inertia_moment; ptab[PT_DASH_RATE][i] = (float)t.dash_power_rate;
     ptab[PT_SIZE][i] = size; ptab[PT_INV_KICK_MARGIN][i] = (float)(1.0 / t.kickable_margin);
-    ptab[PT_KICKABLE_AREA][i] = size + p.ball_size + margin;
+    {  // largest float T with sqrtf(T) <= kickable_area  (dist <= ka  <=>  dist^2 <= T)
+      const float ka = size + p.ball_size + margin;
+      float T = ka * ka;
+      while (std::sqrt(T) > ka) T = std::nextafter(T, 0.0f);
+      while (std::sqrt(std::nextafter(T, INFINITY)) <= ka) T = std::nextafter(T, INFINITY);
+      ptab[PT_KICKABLE_AREA2][i] = T;
+    }
     ptab[PT_KICK_RAND][i] = (float)t.kick_rand; ptab[PT_EXTRA_STAMINA][i] = (float)t.extra_stamina;
     ptab[PT_EFFORT_MAX][i] = (float)t.effort_max; ptab[PT_EFFORT_MIN][i] = (float)t.effort_min;
     ptab[PT_KICK_RATE][i] = (float)t.kick_power_rate;
