@@ -323,3 +323,34 @@ def test_edge_inputs_parity():
     assert torch.equal(before, one.arena)
     one.reset(torch.ones(1, dtype=torch.uint8, device='cuda:0')); orc1.reset(np.ones(1, dtype=np.uint8))
     assert_state_same(one, orc1, 'full mask')
+
+
+@pytest.mark.parametrize('ws', ['0', '1'])
+@pytest.mark.parametrize('name', ['dqn-discrete16', 'turning4'])
+def test_short_rollouts_pipeline_fill_and_drain(name, ws, monkeypatch):
+    """Rollouts of 1, 2, 3 and 5 cycles (shorter than / equal to the depth of the three-stage pipeline of
+    the wave-specialised kernel), interleaved with per-step launches and with caller actions, odd N:
+    state, outputs and policy_step stay equal to the oracle's, launch after launch."""
+    monkeypatch.setenv('S2D_ROLLOUT_WS', ws)
+    kw = dict(CONFIGS[name]); kw['max_steps'] = 12
+    n = 197
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    rs = np.random.RandomState(11)
+    for rep, T in enumerate([1, 2, 3, 5, 1, 2, 3, 5, 4, 1]):
+        if rep % 3 == 2:                                   # caller actions
+            if kw.get('use_continuous_action', True):
+                a = rs.uniform(-1, 1, (T, n, 4 if kw.get('use_turning') else 1)).astype(np.float32)
+            else:
+                a = rs.randint(0, kw['action_space_size'], (T, n)).astype(np.int32)
+            out, ref = eng.rollout(T, torch.as_tensor(a, device='cuda:0')), orc.rollout(T, a)
+        else:
+            out, ref = eng.rollout(T), orc.rollout(T)
+        torch.cuda.synchronize()
+        for k in ('obs', 'action', 'reward', 'done', 'result'):
+            assert_same(out[k], ref[k], f'{name} T={T} rep={rep} {k}')
+        assert_state_same(eng, orc, f'{name} T={T} rep={rep}')
+        assert_same(eng.obs, orc.obs(), f'{name} T={T} rep={rep} last obs')
+        eng.step(None); orc.step(None)
+        assert_state_same(eng, orc, f'{name} step after T={T}')
+    assert int(eng.policy_step.min()) == int(eng.policy_step.max()) > 0
