@@ -70,7 +70,8 @@ def _vec(field, x, y, dist=0.0, angle=0.0):
 def encode_player(p):
     """p: dict with x,y,vx,vy,side,uniform_number,body_direction[,is_tackling,type_id]."""
     return (_vec(1, p['x'], p['y']) + _vec(4, p.get('vx', 0.0), p.get('vy', 0.0)) + _int(15, p.get('side', 0))
-            + _int(16, p.get('uniform_number', 0)) + _f32(19, p.get('body_direction', 0.0))
+            + _int(16, p.get('uniform_number', 0)) + _int(18, 1 if p.get('is_goalie') else 0)
+            + _f32(19, p.get('body_direction', 0.0))
             + _int(29, 1 if p.get('is_tackling') else 0) + _int(30, p.get('type_id', 0)))
 
 
@@ -114,7 +115,7 @@ def encode_state(wm):
 
 def encode_player_action(cmd, a=0.0, b=0.0):
     """PlayerAction bytes for the engine's command ISA: 'dash'(power,dir) 'turn'(dir) 'kick'(power,dir)
-    'tackle'(power_or_dir)."""
+    'tackle'(power_or_dir) 'catch'() 'move'(x,y)."""
     if cmd == 'dash':
         return _msg(1, _f32(1, a) + _f32(2, b))
     if cmd == 'turn':
@@ -123,6 +124,10 @@ def encode_player_action(cmd, a=0.0, b=0.0):
         return _msg(3, _f32(1, a) + _f32(2, b))
     if cmd == 'tackle':
         return _msg(4, _f32(1, a))
+    if cmd == 'catch':                     # Catch{} is an empty message: the oneof member must still be present
+        return _tag(5, 2) + _varint(0)
+    if cmd == 'move':
+        return _msg(6, _f32(1, a) + _f32(2, b))
     raise ValueError(cmd)
 
 
@@ -187,6 +192,10 @@ def decode_player_action(buf):
             return 'kick', float(vals.get(1, 0.0)), float(vals.get(2, 0.0))
         if field == 4:
             return 'tackle', float(vals.get(1, 0.0)), 0.0
+        if field == 5:                     # Catch{}: the engine's catch direction is 0 (straight ahead)
+            return 'catch', 0.0, 0.0
+        if field == 6:                     # Move{x, y}: decoded for completeness, not executed by the engine
+            return 'move', float(vals.get(1, 0.0)), float(vals.get(2, 0.0))
     return None, 0.0, 0.0
 
 
@@ -241,10 +250,11 @@ def match_state_bytes(engine, index, player):
                                                        engine.stamina_capacity, engine.tackle_cycles))
     left = player < 11
     mine, theirs = (range(0, 11), range(11, 22)) if left else (range(11, 22), range(0, 11))
+    types = list(engine.cfg.player_type_id)
 
     def pl(i):
         return dict(x=x[i], y=y[i], vx=vx[i], vy=vy[i], side=1 if i < 11 else 2, uniform_number=i % 11 + 1,
-                    body_direction=body[i], is_tackling=tk[i] > 0)
+                    body_direction=body[i], is_tackling=tk[i] > 0, is_goalie=i % 11 == 0, type_id=types[i])
     me = dict(pl(player), stamina=st[player], effort=ef[player], recovery=rc[player], stamina_capacity=cp[player])
     ball = dict(x=x[22], y=y[22], vx=vx[22], vy=vy[22], rel_x=x[22] - x[player], rel_y=y[22] - y[player])
     sl, sr = int(engine.score_left[index]), int(engine.score_right[index])

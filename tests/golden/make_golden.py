@@ -340,22 +340,28 @@ def gen_wire():
         for team, lst, side in ((wm.teammates, mates, 1), (wm.opponents, opps, 2)):
             for u in range(1, 1 + int(rs.randint(1, 4))):
                 d = dict(x=f32(rs.uniform(-50, 50)), y=f32(rs.uniform(-30, 30)), vx=f32(rs.uniform(-1, 1)), vy=f32(rs.uniform(-1, 1)),
-                         side=side, uniform_number=u, body_direction=f32(rs.uniform(-180, 180)), is_tackling=bool(u == 2))
+                         side=side, uniform_number=u, body_direction=f32(rs.uniform(-180, 180)), is_tackling=bool(u == 2),
+                         is_goalie=bool(u == 1), type_id=int(0 if u == 1 else (3 * u + k) % 18))
                 p = team.add()
                 p.position.x, p.position.y, p.velocity.x, p.velocity.y = d['x'], d['y'], d['vx'], d['vy']
                 p.side, p.uniform_number, p.body_direction, p.is_tackling = d['side'], d['uniform_number'], d['body_direction'], d['is_tackling']
+                p.is_goalie, p.type_id = d['is_goalie'], d['type_id']
                 lst.append(d)
         vals.update(self=me, ball=ball, teammates=mates, opponents=opps, our_team_score=vals['left_team_score'],
                     their_team_score=vals['right_team_score'], game_mode_side=2 if k % 2 else 1)
         out['states'].append({'fields': vals, 'hex': s.SerializeToString().hex()})
     for cmd, a, b in (('dash', 100.0, -22.5), ('dash', 55.5, 180.0), ('turn', 90.0, 0.0), ('turn', -12.25, 0.0),
-                      ('kick', 80.0, 45.0), ('tackle', -30.0, 0.0)):
+                      ('kick', 80.0, 45.0), ('tackle', -30.0, 0.0), ('catch', 0.0, 0.0), ('move', -10.5, 3.25)):
         if cmd == 'dash':
             m = pb2.PlayerAction(dash=pb2.Dash(power=a, relative_direction=b))
         elif cmd == 'turn':
             m = pb2.PlayerAction(turn=pb2.Turn(relative_direction=a))
         elif cmd == 'kick':
             m = pb2.PlayerAction(kick=pb2.Kick(power=a, relative_direction=b))
+        elif cmd == 'catch':
+            m = pb2.PlayerAction(catch=pb2.Catch())
+        elif cmd == 'move':
+            m = pb2.PlayerAction(move=pb2.Move(x=a, y=b))
         else:
             m = pb2.PlayerAction(tackle=pb2.Tackle(power_or_dir=a, foul=False))
         out['player_actions'].append({'cmd': cmd, 'a': a, 'b': b, 'hex': m.SerializeToString().hex(),
