@@ -285,25 +285,33 @@ S2D_DEV int judge_sq(const S2DHot& p, float px, float py, float d2, int step_num
   f |= (step_number > p.max_steps) ? S2D_FLAG_TIMEOUT : 0;
   return f;
 }
-// state_to_observation, reach_ball_env.py:87-111; returns the body->ball angle difference
-S2D_DEV float observe(const S2DHot& p, float px, float py, float body, float bx, float by, float bvx, float bvy,
-                      ObsOut& ob) {
+// state_to_observation, reach_ball_env.py:87-111, in two halves that share nothing (so two waves can
+// evaluate them side by side): the player half (o[0..3], returns the body->ball angle difference) and the
+// ball half (o[4..9]).
+S2D_DEV float observe_player(const S2DHot& p, float px, float py, float body, float bx, float by, float* o) {
   float dx = bx - px, dy = by - py;
-  float ball_speed = hypot2(bvx, bvy);                   // :91
-  float ball_direction = atan2_deg(bvy, bvx);            // :92
   float player_to_ball = atan2_deg(dy, dx);              // :95 / :123
   float rel = norm_deg(player_to_ball - body);           // :96 / :124
-  ob.o[0] = rel * 0.005555555555555556f;                 // :98-107  (x/180, x/52.5, x/34, x/3, x/360)
-  ob.o[1] = body * 0.005555555555555556f;
-  ob.o[2] = px * p.inv_half_l;
-  ob.o[3] = py * p.inv_half_w;
-  ob.o[4] = bx * p.inv_half_l;
-  ob.o[5] = by * p.inv_half_w;
-  ob.o[6] = ball_speed * 0.3333333333333333f;
-  ob.o[7] = ball_direction * 0.002777777777777778f;
-  ob.o[8] = bvx * 0.3333333333333333f;
-  ob.o[9] = bvy * 0.3333333333333333f;
+  o[0] = rel * 0.005555555555555556f;                    // :98-101  (x/180, x/52.5, x/34)
+  o[1] = body * 0.005555555555555556f;
+  o[2] = px * p.inv_half_l;
+  o[3] = py * p.inv_half_w;
   return rel;
+}
+S2D_DEV void observe_ball(const S2DHot& p, float bx, float by, float bvx, float bvy, float* o) {
+  float ball_speed = hypot2(bvx, bvy);                   // :91
+  float ball_direction = atan2_deg(bvy, bvx);            // :92
+  o[4] = bx * p.inv_half_l;                              // :102-107  (x/52.5, x/34, x/3, x/360)
+  o[5] = by * p.inv_half_w;
+  o[6] = ball_speed * 0.3333333333333333f;
+  o[7] = ball_direction * 0.002777777777777778f;
+  o[8] = bvx * 0.3333333333333333f;
+  o[9] = bvy * 0.3333333333333333f;
+}
+S2D_DEV float observe(const S2DHot& p, float px, float py, float body, float bx, float by, float bvx, float bvy,
+                      ObsOut& ob) {
+  observe_ball(p, bx, by, bvx, bvy, ob.o);
+  return observe_player(p, px, py, body, bx, by, ob.o);
 }
 // reward and label of check_trainer_observation, reach_ball_env.py:128-150
 S2D_DEV float reward_of(float prev_dist, float prev_angle, float dist, float rel, int flags, int& result) {

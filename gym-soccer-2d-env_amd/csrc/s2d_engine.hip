@@ -390,25 +390,31 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 }
 
 // ------------------------------------------------------------------------------------------
-// Wave-specialised rollout: a three-stage software pipeline through LDS.
+// Wave-specialised rollout: a software pipeline of four waves through LDS.
 //
-// At N = 65 536 the unified kernel leaves ONE wave per SIMD, and a lone wave issues one
-// instruction per ~4 cycles while the SIMD could take twice that (profiles/r01/instr_rate_gfx950.txt).
-// Here every group of 64 envs is a workgroup of three waves, each one stage of the cycle:
+// At N = 65 536 the unified kernel leaves ONE wave per SIMD: its ~560 instructions per cycle are a
+// single dependent stream (one instruction per ~4 clocks) plus LDS / store latencies, while the SIMD
+// could issue twice as fast (profiles/r01/instr_rate_gfx950.txt).  Here every group of 64 envs is a
+// workgroup of four waves, each one stage of the cycle:
 //   P-wave (policy):   action of step t (caller's, or Philox policy) -> decoded command, the
 //                      command-only half of the dash (clamps, direction rate), action record
 //   S-wave (simulate): command -> dash/turn -> integrate -> stamina -> done test -> reset
-//   O-wave (observe):  observation, reward, labels, LDS transposition, rollout stores
-// In iteration s the P-wave works on step s, the S-wave on step s-1, the O-wave on step s-2;
-// the hand-offs are double-buffered in LDS and ONE s_barrier per iteration separates them.  There
-// is no feedback edge: policy draws are keyed by policy_step (not by the cycle, which resets
-// advance), the S-wave evaluates the done conditions itself, the O-wave owns the reward carry.
-// The arithmetic is the same functions in the same order as in the unified kernel, so the
-// results are bit-identical.  Used for small batches; from ~4 waves per SIMD on the unified
-// kernel is issue-bound by itself and is kept.
+//   A-wave (agent):    player half of the observation (angle to the ball), distance, reward,
+//                      labels, reward / done / result stores, episode counters, reward carry
+//   B-wave (ball):     ball half of the observation (speed, direction), and the transposed
+//                      observation block of the PREVIOUS step streamed out of LDS
+// In iteration s the P-wave works on step s, the S-wave on step s-2 (it fetches the command of
+// step s-1 from LDS while it simulates, so that latency is never exposed), the A- and B-waves on
+// step s-3 (the B-wave also stores the observations of step s-4); the hand-offs are
+// double-buffered in LDS and ONE s_barrier per iteration separates them.  There is no feedback edge: policy
+// draws are keyed by policy_step (not by the cycle, which resets advance), the S-wave evaluates
+// the done conditions itself, the A-wave owns the reward carry.  The arithmetic is the same
+// functions in the same order as in the unified kernel, so the results are bit-identical.
+// Used for small batches; with more env groups per SIMD the unified kernel overlaps whole waves
+// instead and is kept.
 enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_FLAGS, WS_WORDS };
 enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_WORDS };
-static constexpr int kWsBlock = 3 * kWave;
+static constexpr int kWsBlock = 4 * kWave;
 
 template <int MODE, bool NOISE>
 __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
@@ -419,16 +425,15 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   __shared__ float act[2][WA_WORDS][kWave];                // decoded command of step t, double-buffered
   __shared__ float snap[2][WS_WORDS][kWave];               // post-cycle snapshot of step t, double-buffered
   __shared__ float post[2][WS_FLAGS][kWave];               // post-reset state of the envs that finished
-  __shared__ __attribute__((aligned(16))) float tile[kObsTile];
-  __shared__ PrepTile prep;
+  __shared__ __attribute__((aligned(16))) float tile[2][kObsTile];   // observation rows of step t, double-buffered
   const int lane = threadIdx.x & (kWave - 1);
-  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 observe
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 agent, 3 ball
   const int64_t wave_first = (int64_t)blockIdx.x * kWave;
   const int64_t i = wave_first + lane;
   const bool active = i < n;
   int64_t rows = n - wave_first; rows = rows > kWave ? kWave : rows;
   const int valid = (int)rows * S2D_OBS_DIM;
-  const int n_iter = n_steps + 2;
+  const int n_iter = n_steps + 4;
 
   if (role == 0) {
     // ------------------------------------------------------------------ P-wave
@@ -470,9 +475,6 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     }
   } else if (role == 1) {
     // ------------------------------------------------------------------ S-wave
-#ifdef S2D_WS_PRIO
-    __builtin_amdgcn_s_setprio(S2D_WS_PRIO);               // experiment: the simulate wave is the critical path
-#endif
     const S2DHot p = hot_in_vgprs(p_sgpr);
     Env e;
     uint32_t gl = 0, gh = 0;
@@ -484,25 +486,29 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
                    "v"(e.recovery), "v"(e.capacity), "v"(e.bx), "v"(e.by), "v"(e.bvx), "v"(e.bvy),
                    "v"(e.step_number), "v"(e.cycle));
     }
+    // the prepared sample of this env's next episode lives in registers here (VGPRs are plentiful in this
+    // wave), refilled for >= kRefillMin lanes at a time like the LDS tile of the unified kernel
     bool have_prep = false;
-    if (active && p.auto_reset) { prep_fill(p, rp, prep, lane, e, gl, gh); have_prep = true; }   // full wave
+    ResetSample nxt{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (active && p.auto_reset) { const S2DRare r = *rp; nxt = reset_sample(p, r, gl, gh, reset_key(e)); have_prep = true; }
+    int cmd_cur = S2D_CMD_DASH, cmd_nxt = S2D_CMD_DASH;
+    CmdPrep c_cur{0.0f, 0.0f, 0.0f}, c_nxt{0.0f, 0.0f, 0.0f};
     S2D_TICK_INIT(2);
     for (int s = 0; s < n_iter; ++s) {
-      if (s >= 1 && s <= n_steps) {                        // step s - 1
-        const int b = (s - 1) & 1;
+      if (s >= 1 && s <= n_steps && active) {              // command of step s - 1: used in the NEXT iteration
+        const int bn = (s - 1) & 1;
+        if (MODE == S2D_MODE_TURN4) cmd_nxt = __float_as_int(act[bn][WA_CMD][lane]);   // other modes always dash
+        c_nxt = CmdPrep{act[bn][WA_POWER][lane], act[bn][WA_DIR][lane], act[bn][WA_RATE][lane]};
+      }
+      if (s >= 2 && s <= n_steps + 1) {                    // step s - 2
+        const int b = s & 1;
         if (p.auto_reset && __popcll(__ballot(active && !have_prep)) >= kRefillMin) {   // batched refill
-          if (active && !have_prep) { prep_fill(p, rp, prep, lane, e, gl, gh); have_prep = true; }
+          if (active && !have_prep) { const S2DRare r = *rp; nxt = reset_sample(p, r, gl, gh, reset_key(e)); have_prep = true; }
         }
         if (active) {
-          // only the turning action space ever decodes to something other than a dash
-          const int cmd = MODE == S2D_MODE_TURN4 ? __float_as_int(act[b][WA_CMD][lane]) : (int)S2D_CMD_DASH;
-          const CmdPrep c{act[b][WA_POWER][lane], act[b][WA_DIR][lane], act[b][WA_RATE][lane]};
-#if S2D_PROFILE
-          asm volatile("" ::"v"(cmd), "v"(c.power), "v"(c.dir), "v"(c.dir_rate));
-          S2D_TICK(0);                                     // refill check + command read
-#endif
+          S2D_TICK(0);                                     // refill check
           e.step_number += 1;                              // reach_ball_env.py:55
-          const float d2 = sim_cycle<NOISE, true>(p, rp, e, gl, gh, cmd, c);
+          const float d2 = sim_cycle<NOISE, true>(p, rp, e, gl, gh, cmd_cur, c_cur);
 #if S2D_PROFILE
           asm volatile("" ::"v"(e.px), "v"(e.py), "v"(e.bx), "v"(e.by), "v"(e.stamina), "v"(e.effort), "v"(e.vx), "v"(e.vy));
           S2D_TICK(1);                                     // simulator cycle
@@ -512,9 +518,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           snap[b][WS_BX][lane] = e.bx; snap[b][WS_BY][lane] = e.by;
           snap[b][WS_BVX][lane] = e.bvx; snap[b][WS_BVY][lane] = e.bvy;
           snap[b][WS_FLAGS][lane] = __int_as_float(flags);
-          if (flags && p.auto_reset) {
-            if (!have_prep) prep_fill(p, rp, prep, lane, e, gl, gh);
-            reset_apply<NOISE>(p, rp, e, gl, gh, prep_take(prep, lane), p.recover_init);
+          if (flags && p.auto_reset) {                     // rare
+            if (!have_prep) { const S2DRare r = *rp; nxt = reset_sample(p, r, gl, gh, reset_key(e)); }   // episode shorter than the refill cadence
+            reset_apply<NOISE>(p, rp, e, gl, gh, nxt, p.recover_init);
             have_prep = false;
             post[b][WS_PX][lane] = e.px; post[b][WS_PY][lane] = e.py; post[b][WS_BODY][lane] = e.body;
             post[b][WS_BX][lane] = e.bx; post[b][WS_BY][lane] = e.by;
@@ -522,6 +528,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           }
         }
       }
+      cmd_cur = cmd_nxt; c_cur = c_nxt;
 #if S2D_PROFILE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       S2D_TICK(3);                                         // barrier
     }
     S2D_TICK_FLUSH(o.stats, lane);
-    if (active) {                                          // prev_dist / prev_angle belong to the O-wave
+    if (active) {                                          // prev_dist / prev_angle belong to the A-wave
       S[F_PX * stride + i] = e.px; S[F_PY * stride + i] = e.py;
       S[F_VX * stride + i] = e.vx; S[F_VY * stride + i] = e.vy;
       S[F_BODY * stride + i] = e.body;
@@ -541,60 +548,60 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       S[F_STEP * stride + i] = __int_as_float(e.step_number);
       S[F_CYCLE * stride + i] = __int_as_float(e.cycle);
     }
-  } else {
-    // ------------------------------------------------------------------ O-wave
-    const S2DHot p = hot_in_vgprs(p_sgpr);
+  } else if (role == 2) {
+    // ------------------------------------------------------------------ A-wave (player half, reward, labels)
+    const S2DHot& p = p_sgpr;
     float prev_dist = 0.0f, prev_angle = 0.0f;
     if (active) {
       prev_dist = S[F_PREV_DIST * stride + i]; prev_angle = S[F_PREV_ANGLE * stride + i];
       asm volatile("" ::"v"(prev_dist), "v"(prev_angle));
     }
-    ObsOut ob;
+    float oa[S2D_OBS_DIM];                                 // only oa[0..3] are produced here
     float reward = 0.0f; int res = 0, done = 0;
     unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
     int64_t row = 0;
     S2D_TICK_INIT(3);
     for (int s = 0; s < n_iter; ++s) {
-      if (s >= 2) {                                        // step s - 2
-        const int b = s & 1;
+      if (s >= 3 && s < n_steps + 3) {                     // step s - 3
+        const int b = (s - 1) & 1;
         res = 0;
         if (active) {
           float px = snap[b][WS_PX][lane], py = snap[b][WS_PY][lane], body = snap[b][WS_BODY][lane];
           float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
-          float bvx = snap[b][WS_BVX][lane], bvy = snap[b][WS_BVY][lane];
-          float dist = hypot2(bx - px, by - py);
           int flags = __float_as_int(snap[b][WS_FLAGS][lane]);
-          float rel = observe(p, px, py, body, bx, by, bvx, bvy, ob);
+          float dist = hypot2(bx - px, by - py);
+          float rel = observe_player(p, px, py, body, bx, by, oa);
           reward = reward_of(prev_dist, prev_angle, dist, rel, flags, res);
           prev_dist = dist; prev_angle = rel;
           done = flags ? 1 : 0;
 #if S2D_PROFILE
-          asm volatile("" ::"v"(reward), "v"(ob.o[0]), "v"(ob.o[6]), "v"(ob.o[7]), "v"(res));
-          S2D_TICK(0);                                     // snapshot read + observe + reward
+          asm volatile("" ::"v"(reward), "v"(oa[0]), "v"(res));
+          S2D_TICK(0);                                     // snapshot read + player half + reward
 #endif
-          if (flags && p.auto_reset) {           // terminal row, then the new episode's first obs
+          if (flags && p.auto_reset) {                     // rare: terminal row, then the new episode's first obs
 #pragma unroll
-            for (int k = 0; k < S2D_OBS_DIM; ++k) term_row[k] = ob.o[k];
+            for (int k = 0; k < 4; ++k) term_row[k] = oa[k];
             px = post[b][WS_PX][lane]; py = post[b][WS_PY][lane]; body = post[b][WS_BODY][lane];
             bx = post[b][WS_BX][lane]; by = post[b][WS_BY][lane];
-            bvx = post[b][WS_BVX][lane]; bvy = post[b][WS_BVY][lane];
-            prev_angle = observe(p, px, py, body, bx, by, bvx, bvy, ob);    // reach_ball_env.py:166 carry seeded
+            prev_angle = observe_player(p, px, py, body, bx, by, oa);      // reach_ball_env.py:166 carry seeded
             prev_dist = hypot2(bx - px, by - py);
           }
           if (ro.reward) ro.reward[row + i] = reward;
           if (ro.done) ro.done[row + i] = (uint8_t)done;
           if (ro.result) ro.result[row + i] = (uint8_t)res;
           cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
+          if (ro.obs) {                                    // this wave's four words of the row
+            float* t = &tile[b][lane * S2D_OBS_DIM];
+            t[0] = oa[0]; t[1] = oa[1]; t[2] = oa[2]; t[3] = oa[3];
+          }
         }
-        S2D_TICK(1);                                       // reset branch + reward/done/result stores
-        if (ro.obs) store_obs_tile(tile, ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
         row += n;
       }
 #if S2D_PROFILE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-      S2D_TICK(2);                                         // observation tile
+      S2D_TICK(1);                                         // reset branch + stores + tile words
       __syncthreads();
       S2D_TICK(3);                                         // barrier
     }
@@ -602,8 +609,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     if (active) {
       S[F_PREV_DIST * stride + i] = prev_dist; S[F_PREV_ANGLE * stride + i] = prev_angle;
       o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o.obs[i * S2D_OBS_DIM + k] = oa[k];      // last observation, player half
     }
-    store_obs_tile(tile, ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, valid);
     if (!active) { cnt1 = cnt2 = cnt3 = 0; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -616,6 +624,39 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     }
     if (blockIdx.x == 0 && lane == 0)
       atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n * (unsigned long long)n_steps);
+  } else {
+    // ------------------------------------------------------------------ B-wave (ball half, observation stream)
+    const S2DHot& p = p_sgpr;
+    float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here
+    float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
+    for (int s = 0; s < n_iter; ++s) {
+      if (s >= 4 && ro.obs)                                // observation block of step s - 4, completed in iteration s - 1
+        tile_flush(tile[s & 1], lane, ro.obs + ((int64_t)(s - 4) * n + wave_first) * S2D_OBS_DIM, valid);
+      if (s >= 3 && s < n_steps + 3 && active) {           // step s - 3
+        const int b = (s - 1) & 1;
+        float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
+        float bvx = snap[b][WS_BVX][lane], bvy = snap[b][WS_BVY][lane];
+        int flags = __float_as_int(snap[b][WS_FLAGS][lane]);
+        observe_ball(p, bx, by, bvx, bvy, ob6);
+        if (flags && p.auto_reset) {                       // rare: terminal row, then the new episode's first obs
+#pragma unroll
+          for (int k = 4; k < S2D_OBS_DIM; ++k) term_row[k] = ob6[k];
+          bx = post[b][WS_BX][lane]; by = post[b][WS_BY][lane];
+          bvx = post[b][WS_BVX][lane]; bvy = post[b][WS_BVY][lane];
+          observe_ball(p, bx, by, bvx, bvy, ob6);
+        }
+        if (ro.obs) {
+          float* t = &tile[b][lane * S2D_OBS_DIM];
+#pragma unroll
+          for (int k = 4; k < S2D_OBS_DIM; ++k) t[k] = ob6[k];
+        }
+      }
+      __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+      for (int k = 4; k < S2D_OBS_DIM; ++k) o.obs[i * S2D_OBS_DIM + k] = ob6[k];   // last observation, ball half
+    }
   }
 }
 
@@ -1015,7 +1056,7 @@ S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int a
       {s2d_reach_rollout_ws_kernel<S2D_MODE_DISCRETE, false>, s2d_reach_rollout_ws_kernel<S2D_MODE_DISCRETE, true>},
       {s2d_reach_rollout_ws_kernel<S2D_MODE_CONT1, false>, s2d_reach_rollout_ws_kernel<S2D_MODE_CONT1, true>},
       {s2d_reach_rollout_ws_kernel<S2D_MODE_TURN4, false>, s2d_reach_rollout_ws_kernel<S2D_MODE_TURN4, true>}};
-  // small batches: three waves per env group (policy | simulate | observe) keep every SIMD at >= 3 waves
+  // small batches: four waves per env group (policy | simulate | agent | ball)
   const bool ws = h->rollout_ws < 0 ? (h->n <= kWsMaxEnvs) : (h->rollout_ws != 0);
   if (ws) {
     hipLaunchKernelGGL(table_ws[h->mode][h->noise ? 1 : 0], dim3((unsigned)((h->n + kWave - 1) / kWave)),

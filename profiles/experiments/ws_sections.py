@@ -18,7 +18,7 @@ s = eng.stats.cpu().tolist()
 ws = (N // 64) * T * L
 names = {'1': ['policy+decode', '-', '-', 'barrier'],
          '2': ['refill check + command read', 'simulator cycle', 'done test+snapshot+reset', 'barrier'],
-         '3': ['read+observe+reward', 'reset+small stores', 'obs tile', 'barrier']}[os.environ.get('S2D_SECTIONS', '2')]
+         '3': ['read+player half+reward', 'reset+stores+tile words', '-', 'barrier']}[os.environ.get('S2D_SECTIONS', '2')]
 tot = sum(s[4:8])
 print(eng.kernel_name(), 'launch us', e0.elapsed_time(e1) * 1e3 / L, 'per cycle ns', e0.elapsed_time(e1) * 1e6 / L / T)
 for nm, v in zip(names, s[4:8]):
