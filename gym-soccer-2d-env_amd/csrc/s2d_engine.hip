@@ -350,17 +350,20 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
   U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
   bool have_prep = false;
   if (active && p.auto_reset) { prep_fill(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }   // full wave
+  int n_missing = 0;                                       // wave-uniform: lanes whose prepared sample is used up
   int64_t row = 0;
   for (int t = 0; t < n_steps; ++t, row += n) {
     res = 0;
-    if (p.auto_reset && __popcll(__ballot(active && !have_prep)) >= kRefillMin) {   // batched refill
+    if (n_missing >= kRefillMin) {                         // batched refill (wave-uniform counter: no ballot per cycle)
       if (active && !have_prep) { prep_fill(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }
+      n_missing = 0;
     }
     if (active) {
       const uint32_t k = k0 + (uint32_t)t;
       CmdPrep c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, t == 0 || (k & 3u) == 0u, quad, squad,
                                ro.action, cmd, dir);
       step_env<NOISE>(p, rp, e, gl, gh, cmd, c, ob, reward, done, res, term_row, &prep[wv], lane, have_prep);
+      if (p.auto_reset) n_missing += __popcll(__ballot(done != 0));   // samples consumed by this cycle's resets
       if (ro.reward) ro.reward[row + i] = reward;
       if (ro.done) ro.done[row + i] = (uint8_t)done;
       if (ro.result) ro.result[row + i] = (uint8_t)res;
@@ -493,6 +496,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     if (active && p.auto_reset) { const S2DRare r = *rp; nxt = reset_sample(p, r, gl, gh, reset_key(e)); have_prep = true; }
     int cmd_cur = S2D_CMD_DASH, cmd_nxt = S2D_CMD_DASH;
     CmdPrep c_cur{0.0f, 0.0f, 0.0f}, c_nxt{0.0f, 0.0f, 0.0f};
+    int n_missing = 0;                                     // wave-uniform: active lanes without a prepared sample
     S2D_TICK_INIT(2);
     for (int s = 0; s < n_iter; ++s) {
       if (s >= 1 && s <= n_steps && active) {              // command of step s - 1: used in the NEXT iteration
@@ -502,8 +506,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       }
       if (s >= 2 && s <= n_steps + 1) {                    // step s - 2
         const int b = s & 1;
-        if (p.auto_reset && __popcll(__ballot(active && !have_prep)) >= kRefillMin) {   // batched refill
+        if (n_missing >= kRefillMin) {                     // batched refill (scalar counter: no ballot in the hot path)
           if (active && !have_prep) { const S2DRare r = *rp; nxt = reset_sample(p, r, gl, gh, reset_key(e)); have_prep = true; }
+          n_missing = 0;
         }
         if (active) {
           S2D_TICK(0);                                     // refill check
@@ -522,6 +527,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
             if (!have_prep) { const S2DRare r = *rp; nxt = reset_sample(p, r, gl, gh, reset_key(e)); }   // episode shorter than the refill cadence
             reset_apply<NOISE>(p, rp, e, gl, gh, nxt, p.recover_init);
             have_prep = false;
+            n_missing += __popcll(__ballot(true));         // lanes of this wave that consumed their sample now
             post[b][WS_PX][lane] = e.px; post[b][WS_PY][lane] = e.py; post[b][WS_BODY][lane] = e.body;
             post[b][WS_BX][lane] = e.bx; post[b][WS_BY][lane] = e.by;
             post[b][WS_BVX][lane] = e.bvx; post[b][WS_BVY][lane] = e.bvy;
