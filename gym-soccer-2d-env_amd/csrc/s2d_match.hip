@@ -47,7 +47,7 @@ enum { MF_X, MF_Y, MF_VX, MF_VY, MF_BODY, MF_STAMINA, MF_EFFORT, MF_RECOVERY, MF
 enum { PT_SPEED_MAX, PT_SPEED_MAX2, PT_STAMINA_INC, PT_DECAY, PT_INERTIA, PT_DASH_RATE, PT_SIZE, PT_INV_KICK_MARGIN,
        PT_KICKABLE_AREA2, PT_KICK_RAND, PT_EXTRA_STAMINA, PT_EFFORT_MAX, PT_EFFORT_MIN, PT_KICK_RATE, PT_CATCH_LEN, PT_WORDS };
 enum { ME_CYCLE, ME_MODE, ME_MODE_SIDE, ME_SCORE_L, ME_SCORE_R, ME_LAST_TOUCH, ME_TIMER, ME_OFFSIDE, ME_REWARD, ME_NEAREST_L,
-       ME_NEAREST_R, ME_ENV_PLANES };
+       ME_NEAREST_R, ME_HOLDER, ME_MOVES, ME_ENV_PLANES };
 
 struct MParams {   // every field rounded once on the host (double -> float); per-PlayerType values live in the PT table
   float half_l, half_w, ball_size, player_rand, ball_rand;
@@ -64,14 +64,15 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
   float tackle_reach2;   // beyond this squared distance a tackle fails for certain (see m_tackle)
   float goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
   float catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
-  int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle;
+  int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle, goalie_max_moves;
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
 };
 typedef float PTab[kHalf];   // one row of the per-slot table
 
 struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int tackle, catch_ban; };
-struct MGame { int cycle, mode, mode_side, score_l, score_r, last_touch, timer, offside; float reward; int done, nearest_l, nearest_r; };
+struct MGame { int cycle, mode, mode_side, score_l, score_r, last_touch, timer, offside; float reward; int done, nearest_l, nearest_r;
+               int holder, moves; /* 1 + index of the goalie holding a caught ball (0 = nobody), his remaining moves */ };
 
 __constant__ float kFormX[11] = {-50.0f, -35.0f, -35.0f, -35.0f, -35.0f, -20.0f, -20.0f, -20.0f, -20.0f, -10.5f, -10.5f};
 __constant__ float kFormY[11] = {0.0f, -20.0f, -7.0f, 7.0f, 20.0f, -22.0f, -8.0f, 8.0f, 22.0f, -6.0f, 6.0f};
@@ -104,7 +105,7 @@ S2D_DEV void m_recover(const MParams& p, float effort_max, MObj& o, bool with_ca
 }
 S2D_DEV void m_reset(const MParams& p, float effort_max, MObj& o, MGame& g, int l) {
   o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  g = MGame{0, S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0, 0, 0, 0.0f, 0, 10, 20};
+  g = MGame{0, S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0, 0, 0, 0.0f, 0, 10, 20, 0, 0};
   if (l < NP) m_recover(p, effort_max, o, true);
   m_place(o, l, SIDE_LEFT);
 }
@@ -259,7 +260,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   U4 nz{0, 0, 0, 0}, nk{0, 0, 0, 0};
   if (p.noise) { nz = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, (uint32_t)l); nk = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, 32u + (uint32_t)l); }
   const bool may_touch = !is_setplay(mode0) || side_of(l) == side0;
-  bool caught = false;
+  bool caught = false, hold_moved = false;
   if (cmd == S2D_MCMD_DASH) m_dash(p, pt, l, o, a, bb, ax, ay);
   else if (cmd == S2D_MCMD_TURN) m_turn(p, pt[PT_INERTIA][l], o, a, rnd_u01(nz.z));
   else if (cmd == S2D_MCMD_CATCH) {
@@ -269,6 +270,17 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
       if (p.catch_probability < 1.0f) u = rnd_u01(m_draw(p, gl, gh, cyc, S2D_ST_CATCH, (uint32_t)l).x);
       o.catch_ban = p.catch_ban_cycle + 1;
       caught = m_catch(p, pt[PT_CATCH_LEN][l], o, bx0, by0, a, u);
+    }
+  } else if (cmd == S2D_MCMD_MOVE) {
+    // Move(x, y) in the team's own frame (right team mirrored): before a kick-off anywhere in the own half;
+    // while holding a caught ball, goalie_max_moves times inside the own penalty area
+    const float sgn = side_of(l) == SIDE_LEFT ? 1.0f : -1.0f;
+    const bool holds = mode0 == S2D_GM_FREE_KICK && g.holder == l + 1 && g.moves > 0;
+    if (mode0 == S2D_GM_KICK_OFF || holds) {
+      float tx = clampf(a, -p.half_l, holds ? -p.pen_x : 0.0f);
+      float ty = holds ? clampf(bb, -p.pen_half_w, p.pen_half_w) : clampf(bb, -p.half_w, p.half_w);
+      o.x = sgn * tx; o.y = sgn * ty; o.vx = 0.0f; o.vy = 0.0f;
+      hold_moved = holds;
     }
   } else if (cmd == S2D_MCMD_KICK) {
     bool ok = m_kick(p, pt, l, o, bx0, by0, bvx0, bvy0, a, bb, rnd_u01(nk.x), rnd_u01(nk.y), kx, ky);
@@ -297,7 +309,11 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   // a successful catch wins the cycle: every kick / tackle impulse of this cycle is dropped
   const uint32_t cmask = hballot(caught, half) & ((1u << S2D_MATCH_GOALIE_LEFT) | (1u << S2D_MATCH_GOALIE_RIGHT));
   const int caught_by = cmask ? __ffs((int)cmask) - 1 : -1;
-  if (caught_by >= 0) { kicked = false; kx = 0.0f; ky = 0.0f; if (l == caught_by) cnt.kicks++; }
+  // ... and so does a move of the goalie who holds the ball (the holder is a goalie: bits 0 / 11)
+  const uint32_t hmask = hballot(hold_moved, half) & ((1u << S2D_MATCH_GOALIE_LEFT) | (1u << S2D_MATCH_GOALIE_RIGHT));
+  const int hold_move = hmask ? __ffs((int)hmask) - 1 : -1;
+  if (caught_by >= 0 && l == caught_by) cnt.kicks++;
+  if (caught_by >= 0 || hold_move >= 0) { kicked = false; kx = 0.0f; ky = 0.0f; }
   // ---- 2. ball: impulses summed in player order
   const uint32_t kmask = hballot(kicked, half) & 0x3FFFFFu;
   const bool any_kick = kmask != 0u;
@@ -315,6 +331,13 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   if (caught_by >= 0) {                                   // held: the ball rests where it was caught
     g.last_touch = side_of(caught_by);
     if (is_ball) { o.vx = 0.0f; o.vy = 0.0f; }
+  } else if (hold_move >= 0) {                            // the holding goalie moved: the ball goes with him, in front of his body
+    const float gx = hbcast(o.x, hold_move), gy = hbcast(o.y, hold_move), gb = hbcast(o.body, hold_move);
+    const float r = pt[PT_SIZE][hold_move] + p.ball_size + 0.1f;   // clear of the collision radius, inside the kickable area
+    float sn, cs;
+    sincos_deg(gb, sn, cs);
+    if (is_ball) { o.x = gx + r * cs; o.y = gy + r * sn; o.vx = 0.0f; o.vy = 0.0f; }
+    g.moves -= 1;
   } else if (is_ball && ball_live) {
     if (any_kick) {
       float a2 = sq2(bax, bay);
@@ -434,6 +457,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
         // inside the own penalty area: free kick for the goalie's side; outside: catch fault
         place_ball = true; pbx = bx; pby = by;
         g.mode = S2D_GM_FREE_KICK; g.mode_side = in_area ? gs : other_side(gs); g.timer = 0; g.offside = 0;
+        if (in_area) { g.holder = caught_by + 1; g.moves = p.goalie_max_moves; }
       } else if (bx > p.half_l && fabsf(by) < p.goal_half_width) {
         g.score_l += 1; g.reward = 1.0f; if (is_ball) cnt.goals_l++;
         restart_form = true; form_side = SIDE_RIGHT;
@@ -480,6 +504,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
       recover_half = true; restart_form = true; form_side = ks; place_ball = false;
       g.mode = S2D_GM_KICK_OFF; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
     }
+    if (g.mode != S2D_GM_FREE_KICK) { g.holder = 0; g.moves = 0; }   // nobody holds the ball any more
   }
   // resolve the offside spot (uniform shuffle, then apply)
   {
@@ -556,6 +581,7 @@ S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g) {
   g.score_r = q.env[ME_SCORE_R * q.env_stride + e]; g.last_touch = q.env[ME_LAST_TOUCH * q.env_stride + e];
   g.timer = q.env[ME_TIMER * q.env_stride + e]; g.offside = q.env[ME_OFFSIDE * q.env_stride + e];
   g.reward = 0.0f; g.done = 0; g.nearest_l = q.env[ME_NEAREST_L * q.env_stride + e]; g.nearest_r = q.env[ME_NEAREST_R * q.env_stride + e];
+  g.holder = q.env[ME_HOLDER * q.env_stride + e]; g.moves = q.env[ME_MOVES * q.env_stride + e];
 }
 S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGame& g) {
   if (l < SLOTS) {
@@ -574,6 +600,7 @@ S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGam
     q.env[ME_SCORE_R * q.env_stride + e] = g.score_r; q.env[ME_LAST_TOUCH * q.env_stride + e] = g.last_touch;
     q.env[ME_TIMER * q.env_stride + e] = g.timer; q.env[ME_OFFSIDE * q.env_stride + e] = g.offside;
     q.env[ME_NEAREST_L * q.env_stride + e] = g.nearest_l; q.env[ME_NEAREST_R * q.env_stride + e] = g.nearest_r;
+    q.env[ME_HOLDER * q.env_stride + e] = g.holder; q.env[ME_MOVES * q.env_stride + e] = g.moves;
     q.reward[e] = g.reward; q.done[e] = (uint8_t)g.done;
   }
 }
@@ -820,6 +847,7 @@ S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
   m.tackle_cycles = 10; m.half_time_cycles = 3000; m.nr_normal_halfs = 2; m.drop_ball_time = 100; m.use_offside = 1;
   m.catch_ban_cycle = 5; m.catchable_area_l = 1.2; m.catch_area_w = 1.0; m.catch_probability = 1.0;
   m.max_catch_angle = 90.0; m.min_catch_angle = -90.0; m.penalty_area_length = 16.5; m.penalty_area_half_width = 20.16;
+  m.goalie_max_moves = 2;
   c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
   for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) c->player_types[t] = m_default_type(c->sp, m);   // homogeneous
 }
@@ -834,6 +862,7 @@ S2D_API int s2d_match_validate_config(const S2DMatchConfig* c) {
   if (c->mp.half_time_cycles < 1 || c->mp.nr_normal_halfs < 1) return mfail(S2D_EINVAL, "half_time_cycles and nr_normal_halfs must be >= 1");
   if (c->mp.tackle_cycles < 0 || c->mp.drop_ball_time < 0) return mfail(S2D_EINVAL, "tackle_cycles / drop_ball_time must be >= 0");
   if (c->env_id_offset < 0) return mfail(S2D_EINVAL, "env_id_offset must be >= 0");
+  if (c->mp.goalie_max_moves < 0) return mfail(S2D_EINVAL, "goalie_max_moves must be >= 0");
   if (c->mp.catch_ban_cycle < 0 || !(c->mp.catch_area_w > 0) || !(c->mp.catchable_area_l > 0))
     return mfail(S2D_EINVAL, "catch_ban_cycle must be >= 0, catch_area_w and catchable_area_l > 0");
   for (int i = 0; i < S2D_MATCH_PLAYERS; ++i)
@@ -887,7 +916,7 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   p.pen_x = (float)(s.pitch_half_length - m.penalty_area_length); p.pen_half_w = (float)m.penalty_area_half_width;
   p.tackle_cycles = m.tackle_cycles; p.half_time_cycles = m.half_time_cycles;
   p.nr_normal_halfs = m.nr_normal_halfs; p.drop_ball_time = m.drop_ball_time; p.use_offside = m.use_offside;
-  p.catch_ban_cycle = m.catch_ban_cycle;
+  p.catch_ban_cycle = m.catch_ban_cycle; p.goalie_max_moves = m.goalie_max_moves;
   p.auto_reset = c.auto_reset; p.noise = c.noise;
   p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
   p.gid_lo = (uint32_t)(uint64_t)c.env_id_offset; p.gid_hi = (uint32_t)((uint64_t)c.env_id_offset >> 32);
@@ -975,6 +1004,7 @@ S2D_API int s2d_match_create(const S2DMatchConfig* cfg, int64_t n_envs, int devi
   b.cycle = env + ME_CYCLE * es; b.mode = env + ME_MODE * es; b.mode_side = env + ME_MODE_SIDE * es;
   b.score_left = env + ME_SCORE_L * es; b.score_right = env + ME_SCORE_R * es; b.last_touch_side = env + ME_LAST_TOUCH * es;
   b.setplay_timer = env + ME_TIMER * es; b.offside_mask = env + ME_OFFSIDE * es;
+  b.ball_holder = env + ME_HOLDER * es; b.goalie_moves = env + ME_MOVES * es;
   b.reward_left = reinterpret_cast<float*>(h->arena + L.reward);
   b.done = reinterpret_cast<uint8_t*>(h->arena + L.done);
   b.nearest_left = env + ME_NEAREST_L * es; b.nearest_right = env + ME_NEAREST_R * es;
@@ -1015,9 +1045,10 @@ S2D_API int s2d_match_buffer_offsets(S2DMatchHandle h, int64_t* offsets, int n_o
   const S2DMatchBuffers& b = h->buf;
   const void* ptrs[] = {b.x, b.y, b.vx, b.vy, b.body, b.stamina, b.effort, b.recovery, b.stamina_capacity, b.tackle_cycles,
                         b.catch_ban, b.cycle, b.mode, b.mode_side, b.score_left, b.score_right, b.last_touch_side, b.setplay_timer,
-                        b.offside_mask, b.reward_left, b.done, b.nearest_left, b.nearest_right, b.stats};
+                        b.offside_mask, b.ball_holder, b.goalie_moves, b.reward_left, b.done, b.nearest_left, b.nearest_right,
+                        b.stats};
   const int count = 1 + (int)(sizeof ptrs / sizeof ptrs[0]);
-  if (n_offsets < count) return mfail(S2D_EINVAL, "offsets array too small (need 25)");
+  if (n_offsets < count) return mfail(S2D_EINVAL, "offsets array too small (need 27)");
   offsets[0] = (int64_t)h->arena_bytes;
   for (int k = 1; k < count; ++k) offsets[k] = (int64_t)(static_cast<const char*>(ptrs[k - 1]) - h->arena);
   return S2D_OK;

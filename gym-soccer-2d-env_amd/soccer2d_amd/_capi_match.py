@@ -4,7 +4,7 @@ import ctypes as C
 from . import _capi
 
 MATCH_PLAYERS, MATCH_SLOTS, MATCH_BALL, MATCH_OBJ_WORDS = 22, 24, 22, 5
-MCMD_NONE, MCMD_DASH, MCMD_TURN, MCMD_KICK, MCMD_TACKLE, MCMD_CATCH = 0, 1, 2, 3, 4, 5
+MCMD_NONE, MCMD_DASH, MCMD_TURN, MCMD_KICK, MCMD_TACKLE, MCMD_CATCH, MCMD_MOVE = 0, 1, 2, 3, 4, 5, 6
 MATCH_PLAYER_TYPES, GOALIE_LEFT, GOALIE_RIGHT = 18, 0, 11
 GM_TIME_OVER, GM_PLAY_ON, GM_KICK_OFF, GM_KICK_IN, GM_FREE_KICK, GM_CORNER_KICK, GM_GOAL_KICK, GM_OFF_SIDE = 1, 2, 3, 4, 5, 6, 7, 9
 GM_NAMES = {1: 'TimeOver', 2: 'PlayOn', 3: 'KickOff_', 4: 'KickIn_', 5: 'FreeKick_', 6: 'CornerKick_', 7: 'GoalKick_', 9: 'OffSide_'}
@@ -18,7 +18,8 @@ class S2DMatchParams(C.Structure):
         'goal_width', 'offside_active_area_size', 'free_kick_distance')] + [(n, C.c_int32) for n in (
             'tackle_cycles', 'half_time_cycles', 'nr_normal_halfs', 'drop_ball_time', 'use_offside', 'catch_ban_cycle')] + [
                 (n, C.c_double) for n in ('catchable_area_l', 'catch_area_w', 'catch_probability', 'max_catch_angle',
-                                          'min_catch_angle', 'penalty_area_length', 'penalty_area_half_width')]
+                                          'min_catch_angle', 'penalty_area_length', 'penalty_area_half_width')] + [
+                    ('goalie_max_moves', C.c_int32), ('reserved1', C.c_int32)]
 
 
 PLAYER_TYPE_FIELDS = ('player_speed_max', 'stamina_inc_max', 'player_decay', 'inertia_moment', 'dash_power_rate',
@@ -56,7 +57,7 @@ MATCH_BUFFER_FIELDS = tuple(
     [(n, _F, 'float32', (MATCH_SLOTS,)) for n in ('x', 'y', 'vx', 'vy', 'body', 'stamina', 'effort', 'recovery', 'stamina_capacity')]
     + [('tackle_cycles', _I, 'int32', (MATCH_SLOTS,)), ('catch_ban', _I, 'int32', (MATCH_SLOTS,))]
     + [(n, _I, 'int32', ()) for n in ('cycle', 'mode', 'mode_side', 'score_left', 'score_right', 'last_touch_side',
-                                      'setplay_timer', 'offside_mask')]
+                                      'setplay_timer', 'offside_mask', 'ball_holder', 'goalie_moves')]
     + [('reward_left', _F, 'float32', ()), ('done', _U8, 'uint8', ()),
        ('nearest_left', _I, 'int32', ()), ('nearest_right', _I, 'int32', ()),
        ('stats', C.POINTER(C.c_ulonglong), 'int64', None)])

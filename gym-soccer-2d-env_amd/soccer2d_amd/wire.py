@@ -194,7 +194,7 @@ def decode_player_action(buf):
             return 'tackle', float(vals.get(1, 0.0)), 0.0
         if field == 5:                     # Catch{}: the engine's catch direction is 0 (straight ahead)
             return 'catch', 0.0, 0.0
-        if field == 6:                     # Move{x, y}: decoded for completeness, not executed by the engine
+        if field == 6:                     # Move{x, y}: team-frame coordinates (S2D_MCMD_MOVE)
             return 'move', float(vals.get(1, 0.0)), float(vals.get(2, 0.0))
     return None, 0.0, 0.0
 

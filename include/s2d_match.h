@@ -31,9 +31,10 @@ extern "C" {
 #define S2D_MATCH_GOALIE_LEFT 0   /* the goalie is the first player of each team */
 #define S2D_MATCH_GOALIE_RIGHT 11
 
-/* body commands, PlayerAction oneof members idl/service.proto:380-406, 1291-1298 (move: later) */
+/* body commands = the PlayerAction oneof members 1..6 (idl/service.proto:380-411, 1291-1298).  TurnNeck and
+ * ChangeView only steer the vision model, which a full-state engine does not have: send S2D_MCMD_NONE. */
 enum { S2D_MCMD_NONE = 0, S2D_MCMD_DASH = 1, S2D_MCMD_TURN = 2, S2D_MCMD_KICK = 3, S2D_MCMD_TACKLE = 4,
-       S2D_MCMD_CATCH = 5 };
+       S2D_MCMD_CATCH = 5, S2D_MCMD_MOVE = 6 };
 /* GameModeType values used (idl/service.proto:267-301); the taking side is in mode_side */
 enum {
   S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4, S2D_GM_FREE_KICK = 5,
@@ -53,6 +54,7 @@ typedef struct S2DMatchParams {
    * PlayerType.catchable_area_l_stretch long, catch_area_w wide, rooted at the goalie */
   double catchable_area_l, catch_area_w, catch_probability, max_catch_angle, min_catch_angle;  /* 1.2 1 1 90 -90 */
   double penalty_area_length, penalty_area_half_width;                             /* 16.5 20.16 */
+  int32_t goalie_max_moves, reserved1;    /* 2: Move commands a goalie may issue while he holds a caught ball */
 } S2DMatchParams;
 
 /* PlayerType (idl/service.proto:1697-1732): the members that enter the dynamics.  Type 0 is the
@@ -102,6 +104,7 @@ typedef struct S2DMatchBuffers {
   int32_t *catch_ban;                                 /* >0: goalie may not catch (catch_ban_cycle after every attempt) */
   int32_t *cycle, *mode, *mode_side, *score_left, *score_right;
   int32_t *last_touch_side, *setplay_timer, *offside_mask;     /* bit i = player i flagged */
+  int32_t *ball_holder, *goalie_moves;  /* 1 + index of the goalie holding a caught ball (0 = nobody), his remaining moves */
   float *reward_left;      /* [N] +1 left goal, -1 right goal this cycle */
   uint8_t *done;           /* [N] 1 when the match reached TimeOver this cycle */
   int32_t *nearest_left, *nearest_right;              /* [N] index of the player closest to the ball, per team */
@@ -136,7 +139,9 @@ int s2d_match_buffer_offsets(S2DMatchHandle h, int64_t *offsets, int n_offsets);
 /* kick-off formation, full stamina, score 0-0, cycle 0, KickOff for the left side */
 int s2d_match_reset(S2DMatchHandle h, const uint8_t *mask_dev, void *stream);
 /* actions_dev: float[N][22][3] = {command, a, b}: Dash(power=a, dir=b) Turn(moment=a)
- * Kick(power=a, dir=b) Tackle(dir=a) Catch(dir=a, goalies only); NULL = uniform random policy drawn in-kernel */
+ * Kick(power=a, dir=b) Tackle(dir=a) Catch(dir=a, goalies only) Move(x=a, y=b in the team's own frame: the
+ * right team's coordinates are mirrored; legal before a kick-off into the own half, and for a goalie
+ * holding a caught ball inside his penalty area); NULL = uniform random policy drawn in-kernel */
 int s2d_match_step(S2DMatchHandle h, const float *actions_dev, void *stream);
 int s2d_match_rollout(S2DMatchHandle h, int n_steps, const float *actions_dev /* [T][N][22][3] or NULL */,
                       const S2DMatchRollout *out, void *stream);

@@ -37,7 +37,7 @@ typedef struct MP {
   REAL kick_power_rate, kickable_area, kickable_margin, inv_kickable_margin, kick_rand, max_power, min_power, inv_max_power;
   REAL tackle_dist, tackle_back_dist, tackle_width, tackle_power_rate, max_tackle_power, max_back_tackle_power;
   REAL goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
-  int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle;
+  int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle, goalie_max_moves;
   REAL catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
   /* heterogeneous players: the parameters of every player slot's PlayerType (idl/service.proto:1697-1732) */
@@ -88,7 +88,7 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   p->inv_speed_decay = (REAL)(1.0 / (s->ball_speed_max * s->ball_decay));
   p->tackle_cycles = m->tackle_cycles; p->half_time_cycles = m->half_time_cycles;
   p->nr_normal_halfs = m->nr_normal_halfs; p->drop_ball_time = m->drop_ball_time; p->use_offside = m->use_offside;
-  p->catch_ban_cycle = m->catch_ban_cycle;
+  p->catch_ban_cycle = m->catch_ban_cycle; p->goalie_max_moves = m->goalie_max_moves;
   p->catch_half_w = (REAL)(m->catch_area_w * 0.5); p->catch_probability = (REAL)m->catch_probability;
   p->max_catch_angle = (REAL)m->max_catch_angle; p->min_catch_angle = (REAL)m->min_catch_angle;
   p->pen_x = (REAL)(s->pitch_half_length - m->penalty_area_length); p->pen_half_w = (REAL)m->penalty_area_half_width;
@@ -115,6 +115,7 @@ typedef struct Obj { REAL x, y, vx, vy, body, stamina, effort, recovery, capacit
 typedef struct Match {
   Obj o[NOBJ];
   int32_t cycle, mode, mode_side, score_left, score_right, last_touch_side, setplay_timer, offside_mask;
+  int32_t ball_holder, goalie_moves;    /* 1 + index of the goalie holding a caught ball (0 = nobody), remaining moves */
   REAL reward_left; uint8_t done; int32_t nearest_left, nearest_right;
 } Match;
 
@@ -291,7 +292,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   /* 1. commands */
   REAL ax[NP], ay[NP], kx[NP], ky[NP];
   int kicked[NP];
-  int caught_by = -1;
+  int caught_by = -1, hold_move = -1;
   uint32_t nzb[4] = {0, 0, 0, 0};
   if (p->noise) draw(p->seed, gid, cyc, ST_NOISE, BALL, nzb);
   for (int i = 0; i < NP; ++i) {
@@ -313,6 +314,17 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
         if (p->catch_probability < R(1.0)) { uint32_t w[4]; draw(p->seed, gid, cyc, ST_CATCH, (uint32_t)i, w); u = rnd_u01(w[0]); }
         o->catch_ban = p->catch_ban_cycle + 1;
         if (m_catch(p, t, o, b, a, u) && caught_by < 0) caught_by = i;
+      }
+    } else if (cmd == S2D_MCMD_MOVE) {
+      /* Move(x, y) in the team's own frame (right team mirrored): before a kick-off anywhere in the own
+       * half; while holding a caught ball, goalie_max_moves times inside the own penalty area */
+      REAL sgn = side_of(i) == SIDE_LEFT ? R(1.0) : R(-1.0);
+      int holds = mode0 == S2D_GM_FREE_KICK && m->ball_holder == i + 1 && m->goalie_moves > 0;
+      if (mode0 == S2D_GM_KICK_OFF || holds) {
+        REAL tx = clampr(a, -p->half_l, holds ? -p->pen_x : R(0.0));
+        REAL ty = holds ? clampr(bb, -p->pen_half_w, p->pen_half_w) : clampr(bb, -p->half_w, p->half_w);
+        o->x = sgn * tx; o->y = sgn * ty; o->vx = R(0.0); o->vy = R(0.0);
+        if (holds) hold_move = i;
       }
     } else if (cmd == S2D_MCMD_KICK) {
       int ok = m_kick(p, t, o, b, a, bb, rnd_u01(nk[0]), rnd_u01(nk[1]), &kx[i], &ky[i]);
@@ -336,7 +348,9 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     if (p->noise) add_noise(&o->vx, &o->vy, p->player_rand, rnd_u01(nz[0]), rnd_u01(nz[1]));
     o->x += o->vx; o->y += o->vy;
   }
-  if (caught_by >= 0) { st->v[4]++; for (int i = 0; i < NP; ++i) { kicked[i] = 0; kx[i] = ky[i] = R(0.0); } }   /* the catch wins the cycle */
+  if (caught_by >= 0) st->v[4]++;
+  if (caught_by >= 0 || hold_move >= 0)                    /* a catch / a move with the ball wins the cycle: kicks are dropped */
+    for (int i = 0; i < NP; ++i) { kicked[i] = 0; kx[i] = ky[i] = R(0.0); }
   /* 2. ball: accelerations summed in player order */
   REAL bax = R(0.0), bay = R(0.0);
   int any_kick = 0, last_kicker = -1;
@@ -345,6 +359,12 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   const int ball_live = !is_setplay(mode0) || any_kick;
   if (caught_by >= 0) {                                   /* held: the ball rests where it was caught */
     b->vx = R(0.0); b->vy = R(0.0); m->last_touch_side = side_of(caught_by);
+  } else if (hold_move >= 0) {                            /* the holding goalie moved: the ball goes with him, in front of his body */
+    const Obj *g = &m->o[hold_move];
+    REAL sn, cs, r = p->pt[hold_move].player_size + p->ball_size + R(0.1);   /* clear of the collision radius, well inside the kickable area */
+    sincos_deg(g->body, &sn, &cs);
+    b->x = g->x + r * cs; b->y = g->y + r * sn; b->vx = R(0.0); b->vy = R(0.0);
+    m->goalie_moves -= 1;
   } else if (ball_live) {
     if (any_kick) {
       REAL a2 = sq2(bax, bay);
@@ -441,6 +461,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
         int in_area = R(fabs)(by) <= p->pen_half_w && (gs == SIDE_LEFT ? bx <= -p->pen_x : bx >= p->pen_x);
         /* inside the own penalty area: free kick for the goalie's side; outside: catch fault */
         restart(m, S2D_GM_FREE_KICK, in_area ? gs : other_side(gs), bx, by);
+        if (in_area) { m->ball_holder = caught_by + 1; m->goalie_moves = p->goalie_max_moves; }
       } else if (bx > p->half_l && R(fabs)(by) < p->goal_half_width) {       /* goal for the left team */
         m->score_left += 1; m->reward_left = R(1.0); st->v[1]++;
         place_formation(m, SIDE_RIGHT);
@@ -482,6 +503,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
       place_formation(m, ks);
       restart(m, S2D_GM_KICK_OFF, ks, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
     }
+    if (m->mode != S2D_GM_FREE_KICK) { m->ball_holder = 0; m->goalie_moves = 0; }   /* nobody holds the ball any more */
   }
   /* 6. decay, tackle timers, stamina */
   for (int i = 0; i < NP; ++i) {
@@ -582,6 +604,7 @@ API int s2dmo_get(const S2DMOEngine *h, int field, double *out) {
         case 13: v = m->score_left; break; case 14: v = m->score_right; break; case 15: v = m->last_touch_side; break;
         case 16: v = m->setplay_timer; break; case 17: v = m->offside_mask; break; case 18: v = m->reward_left; break;
         case 19: v = m->done; break; case 20: v = m->nearest_left; break; case 21: v = m->nearest_right; break;
+        case 23: v = m->ball_holder; break; case 24: v = m->goalie_moves; break;
         default: return -1;
       }
       out[e] = v;

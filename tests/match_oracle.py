@@ -15,7 +15,7 @@ MATCH_DEFAULTS = dict(
     goal_width=14.02, offside_active_area_size=2.5, free_kick_distance=9.15,
     tackle_cycles=10, half_time_cycles=3000, nr_normal_halfs=2, drop_ball_time=100, use_offside=1, catch_ban_cycle=5,
     catchable_area_l=1.2, catch_area_w=1.0, catch_probability=1.0, max_catch_angle=90.0, min_catch_angle=-90.0,
-    penalty_area_length=16.5, penalty_area_half_width=20.16)
+    penalty_area_length=16.5, penalty_area_half_width=20.16, goalie_max_moves=2, reserved1=0)
 
 
 def default_player_type(sp, mp):
@@ -29,6 +29,7 @@ def default_player_type(sp, mp):
 
 OBJ_FIELDS = ('x', 'y', 'vx', 'vy', 'body', 'stamina', 'effort', 'recovery', 'stamina_capacity', 'tackle_cycles')
 EXTRA_OBJ_FIELDS = {'catch_ban': 22}      # s2dmo_get field ids beyond the contiguous block
+EXTRA_ENV_FIELDS = {'ball_holder': 23, 'goalie_moves': 24}
 ENV_FIELDS = ('cycle', 'mode', 'mode_side', 'score_left', 'score_right', 'last_touch_side', 'setplay_timer',
               'offside_mask', 'reward_left', 'done', 'nearest_left', 'nearest_right')
 
@@ -129,7 +130,7 @@ class MatchOracle:
             out = np.zeros((self.n, 24))
             assert self.L.s2dmo_get(self.h, idx, out.ctypes.data_as(C.POINTER(C.c_double))) == 0
             return out.astype(np.int32 if name in ('tackle_cycles', 'catch_ban') else np.float32)
-        idx = 10 + ENV_FIELDS.index(name)
+        idx = EXTRA_ENV_FIELDS[name] if name in EXTRA_ENV_FIELDS else 10 + ENV_FIELDS.index(name)
         out = np.zeros(self.n)
         assert self.L.s2dmo_get(self.h, idx, out.ctypes.data_as(C.POINTER(C.c_double))) == 0
         if name == 'reward_left':

@@ -32,7 +32,7 @@ def _bits(a):
 
 def assert_match_same(eng, orc, tag):
     torch.cuda.synchronize()
-    for f in MO.OBJ_FIELDS + ('catch_ban',) + MO.ENV_FIELDS:
+    for f in MO.OBJ_FIELDS + ('catch_ban',) + MO.ENV_FIELDS + ('ball_holder', 'goalie_moves'):
         g = getattr(eng, f).cpu().numpy()
         c = orc.get(f)
         if not np.array_equal(_bits(g), _bits(c)):
@@ -178,7 +178,7 @@ def test_match_heterogeneous_types_and_catch_parity():
     """18 generated PlayerTypes, a different one on every field player, goalies that catch whenever the
     ball is close (caller actions: the random policy mixed with Catch commands), noise on: every word
     equal after every cycle, and the catch / free-kick path does occur."""
-    from soccer2d_amd._capi_match import GM_FREE_KICK, MCMD_CATCH
+    from soccer2d_amd._capi_match import GM_FREE_KICK, GM_KICK_OFF, MCMD_CATCH, MCMD_MOVE
     n, T = 41, 260
     ids = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0, 11, 12, 13, 14, 15, 16, 17, 1, 2, 3]
     eng, orc = _pair(n, hetero_seed=7, player_type_id=ids, half_time_cycles=140, noise=True)
@@ -186,7 +186,7 @@ def test_match_heterogeneous_types_and_catch_parity():
     eff = eng.effort.cpu().numpy()[0]
     assert len(set(np.round(eff[:22], 6))) > 5                       # effort_max differs by type
     rs = np.random.RandomState(4)
-    free_kicks = 0
+    free_kicks = moves = 0
     for t in range(T):
         a = orc.random_actions()
         bx, by = orc.get('x')[:, 22], orc.get('y')[:, 22]
@@ -194,6 +194,15 @@ def test_match_heterogeneous_types_and_catch_parity():
             gxs, gys = orc.get('x')[:, g], orc.get('y')[:, g]
             near = np.hypot(bx - gxs, by - gys) < 2.0
             a[near, g] = [MCMD_CATCH, rs.uniform(-90, 90), 0]
+        mode, holder = orc.get('mode'), orc.get('ball_holder')
+        ko = np.nonzero(mode == GM_KICK_OFF)[0]                      # before a kick-off: a few players reposition (Move)
+        for e in ko[:6]:
+            for pl in rs.choice(22, 3, replace=False):
+                a[e, pl] = [MCMD_MOVE, rs.uniform(-60, 10), rs.uniform(-40, 40)]
+        for e in np.nonzero(holder > 0)[0]:                          # a goalie holding the ball: carry it or kick it away
+            g = int(holder[e]) - 1
+            a[e, g] = [MCMD_MOVE, rs.uniform(-55, -30), rs.uniform(-25, 25)] if rs.rand() < 0.6 else [3, 90.0, rs.uniform(-40, 40)]
+            moves += 1
         if t == 3:                                                   # make sure the path is exercised: drop the ball at a goalie
             for e in range(0, n, 4):
                 gx, gy = float(orc.get('x')[e, 0]), float(orc.get('y')[e, 0])
@@ -207,7 +216,7 @@ def test_match_heterogeneous_types_and_catch_parity():
             assert_match_same(eng, orc, f'hetero t={t}')
     assert_match_same(eng, orc, 'hetero final')
     assert list(eng.stats.cpu().numpy()) == list(orc.stats())
-    assert free_kicks > 0
+    assert free_kicks > 0 and moves > 0
 
 
 def test_match_hetero_rollout_random_policy_parity():

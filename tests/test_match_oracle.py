@@ -283,3 +283,32 @@ def test_player_types_change_the_dynamics_of_their_players_only():
     m.set_obj(0, 22, x=-20.0 + 1.12, y=-22.0)
     m.step(acts(p5=[MCMD_KICK, 50, 0]))
     assert m.get('vx')[0][22] == 0
+
+
+# ------------------------------------------------------------------ Move{x, y} (idl/service.proto:408-411)
+def test_move_before_kick_off_and_with_a_caught_ball():
+    from soccer2d_amd._capi_match import GM_FREE_KICK, MCMD_CATCH, MCMD_MOVE
+    m = fresh()                                            # KickOff for the left side
+    m.step(acts(p3=[MCMD_MOVE, -12.0, 5.0], p14=[MCMD_MOVE, -30.0, -4.0], p5=[MCMD_MOVE, 20.0, 50.0]))
+    x, y = m.get('x')[0], m.get('y')[0]
+    assert (x[3], y[3]) == (-12.0, 5.0)                    # left team: as given
+    assert (x[14], y[14]) == (30.0, 4.0)                   # right team: mirrored frame
+    assert (x[5], y[5]) == (0.0, 34.0)                     # clamped to the own half / the pitch
+    assert m.get('mode')[0] == GM_KICK_OFF and (m.get('vx')[0][[3, 14, 5]] == 0).all()
+    play_on(m)
+    m.step(acts(p3=[MCMD_MOVE, -40.0, 0.0]))               # not legal in play_on: ignored
+    assert m.get('x')[0][3] == -12.0
+    # goalie catches, then carries the ball twice inside his area; the third move is refused
+    m = fresh(); play_on(m)
+    m.set_obj(0, 22, x=-49.3, y=0.0)
+    m.step(acts(p0=[MCMD_CATCH, 0, 0]))
+    assert m.get('mode')[0] == GM_FREE_KICK and m.get('ball_holder')[0] == 1 and m.get('goalie_moves')[0] == 2
+    m.step(acts(p0=[MCMD_MOVE, -40.0, 10.0]))
+    assert (m.get('x')[0][0], m.get('y')[0][0]) == (-40.0, 10.0) and m.get('goalie_moves')[0] == 1
+    assert m.get('x')[0][22] == pytest.approx(-40.0 + 0.485) and m.get('y')[0][22] == pytest.approx(10.0)   # in front of the body (0 deg)
+    m.step(acts(p0=[MCMD_MOVE, -20.0, 30.0]))              # clamped into the penalty area
+    assert (m.get('x')[0][0], m.get('y')[0][0]) == (-36.0, pytest.approx(20.16)) and m.get('goalie_moves')[0] == 0
+    m.step(acts(p0=[MCMD_MOVE, -45.0, 0.0]))
+    assert m.get('x')[0][0] == -36.0
+    m.step(acts(p0=[MCMD_KICK, 60, 0]))                    # the kick puts the ball in play and ends the hold
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('ball_holder')[0] == 0 and m.get('vx')[0][22] > 0
