@@ -478,6 +478,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     }
   } else if (role == 1) {
     // ------------------------------------------------------------------ S-wave
+    __builtin_amdgcn_s_setprio(1);                         // the simulate wave is the critical stream of the group (+3 %)
     const S2DHot p = hot_in_vgprs(p_sgpr);
     Env e;
     uint32_t gl = 0, gh = 0;
