@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the reach_ball hot path on N MI355X (BASELINE.json metric).
 
-A "step" is one simulator cycle for every env of the batch (action decode -> dash/turn ->
-stamina -> integrate -> collide -> decay -> observation -> reward/done/result -> auto-reset),
-with the rollout record of that step (obs[10], action, reward, done, result per env) written
-to HBM.  Workload = BASELINE.json configs[2]: 65 536 reach_ball envs per GPU, kwargs of
+One simulator CYCLE for every env of the batch = action decode -> dash/turn -> stamina ->
+integrate -> collide -> decay -> observation -> reward/done/result -> auto-reset, with the
+rollout record of that cycle (obs[10], action, reward, done, result per env) written to HBM.
+A bench "step" (--steps K / --warmup W) is one pass of the hot path over the batch as the mode
+issues it: ONE LAUNCH of T = 64 fused cycles in the default rollout mode (and one replay of a
+T-cycle hipGraph in graph mode), one cycle in step mode.  `value` is env-steps (env-cycles) per
+second in every mode: N envs x cycles / seconds.  Workload = BASELINE.json configs[2]: 65 536 reach_ball envs per GPU, kwargs of
 dqn_stable_baselines3.py:18-31, uniform random policy drawn in-kernel (Philox), synthetic
 reset distribution of reach_ball_env.py:170-218.  Inputs are resident in HBM before the
 timed region; nothing is copied to the host inside it.
@@ -41,8 +44,8 @@ DQN_KWARGS = dict(change_ball_position=True, change_ball_velocity=True, min_dist
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4096)
-    ap.add_argument('--warmup', type=int, default=256)
+    ap.add_argument('--steps', type=int, default=None, help='timed bench steps (default 64 launches; 4096 in step mode)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed bench steps (default 4 launches; 256 in step mode)')
     ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
     ap.add_argument('--mode', choices=('rollout', 'step', 'graph'), default='rollout')
     ap.add_argument('--fuse', type=int, default=64, help='cycles per launch (rollout) / per graph (graph)')
@@ -53,7 +56,17 @@ def parse():
                     help='experiments only: dqn = the benchmark workload; the others switch episode ends off')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-steps', type=int, default=0, help='0 = auto (about 10-20 s of CPU work)')
-    return ap.parse_args()
+    args = ap.parse_args()
+    per_cycle = args.mode == 'step'
+    if args.steps is None:
+        args.steps = 4096 if per_cycle else 64
+    if args.warmup is None:
+        args.warmup = 256 if per_cycle else 4
+    if args.steps < 1 or args.warmup < 0 or args.fuse < 1:
+        ap.error('--steps must be >= 1, --warmup >= 0, --fuse >= 1')
+    # cycles per bench step: a whole launch (or graph replay) of `fuse` cycles, or one cycle in step mode
+    args.cycles_per_step = 1 if per_cycle else args.fuse
+    return args
 
 
 def cpu_baseline(n_envs, sample_steps):
@@ -180,7 +193,8 @@ def bench_match(args):
     dev, dist = init_distributed(rank, local_rank, world)
     n = args.envs if args.envs != 65536 else 8192
     eng = MatchEngine(n, dev, cfg=make_match_config(env_id_offset=rank * n, noise=args.noise))
-    T, K, W = max(1, args.fuse), args.steps, args.warmup
+    T = max(1, args.fuse)
+    K, W = args.steps * args.cycles_per_step, args.warmup * args.cycles_per_step     # in cycles
     ro = eng.alloc_rollout(T) if args.mode == 'rollout' else None
     stream = torch.cuda.current_stream(dev)
 
@@ -216,8 +230,8 @@ def bench_match(args):
     st = eng.stats.cpu().tolist()
     if rank == 0:
         line = {'metric': 'env-steps/sec, 11v11 full-match engine (22 players, kick/tackle/catch/offside/stamina, player types)',
-                'value': world * n * K / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
-                'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'value': world * n * K / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': f'11v11 match, {n} matches per GPU, random policy (BASELINE.json configs[3])',
                            'envs_per_gpu': n, 'mode': args.mode, 'cycles_per_launch': per_launch_steps,
@@ -284,7 +298,7 @@ def main():
     eng = Engine(n, dev, cfg=cfg)
     eng.reset()
     T = max(1, args.fuse)
-    K, W = args.steps, args.warmup
+    K, W = args.steps * args.cycles_per_step, args.warmup * args.cycles_per_step     # in cycles
     ro = eng.alloc_rollout(T) if args.mode == 'rollout' else None
     stream = torch.cuda.current_stream(dev)
 
@@ -336,7 +350,7 @@ def main():
             e0.record(stream)
             eng.rollout(T if i < full else rem, out=ro)
             e1.record(stream)
-            if i < full:
+            if i < full or full == 0:                 # K < T: the single short launch is the dominant kernel
                 per_launch_events.append((e0, e1))
         n_launches = full + (1 if rem else 0)
     else:
@@ -357,7 +371,7 @@ def main():
     if args.mode == 'rollout' and per_launch_events:
         durs = sorted(a.elapsed_time(b) * 1e-3 for a, b in per_launch_events)
         launch_s = sum(durs) / len(durs)
-        steps_per_launch = T
+        steps_per_launch = T if K >= T else K
     else:
         a, b = per_launch_events[0]
         launch_s = a.elapsed_time(b) * 1e-3 / K
@@ -377,8 +391,8 @@ def main():
             'metric': 'env-steps/sec at 65 536 parallel reach_ball envs per MI355X',
             'value': total_steps / elapsed,
             'unit': 'env-steps/s',
-            'n_gpus': world, 'steps': K, 'warmup': W,
-            'ms_per_step': elapsed / K * 1e3,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,

@@ -15,8 +15,8 @@ run() { # name, bench args...
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${NAME}_fetch -- python3 bench.py --no-cpu-baseline "$@" > $OUT/${NAME}_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${NAME}_write -- python3 bench.py --no-cpu-baseline "$@" > $OUT/${NAME}_write.log 2>&1
 }
-run rollout64k --steps 1024 --warmup 64
-run rollout1m --steps 1024 --warmup 64 --envs 1048576
+run rollout64k --steps 16 --warmup 1
+run rollout1m --steps 16 --warmup 1 --envs 1048576
 run step64k --steps 1024 --warmup 64 --mode step
 python3 - <<PY
 import csv, glob, json, collections
