@@ -42,7 +42,7 @@ static constexpr int kBlock = S2D_BLOCK;
 static constexpr int kWave = 64;
 static constexpr int kWavesPerBlock = kBlock / kWave;
 static constexpr int kObsTile = kWave * S2D_OBS_DIM;  // 640 floats per wave
-static constexpr int64_t kWsMaxEnvs = 98304;          // up to ~1.5 env groups per SIMD the wave-specialised rollout wins (measured)
+static constexpr int64_t kWsMaxEnvs = 131072;         // up to 2 env groups per SIMD the wave-specialised rollout wins (measured)
 
 // ------------------------------------------------------------------------------------------
 // device helpers
