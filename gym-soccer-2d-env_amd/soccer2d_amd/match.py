@@ -177,6 +177,23 @@ class MatchEngine:
         _capi.check(self.lib, self.lib.s2d_match_relative(self._h, d.data_ptr(), a.data_ptr(), self._stream()), 's2d_match_relative')
         return d, a
 
+    def egocentric_tables(self):
+        """Per-agent view for policies that act from the player's own frame: dict of device tensors
+        dist [N,22,23], bearing [N,22,23] (direction of object j seen from agent p RELATIVE to p's body,
+        degrees in (-180, 180]; 0 on the diagonal), teammate [22,23] bool (same side; the ball column is
+        False).  Built from the relative-tables kernel (Player.dist_from_self / angle_from_self) and the body
+        directions; nothing leaves the device."""
+        d, a = self.relative_tables()
+        body = self.body[:, :M.MATCH_PLAYERS].unsqueeze(2)
+        bearing = a - body
+        bearing = torch.where(bearing > 180.0, bearing - 360.0, torch.where(bearing <= -180.0, bearing + 360.0, bearing))
+        eye = torch.eye(M.MATCH_PLAYERS, M.MATCH_BALL + 1, dtype=torch.bool, device=self.device)
+        bearing = torch.where(eye.unsqueeze(0), torch.zeros_like(bearing), bearing)
+        side = torch.arange(M.MATCH_BALL + 1, device=self.device) < 11
+        teammate = (side[:M.MATCH_PLAYERS, None] == side[None, :])
+        teammate[:, M.MATCH_BALL] = False
+        return {'dist': d, 'bearing': bearing, 'teammate': teammate}
+
     def world_model(self):
         """dict proto-path -> device tensor (left team's point of view = absolute coordinates)."""
         P = M.MATCH_PLAYERS

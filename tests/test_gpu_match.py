@@ -227,3 +227,25 @@ def test_match_hetero_rollout_random_policy_parity():
     for _ in range(T):
         orc.step(None)
     assert_match_same(eng, orc, 'hetero rollout')
+
+
+def test_egocentric_tables():
+    n = 9
+    eng, orc = _pair(n, half_time_cycles=100)
+    for _ in range(25):
+        eng.step(None); orc.step(None)
+    t = eng.egocentric_tables()
+    d, a = orc.relative()
+    body = orc.get('body')[:, :22, None]
+    want = a - body
+    want = np.where(want > 180, want - 360, np.where(want <= -180, want + 360, want))
+    want[:, np.arange(22), np.arange(22)] = 0
+    assert np.array_equal(t['dist'].cpu().numpy(), d)
+    np.testing.assert_allclose(t['bearing'].cpu().numpy(), want, atol=1e-4)
+    tm = t['teammate'].cpu().numpy()
+    assert tm[0, 5] and not tm[0, 15] and tm[12, 20] and not tm[3, 22] and tm.shape == (22, 23)
+    # the ball straight ahead of a player has bearing ~0: place it
+    eng.x[0, 22] = eng.x[0, 3] + 2.0 * torch.cos(torch.deg2rad(eng.body[0, 3]))
+    eng.y[0, 22] = eng.y[0, 3] + 2.0 * torch.sin(torch.deg2rad(eng.body[0, 3]))
+    t = eng.egocentric_tables()
+    assert abs(float(t['bearing'][0, 3, 22])) < 1e-2 and abs(float(t['dist'][0, 3, 22]) - 2.0) < 1e-4
