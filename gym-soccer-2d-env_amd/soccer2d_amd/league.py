@@ -131,3 +131,62 @@ def exchange_results(left, right, goals_left, goals_right, group=None):
     dist.all_gather_into_tensor(out.view(-1), packed.view(-1), group=group)
     out = out.permute(1, 0, 2).reshape(4, -1)
     return out[0], out[1], out[2], out[3]
+
+
+# ---------------------------------------------------------------- a learner: population-based search
+class ParamChaser:
+    """Chaser policy with four learnable numbers (a league member's genome):
+    kick_power [0,100], aim_y (where on the goal line it shoots, metres), turn_tol (degrees of
+    misalignment it accepts before dashing), n_chasers (how many nearest players go for the ball)."""
+    LOW = torch.tensor([5.0, -30.0, 2.0, 1.0])
+    HIGH = torch.tensor([100.0, 30.0, 90.0, 4.0])
+
+    def __init__(self, theta):
+        self.theta = torch.as_tensor(theta, dtype=torch.float32).clone()
+
+    def __call__(self, engine, side):
+        kp, aim_y, tol, nch = (float(v) for v in self.theta)
+        x, y, body, bx, by = team_view(engine, side)
+        act = torch.zeros((x.shape[0], 11, 3), device=x.device)
+        dx, dy = bx - x, by - y
+        dist = torch.hypot(dx, dy)
+        to_ball = _wrap(torch.rad2deg(torch.atan2(dy, dx)) - body)
+        to_goal = _wrap(torch.rad2deg(torch.atan2(aim_y - y, 52.5 - x)) - body)
+        rank = dist.argsort(dim=1).argsort(dim=1)
+        is_chaser = rank < int(round(nch))
+        kickable = dist <= 1.0
+        turn = is_chaser & ~kickable & (to_ball.abs() > tol)
+        dash = is_chaser & ~kickable & ~turn
+        act[..., 0] = torch.where(kickable, 3.0, torch.where(turn, 2.0, torch.where(dash, 1.0, 0.0)))
+        act[..., 1] = torch.where(kickable, torch.full_like(dist, kp), torch.where(turn, to_ball, torch.where(dash, 100.0, 0.0)))
+        act[..., 2] = torch.where(kickable, to_goal, torch.zeros_like(dist))
+        return act
+
+    def mutated(self, gen, scale=0.15):
+        span = self.HIGH - self.LOW
+        noise = torch.randn(4, generator=gen) * scale * span
+        return ParamChaser(torch.minimum(torch.maximum(self.theta + noise, self.LOW), self.HIGH))
+
+
+def evolve_league(engine, population, rounds, n_cycles, seed=0, first_match=0, total_matches=None, group=None):
+    """Population-based training on the league: each round every rank plays its shard of the matches
+    (pairing by global match id), results are all-gathered, the replicated Elo table is updated, and the
+    weakest member is replaced by a mutation of the strongest -- drawn from a generator seeded by
+    (seed, round), so every rank makes the same replacement without exchanging parameters.
+    Returns (league, population, history of (round, champion id, champion theta))."""
+    league = League(len(population), seed=seed)
+    total = total_matches if total_matches is not None else engine.num_envs
+    history = []
+    for r in range(rounds):
+        left, right = league.pairing(r, first_match, engine.num_envs)
+        gl, gr = play_round(engine, population, left, right, n_cycles)
+        L, R, GL, GR = exchange_results(left.to(engine.device), right.to(engine.device), gl, gr, group=group)
+        league.update(L.cpu(), R.cpu(), GL.cpu(), GR.cpu())
+        assert L.numel() >= engine.num_envs and (total is None or L.numel() <= max(total, engine.num_envs))
+        best, worst = int(league.elo.argmax()), int(league.elo.argmin())
+        gen = torch.Generator().manual_seed(seed * 1000003 + r)
+        if best != worst:
+            population[worst] = population[best].mutated(gen)
+            league.elo[worst] = league.elo.mean()          # the newcomer starts from the table's mean
+        history.append((r, best, population[best].theta.clone()))
+    return league, population, history

@@ -249,3 +249,25 @@ def test_egocentric_tables():
     eng.y[0, 22] = eng.y[0, 3] + 2.0 * torch.sin(torch.deg2rad(eng.body[0, 3]))
     t = eng.egocentric_tables()
     assert abs(float(t['bearing'][0, 3, 22])) < 1e-2 and abs(float(t['dist'][0, 3, 22]) - 2.0) < 1e-4
+
+
+def test_population_based_training_on_the_league():
+    """The league learner: 6 ParamChaser genomes, 5 rounds of 96 matches x 300 cycles; the weakest is
+    replaced by a mutation of the strongest each round.  The evolved champion beats the weakest initial
+    genome head to head."""
+    from soccer2d_amd import league as LG
+    from soccer2d_amd.match import MatchEngine
+    g = torch.Generator().manual_seed(5)
+    span = LG.ParamChaser.HIGH - LG.ParamChaser.LOW
+    init = [LG.ParamChaser(LG.ParamChaser.LOW + torch.rand(4, generator=g) * span) for _ in range(6)]
+    init[0] = LG.ParamChaser([6.0, 25.0, 80.0, 1.0])          # a deliberately poor member: feeble kicks, sloppy turns
+    eng = MatchEngine(96, 'cuda:0', half_time_cycles=3000)
+    pop = [LG.ParamChaser(p.theta) for p in init]
+    league, pop, hist = LG.evolve_league(eng, pop, rounds=5, n_cycles=300, seed=3)
+    assert len(hist) == 5 and int(league.games.sum()) == 2 * 96 * 5
+    champ = pop[int(league.elo.argmax())]
+    ids_l = torch.zeros(96, dtype=torch.int64); ids_r = torch.ones(96, dtype=torch.int64)
+    gl, gr = LG.play_round(eng, [champ, init[0]], ids_l, ids_r, 600)
+    gl2, gr2 = LG.play_round(eng, [init[0], champ], ids_l, ids_r, 600)     # sides swapped
+    champ_goals = int(gl.sum() + gr2.sum()); poor_goals = int(gr.sum() + gl2.sum())
+    assert champ_goals > poor_goals and champ_goals > 0
