@@ -89,7 +89,7 @@ S2D_DEV S2DHot hot_in_vgprs(const S2DHot& p) {
 }
 
 // ------------------------------------------------------------------ Philox4x32-10
-enum { S2D_ST_RESET = 0, S2D_ST_POLICY = 1, S2D_ST_SELECT = 2, S2D_ST_NOISE = 3 };
+enum { S2D_ST_RESET = 0, S2D_ST_POLICY = 1, S2D_ST_SELECT = 2, S2D_ST_NOISE = 3, S2D_ST_NOISE_RESET = 5 };   // 4 = tackle (match)
 
 struct U4 { uint32_t x, y, z, w; };
 
@@ -380,11 +380,24 @@ S2D_DEV void cmd_turn(const S2DHot& p, Env& e, float moment, bool noise, float n
   float f = noise ? 1.0f + (noise_u * 2.0f - 1.0f) * p.player_rand : 1.0f;
   e.body = norm_deg(e.body + f * moment / (1.0f + p.inertia_moment * speed));
 }
-S2D_DEV void add_noise(float& vx, float& vy, float rnd, float u_mag, float u_ang) {
+// Velocity noise of MPObject::_inc: polar(U(0, rand * |vel|), U(-180, 180)).  The uniforms and the sine /
+// cosine of the two directions do not depend on the state, so -- like the policy draw -- they are keyed by
+// the env's policy_step (stream NOISE; the command-less cycle of a reset uses stream NOISE_RESET at the
+// cycle) and can be prepared ahead of the simulation by another wave.
+struct NoiseIn { float pm, ps, pc, bm, bs, bc, tu; };   // player: magnitude uniform, sin, cos; ball: same; turn uniform
+S2D_DEV NoiseIn noise_prepare(const S2DHot& p, uint32_t gid_lo, uint32_t gid_hi, uint32_t ctr, uint32_t stream,
+                              bool turn) {
+  const U4 nz = s2d_draw(p, gid_lo, gid_hi, ctr, stream, 0);
+  NoiseIn n;
+  n.pm = rnd_u01(nz.x); sincos_deg(rnd_u01(nz.y) * 360.0f - 180.0f, n.ps, n.pc);
+  n.bm = rnd_u01(nz.z); sincos_deg(rnd_u01(nz.w) * 360.0f - 180.0f, n.bs, n.bc);
+  n.tu = 0.0f;
+  if (turn) n.tu = rnd_u01(s2d_draw(p, gid_lo, gid_hi, ctr, stream, 1).x);
+  return n;
+}
+S2D_DEV void add_noise(float& vx, float& vy, float rnd, float u_mag, float sn, float cs) {
   float s = hypot2(vx, vy);
   float mag = u_mag * (rnd * s);
-  float sn, cs;
-  sincos_deg(u_ang * 360.0f - 180.0f, sn, cs);
   vx += mag * cs; vy += mag * sn;
 }
 S2D_DEV void update_stamina(const S2DHot& p, Env& e) {
@@ -414,7 +427,7 @@ S2D_DEV void update_stamina(const S2DHot& p, Env& e) {
 // Returns |ball - player|^2 of the final positions.
 template <bool NOISE>
 S2D_DEV float move_sequential(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, bool accel, float ax, float ay,
-                              const U4& nz) {
+                              const NoiseIn& nz) {
   if (accel) {
     float a2 = sq2(ax, ay);
     if (a2 > p.player_accel_max2) { float k = rp->player_accel_max / sqrtf(a2); ax *= k; ay *= k; }
@@ -422,11 +435,11 @@ S2D_DEV float move_sequential(const S2DHot& p, const S2DRare* __restrict__ rp, E
   }
   float s2 = sq2(e.vx, e.vy);
   if (s2 > p.player_speed_max2) { float k = rp->player_speed_max / sqrtf(s2); e.vx *= k; e.vy *= k; }
-  if (NOISE) add_noise(e.vx, e.vy, p.player_rand, rnd_u01(nz.x), rnd_u01(nz.y));
+  if (NOISE) add_noise(e.vx, e.vy, p.player_rand, nz.pm, nz.ps, nz.pc);
   e.px += e.vx; e.py += e.vy;
   float b2 = sq2(e.bvx, e.bvy);
   if (b2 > p.ball_speed_max2) { float k = rp->ball_speed_max / sqrtf(b2); e.bvx *= k; e.bvy *= k; }
-  if (NOISE) add_noise(e.bvx, e.bvy, p.ball_rand, rnd_u01(nz.z), rnd_u01(nz.w));
+  if (NOISE) add_noise(e.bvx, e.bvy, p.ball_rand, nz.bm, nz.bs, nz.bc);
   e.bx += e.bvx; e.by += e.bvy;
   float dx = e.bx - e.px, dy = e.by - e.py;
   float d2 = sq2(dx, dy);
@@ -452,10 +465,8 @@ S2D_DEV float move_sequential(const S2DHot& p, const S2DRare* __restrict__ rp, E
 // only a wave with a lane that trips one re-runs those lanes through move_sequential: one
 // branch per cycle instead of four.  Returns |ball - player|^2 after the cycle (judge_sq).
 template <bool NOISE, bool HAS_CMD>
-S2D_DEV float sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
-                        int cmd, const CmdPrep& c) {
-  U4 nz{0, 0, 0, 0};
-  if (NOISE) nz = s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_NOISE, 0);
+S2D_DEV float sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, int cmd, const CmdPrep& c,
+                        const NoiseIn& nz) {
   float ax = 0.0f, ay = 0.0f;
   bool accel = false;
   if (HAS_CMD) {
@@ -463,9 +474,7 @@ S2D_DEV float sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e,
       dash_apply(p, e, c, ax, ay);
       accel = true;
     } else if (cmd == S2D_CMD_TURN) {
-      float nu = 0.0f;
-      if (NOISE) nu = rnd_u01(s2d_draw(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_NOISE, 1).x);
-      cmd_turn(p, e, c.dir, NOISE, nu);
+      cmd_turn(p, e, c.dir, NOISE, nz.tu);
     }
   }
   float d2;
@@ -557,7 +566,9 @@ S2D_DEV float reset_apply(const S2DHot& p, const S2DRare* __restrict__ rp, Env& 
   e.px = o.px; e.py = o.py; e.body = o.body; e.vx = 0.0f; e.vy = 0.0f;
   e.stamina = p.stamina_max; e.recovery = recover_init;
   e.effort = p.effort_init; e.capacity = p.stamina_capacity;
-  return sim_cycle<NOISE, false>(p, rp, e, gid_lo, gid_hi, S2D_CMD_NONE, CmdPrep{0.0f, 0.0f, 0.0f});
+  NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (NOISE) nz = noise_prepare(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_NOISE_RESET, false);
+  return sim_cycle<NOISE, false>(p, rp, e, S2D_CMD_NONE, CmdPrep{0.0f, 0.0f, 0.0f}, nz);
 }
 template <bool NOISE>
 S2D_DEV float env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo,

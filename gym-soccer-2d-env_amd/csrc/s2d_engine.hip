@@ -143,9 +143,9 @@ S2D_DEV Action4 random_action(const S2DHot& p, uint32_t gid_lo, uint32_t gid_hi,
   }
   return a;
 }
-// does a launch of this mode / action kind consume the env's policy_step?  (wave-uniform)
-template <int MODE>
-S2D_DEV bool uses_policy_step(int kind) { return kind == S2D_ACT_RANDOM || MODE == S2D_MODE_TURN4; }
+// does a launch of this mode / action kind / noise setting consume the env's policy_step?  (wave-uniform)
+template <int MODE, bool NOISE>
+S2D_DEV bool uses_policy_step(int kind) { return kind == S2D_ACT_RANDOM || MODE == S2D_MODE_TURN4 || NOISE; }
 
 template <int MODE>
 S2D_DEV void store_rollout_action(void* __restrict__ dst, int64_t idx, const Action4& a) {
@@ -199,10 +199,12 @@ S2D_DEV ResetSample prep_take(const PrepTile& t, int lane) {
 // prep == nullptr: the reset sample is drawn on the spot (per-step API).
 template <bool NOISE>
 S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
-                      int cmd, const CmdPrep& c, ObsOut& ob, float& reward, int& done, int& result,
+                      uint32_t k, int cmd, const CmdPrep& c, ObsOut& ob, float& reward, int& done, int& result,
                       float* __restrict__ terminal_row, PrepTile* prep, int lane, bool& have_prep) {
   e.step_number += 1;                                    // reach_ball_env.py:55
-  float d2 = sim_cycle<NOISE, true>(p, rp, e, gid_lo, gid_hi, cmd, c);   // trainer forces PlayOn each cycle (:242)
+  NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (NOISE) nz = noise_prepare(p, gid_lo, gid_hi, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);
+  float d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);   // trainer forces PlayOn each cycle (:242)
   observe_and_check(p, e, d2, ob, done, reward, result);
   if (done && p.auto_reset) {                  // SB3 VecEnv convention
 #pragma unroll
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
   const int64_t wave_first = i - lane;
   if (wave_first >= n) return;                           // wave-uniform
   const bool active = i < n;
-  const bool use_k = uses_policy_step<MODE>(kind);
+  const bool use_k = uses_policy_step<MODE, NOISE>(kind);
   uint32_t* const kplane = reinterpret_cast<uint32_t*>(S + F_POLICY * stride);
   ObsOut ob;
   int res = 0;
@@ -290,8 +292,8 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
     float reward, dir; int done, cmd;
     CmdPrep c = decide<MODE>(p, actions, kind, i, gl, gh, k, true, quad, squad, nullptr, cmd, dir);
     bool no_prep = false;
-    step_env<NOISE>(p, rp, e, gl, gh, cmd, c, ob, reward, done, res, o.terminal_obs + i * S2D_OBS_DIM, nullptr, lane,
-                    no_prep);
+    step_env<NOISE>(p, rp, e, gl, gh, k, cmd, c, ob, reward, done, res, o.terminal_obs + i * S2D_OBS_DIM, nullptr,
+                    lane, no_prep);
     env_store(e, S, stride, i);
     if (use_k) kplane[i] = k + 1u;
     o.reward[i] = reward;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
   const bool active = i < n;
   int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
   const int valid = (int)rows * S2D_OBS_DIM;
-  const bool use_k = uses_policy_step<MODE>(kind);
+  const bool use_k = uses_policy_step<MODE, NOISE>(kind);
   uint32_t* const kplane = reinterpret_cast<uint32_t*>(S + F_POLICY * stride);
   Env e;
   uint32_t gl = 0, gh = 0, k0 = 0;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
       const uint32_t k = k0 + (uint32_t)t;
       CmdPrep c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, t == 0 || (k & 3u) == 0u, quad, squad,
                                ro.action, cmd, dir);
-      step_env<NOISE>(p, rp, e, gl, gh, cmd, c, ob, reward, done, res, term_row, &prep[wv], lane, have_prep);
+      step_env<NOISE>(p, rp, e, gl, gh, k, cmd, c, ob, reward, done, res, term_row, &prep[wv], lane, have_prep);
       if (p.auto_reset) n_missing += __popcll(__ballot(done != 0));   // samples consumed by this cycle's resets
       if (ro.reward) ro.reward[row + i] = reward;
       if (ro.done) ro.done[row + i] = (uint8_t)done;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 // Used for small batches; with more env groups per SIMD the unified kernel overlaps whole waves
 // instead and is kept.
 enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_FLAGS, WS_WORDS };
-enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_WORDS };
+enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_NPM, WA_NPS, WA_NPC, WA_NBM, WA_NBS, WA_NBC, WA_NTU, WA_WORDS };   // command + prepared noise
 static constexpr int kWsBlock = 4 * kWave;
 
 template <int MODE, bool NOISE>
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   if (role == 0) {
     // ------------------------------------------------------------------ P-wave
     const S2DHot& p = p_sgpr;
-    const bool use_k = uses_policy_step<MODE>(kind);
+    const bool use_k = uses_policy_step<MODE, NOISE>(kind);
     uint32_t* const kplane = reinterpret_cast<uint32_t*>(S + F_POLICY * stride);
     uint32_t gl = 0, gh = 0, k0 = 0;
     if (active) {
@@ -462,6 +464,12 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         if (MODE == S2D_MODE_TURN4) act[b][WA_CMD][lane] = __int_as_float(cmd);
         act[b][WA_POWER][lane] = c.power;
         act[b][WA_DIR][lane] = c.dir; act[b][WA_RATE][lane] = c.dir_rate;
+        if (NOISE) {                                       // the state-independent half of this cycle's noise
+          const NoiseIn nz = noise_prepare(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);
+          act[b][WA_NPM][lane] = nz.pm; act[b][WA_NPS][lane] = nz.ps; act[b][WA_NPC][lane] = nz.pc;
+          act[b][WA_NBM][lane] = nz.bm; act[b][WA_NBS][lane] = nz.bs; act[b][WA_NBC][lane] = nz.bc;
+          if (MODE == S2D_MODE_TURN4) act[b][WA_NTU][lane] = nz.tu;
+        }
         row += n;
       }
 #if S2D_PROFILE
@@ -497,6 +505,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     if (active && p.auto_reset) { const S2DRare r = *rp; nxt = reset_sample(p, r, gl, gh, reset_key(e)); have_prep = true; }
     int cmd_cur = S2D_CMD_DASH, cmd_nxt = S2D_CMD_DASH;
     CmdPrep c_cur{0.0f, 0.0f, 0.0f}, c_nxt{0.0f, 0.0f, 0.0f};
+    NoiseIn nz_cur{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, nz_nxt = nz_cur;
     int n_missing = 0;                                     // wave-uniform: active lanes without a prepared sample
     S2D_TICK_INIT(2);
     for (int s = 0; s < n_iter; ++s) {
@@ -504,6 +513,11 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         const int bn = (s - 1) & 1;
         if (MODE == S2D_MODE_TURN4) cmd_nxt = __float_as_int(act[bn][WA_CMD][lane]);   // other modes always dash
         c_nxt = CmdPrep{act[bn][WA_POWER][lane], act[bn][WA_DIR][lane], act[bn][WA_RATE][lane]};
+        if (NOISE) {
+          nz_nxt = NoiseIn{act[bn][WA_NPM][lane], act[bn][WA_NPS][lane], act[bn][WA_NPC][lane], act[bn][WA_NBM][lane],
+                           act[bn][WA_NBS][lane], act[bn][WA_NBC][lane], 0.0f};
+          if (MODE == S2D_MODE_TURN4) nz_nxt.tu = act[bn][WA_NTU][lane];
+        }
       }
       if (s >= 2 && s <= n_steps + 1) {                    // step s - 2
         const int b = s & 1;
@@ -514,7 +528,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         if (active) {
           S2D_TICK(0);                                     // refill check
           e.step_number += 1;                              // reach_ball_env.py:55
-          const float d2 = sim_cycle<NOISE, true>(p, rp, e, gl, gh, cmd_cur, c_cur);
+          const float d2 = sim_cycle<NOISE, true>(p, rp, e, cmd_cur, c_cur, nz_cur);
 #if S2D_PROFILE
           asm volatile("" ::"v"(e.px), "v"(e.py), "v"(e.bx), "v"(e.by), "v"(e.stamina), "v"(e.effort), "v"(e.vx), "v"(e.vy));
           S2D_TICK(1);                                     // simulator cycle
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           }
         }
       }
-      cmd_cur = cmd_nxt; c_cur = c_nxt;
+      cmd_cur = cmd_nxt; c_cur = c_nxt; nz_cur = nz_nxt;
 #if S2D_PROFILE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif

@@ -400,11 +400,15 @@ static void update_stamina(const P *p, Env *e) {
 
 /* One simulator cycle (appendix A "Per-cycle order", play_on, referee off in coach mode:
  * soccer_2d_env.py:363-366 starts rcssserver with coach=true and no coach_w_referee). */
-static void sim_cycle(const P *p, Env *e, uint64_t gid, int cmd, REAL power, REAL dir) {
+/* Noise draws (player_rand / ball_rand / turn) of a commanded cycle are keyed by the env's policy_step
+ * (stream NOISE), those of the command-less cycle a reset consumes by the cycle (stream NOISE_RESET):
+ * like the policy draws they must not depend on whether an episode ended earlier. */
+static void sim_cycle(const P *p, Env *e, uint64_t gid, int cmd, REAL power, REAL dir, uint32_t noise_ctr,
+                      uint32_t noise_stream) {
   uint32_t nz[4] = {0, 0, 0, 0}, nz2[4] = {0, 0, 0, 0};
   if (p->noise) {
-    draw(p->seed, gid, (uint32_t)e->cycle, ST_NOISE, 0, nz);
-    draw(p->seed, gid, (uint32_t)e->cycle, ST_NOISE, 1, nz2);
+    draw(p->seed, gid, noise_ctr, noise_stream, 0, nz);
+    draw(p->seed, gid, noise_ctr, noise_stream, 1, nz2);
   }
   REAL ax = R(0.0), ay = R(0.0);
   if (cmd == S2D_CMD_DASH) cmd_dash(p, e, power, dir, &ax, &ay);
@@ -435,7 +439,7 @@ static void env_reset(const P *p, Env *e, uint64_t gid, REAL *obs) {
   e->px = o.px; e->py = o.py; e->body = norm_deg(o.body); e->vx = R(0.0); e->vy = R(0.0); /* (move (player..)) */
   e->stamina = p->stamina_max; e->recovery = p->recover_init;     /* (recover) */
   e->effort = p->effort_init; e->capacity = p->stamina_capacity;
-  sim_cycle(p, e, gid, S2D_CMD_NONE, R(0.0), R(0.0));
+  sim_cycle(p, e, gid, S2D_CMD_NONE, R(0.0), R(0.0), (uint32_t)e->cycle, ST_NOISE_RESET);
   observation(p, e->bx, e->by, e->bvx, e->bvy, e->px, e->py, e->body, obs);
   int d, res; REAL rw;
   check_trainer(p, e->bx, e->by, e->px, e->py, e->body, e->step_number, &e->prev_dist, &e->prev_angle, &d, &rw, &res);
@@ -538,13 +542,14 @@ static void step_one(S2DOEngine *h, int64_t i, const void *actions, int kind, vo
   const int turning = p->use_continuous && p->use_turning;
   fetch_action(h, i, actions, kind, e->policy_step, a, rollout_action_out);
   e->step_number += 1;                                   /* reach_ball_env.py:55 */
+  const uint32_t k = e->policy_step;
   REAL u = R(0.0);
-  if (turning) u = rnd_u01(quad_word(p->seed, gid, e->policy_step, ST_SELECT));
-  if (turning || kind == S2D_ACT_RANDOM) e->policy_step += 1u;
+  if (turning) u = rnd_u01(quad_word(p->seed, gid, k, ST_SELECT));
+  if (turning || kind == S2D_ACT_RANDOM || p->noise) e->policy_step += 1u;
   int cmd; REAL power, dir;
   action_map(p, a, u, &cmd, &power, &dir);               /* :238 */
   h->action_cmd[i] = (uint8_t)cmd; h->action_dir[i] = dir;
-  sim_cycle(p, e, gid, cmd, power, dir);                 /* rcssserver cycle; trainer forces PlayOn :242 */
+  sim_cycle(p, e, gid, cmd, power, dir, k, ST_NOISE);    /* rcssserver cycle; trainer forces PlayOn :242 */
   REAL *obs = &h->obs[i * 10];
   observation(p, e->bx, e->by, e->bvx, e->bvy, e->px, e->py, e->body, obs);   /* :249 */
   int d, res; REAL rw;

@@ -35,7 +35,7 @@ typedef float REAL;
  * Counter layout of this project:
  *   ctr = { gid_lo, gid_hi, cycle, (stream << 16) | block },  key = { seed_lo, seed_hi }
  * ==================================================================================== */
-enum { ST_RESET = 0, ST_POLICY = 1, ST_SELECT = 2, ST_NOISE = 3 };
+enum { ST_RESET = 0, ST_POLICY = 1, ST_SELECT = 2, ST_NOISE = 3, ST_NOISE_RESET = 5 };   /* 4 = tackle (match) */
 
 static void s2do_philox4x32_10_impl(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];

@@ -6,7 +6,7 @@ import torch
 from soccer2d_amd.engine import Engine, make_config
 from ablate import KW
 N, T, L = 65536, 64, 16
-eng = Engine(N, 'cuda:0', cfg=make_config(**KW)); eng.reset()
+eng = Engine(N, 'cuda:0', cfg=make_config(noise=bool(int(os.environ.get('S2D_NOISE', '0'))), **KW)); eng.reset()
 out = eng.alloc_rollout(T)
 for _ in range(8): eng.rollout(T, out=out)
 eng.stats_reset()
