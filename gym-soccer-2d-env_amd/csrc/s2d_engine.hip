@@ -723,6 +723,37 @@ __global__ void s2d_debug_eval_kernel(int op, const float* __restrict__ in, floa
       break;
     }
     case 5: out[i] = hypot2(in[2 * i], in[2 * i + 1]); break;
+    case 6: {                                            // A3 state_to_observation
+      const float* r = in + 9 * i;
+      S2DHot p{}; p.inv_half_l = r[7]; p.inv_half_w = r[8];
+      ObsOut ob;
+      observe(p, r[4], r[5], r[6], r[0], r[1], r[2], r[3], ob);
+      for (int k = 0; k < S2D_OBS_DIM; ++k) out[S2D_OBS_DIM * i + k] = ob.o[k];
+      break;
+    }
+    case 7: {                                            // A2 action_to_rpc_actions
+      const float* r = in + 8 * i;
+      S2DHot p{}; p.act_scale = r[6];
+      const Action4 a{r[0], r[1], r[2], r[3]};
+      int cmd = 0; float power = 0.0f, dir = 0.0f;
+      const int mode = (int)r[5];
+      if (mode == S2D_MODE_DISCRETE) action_map<S2D_MODE_DISCRETE>(p, a, r[4], cmd, power, dir);
+      else if (mode == S2D_MODE_CONT1) action_map<S2D_MODE_CONT1>(p, a, r[4], cmd, power, dir);
+      else action_map<S2D_MODE_TURN4>(p, a, r[4], cmd, power, dir);
+      out[3 * i] = (float)cmd; out[3 * i + 1] = power; out[3 * i + 2] = dir;
+      break;
+    }
+    case 8: {                                            // A4 check_trainer_observation
+      const float* r = in + 12 * i;
+      S2DHot p{}; p.min_distance_to_ball = r[8]; p.max_steps = (int)r[9]; p.half_l = r[10]; p.half_w = r[11];
+      Env e{}; e.bx = r[0]; e.by = r[1]; e.px = r[2]; e.py = r[3]; e.body = r[4]; e.step_number = (int)r[5];
+      e.prev_dist = r[6]; e.prev_angle = r[7];
+      ObsOut ob; int done, result; float reward;
+      observe_and_check(p, e, sq2(e.bx - e.px, e.by - e.py), ob, done, reward, result);
+      float* q = out + 5 * i;
+      q[0] = (float)done; q[1] = reward; q[2] = (float)result; q[3] = e.prev_dist; q[4] = e.prev_angle;
+      break;
+    }
     default: break;
   }
 }
@@ -1117,7 +1148,7 @@ S2D_API int s2d_stats_reset(S2DHandle h, void* stream) {
 S2D_API const char* s2d_kernel_name(S2DHandle h) { return h ? h->last_kernel : ""; }
 
 S2D_API int s2d_debug_eval(int op, const void* in_dev, void* out_dev, int64_t n, void* stream) {
-  if (!in_dev || !out_dev || n <= 0 || op < 0 || op > 5) return fail(S2D_EINVAL, "bad s2d_debug_eval argument");
+  if (!in_dev || !out_dev || n <= 0 || op < 0 || op > 8) return fail(S2D_EINVAL, "bad s2d_debug_eval argument");
   hipLaunchKernelGGL(s2d_debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), op, static_cast<const float*>(in_dev),
                      static_cast<float*>(out_dev), n);

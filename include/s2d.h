@@ -212,7 +212,15 @@ const char *s2d_kernel_name(S2DHandle h);
 /* diagnostic: evaluate one primitive of the fp32 math spec / Philox on the device so that
  * tests can compare it bit for bit with the CPU oracle.  op: 0 sincos_deg (in[n] -> out[n][2]),
  * 1 atan2_deg (in[n][2]=y,x -> out[n]), 2 exp, 3 norm_deg, 4 philox4x32-10 (in = uint32[n][6]
- * ctr+key -> out = uint32[n][4]), 5 hypot (in[n][2] -> out[n]). */
+ * ctr+key -> out = uint32[n][4]), 5 hypot (in[n][2] -> out[n]).
+ * The three hooks of ReachBallEnv, evaluated stand-alone so that the device code can be checked against the
+ * golden vectors produced by the reference's own Python (tests/golden):
+ * 6 state_to_observation (reach_ball_env.py:87-111): in[n][9] = bx,by,bvx,bvy,px,py,body,1/half_length,1/half_width
+ *   -> out[n][10];
+ * 7 action_to_rpc_actions (:53-85): in[n][8] = a0,a1,a2,a3,u,mode(0 discrete,1 continuous,2 turning),360/n,0
+ *   -> out[n][3] = S2D_CMD_*, power, relative direction;
+ * 8 check_trainer_observation (:113-161): in[n][12] = bx,by,px,py,body,step_number,prev_dist,prev_angle,
+ *   min_distance_to_ball,max_steps,half_length,half_width -> out[n][5] = done,reward,S2D_RESULT_*,dist,angle. */
 int s2d_debug_eval(int op, const void *in_dev, void *out_dev, int64_t n, void *stream);
 
 #ifdef __cplusplus
