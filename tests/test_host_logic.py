@@ -203,3 +203,21 @@ def test_player_type_generator_is_deterministic_and_respects_the_trade_offs():
     assert lib.s2d_match_validate_config(C.byref(a)) == 0
     a.player_type_id[3] = 18
     assert lib.s2d_match_validate_config(C.byref(a)) != 0
+
+
+def test_bench_step_units(monkeypatch):
+    """bench.py: a step is one launch of `--fuse` cycles in rollout / graph mode, one cycle in step mode."""
+    import importlib
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module('bench')
+    for argv, want in ((['bench.py'], (64, 4, 64)), (['bench.py', '--mode', 'step'], (4096, 256, 1)),
+                       (['bench.py', '--steps', '5', '--warmup', '1', '--fuse', '32'], (5, 1, 32)),
+                       (['bench.py', '--mode', 'graph', '--steps', '7'], (7, 4, 64))):
+        monkeypatch.setattr(_sys, 'argv', argv)
+        a = bench.parse()
+        assert (a.steps, a.warmup, a.cycles_per_step) == want
+    monkeypatch.setattr(_sys, 'argv', ['bench.py', '--steps', '0'])
+    with pytest.raises(SystemExit):
+        bench.parse()
