@@ -496,7 +496,7 @@ S2D_DEV float sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e,
       d2 = move_sequential<false>(p, rp, e, accel, ax, ay, nz);
     }
   }
-  e.cycle += 1;
+  e.cycle = (int)((uint32_t)e.cycle + 1u);               // wraps after 2^31 cycles (~47 min of fused rollouts) without UB
   e.vx *= p.player_decay; e.vy *= p.player_decay;
   e.bvx *= p.ball_decay; e.bvy *= p.ball_decay;
   update_stamina(p, e);
@@ -515,7 +515,7 @@ struct ResetSample { float px, py, body, bx, by, bvx, bvy; };
 // (cycle - step_number - 1: constant during an episode, unique per episode).  The sample of the
 // NEXT episode is therefore computable at any time during the current one, which lets the
 // rollout kernels prepare samples for many lanes at once instead of one lane at a time.
-S2D_DEV uint32_t reset_key(const Env& e) { return (uint32_t)(e.cycle - e.step_number - 1); }
+S2D_DEV uint32_t reset_key(const Env& e) { return (uint32_t)e.cycle - (uint32_t)e.step_number - 1u; }
 
 S2D_DEV ResetSample reset_sample(const S2DHot& p, const S2DRare& r, uint32_t gid_lo, uint32_t gid_hi, uint32_t c0) {
   U4 w = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 0);

@@ -418,7 +418,7 @@ static void sim_cycle(const P *p, Env *e, uint64_t gid, int cmd, REAL power, REA
   obj_inc(&e->bx, &e->by, &e->bvx, &e->bvy, 0, R(0.0), R(0.0), R(0.0), R(0.0),
           p->ball_speed_max, p->ball_speed_max2, p->noise, p->ball_rand, rnd_u01(nz[2]), rnd_u01(nz[3]));
   collide(p, e);
-  e->cycle += 1;                                        /* referee: time += 1 */
+  e->cycle = (int32_t)((uint32_t)e->cycle + 1u);        /* referee: time += 1 (wraps, never UB) */
   e->vx *= p->player_decay; e->vy *= p->player_decay;   /* _turn */
   e->bvx *= p->ball_decay; e->bvy *= p->ball_decay;
   update_stamina(p, e);
@@ -431,7 +431,7 @@ static void env_reset(const P *p, Env *e, uint64_t gid, REAL *obs) {
   /* RESET stream counter word: the cycle at which the CURRENT episode began
    * (= cycle - step_number - 1, constant during an episode, unique per episode), so the next
    * episode's initial state is a function of data known from the episode's first cycle on. */
-  s.seed = p->seed; s.gid = gid; s.cycle = (uint32_t)(e->cycle - e->step_number - 1);
+  s.seed = p->seed; s.gid = gid; s.cycle = (uint32_t)e->cycle - (uint32_t)e->step_number - 1u;
   ResetDraw o;
   reset_sample(p, &s, &o);
   e->step_number = 0;                                    /* :172 */

@@ -354,3 +354,22 @@ def test_short_rollouts_pipeline_fill_and_drain(name, ws, monkeypatch):
         eng.step(None); orc.step(None)
         assert_state_same(eng, orc, f'{name} step after T={T}')
     assert int(eng.policy_step.min()) == int(eng.policy_step.max()) > 0
+
+
+def test_cycle_counter_wraps_past_int32():
+    """`cycle` is an int32 like WorldModel.cycle; a long-running engine passes 2^31 (47 minutes of fused
+    rollouts): the counter wraps, the Philox counters derived from it keep matching the oracle."""
+    kw = dict(CONFIGS['dqn-discrete16']); kw['max_steps'] = 15
+    n = 96
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    for i in range(0, n, 3):
+        c = 2 ** 31 - 1 - (i % 7)
+        eng.cycle[i] = c
+        orc.set_env(i, cycle=c)
+    out, ref = eng.rollout(40), orc.rollout(40)
+    torch.cuda.synchronize()
+    for k in ('obs', 'reward', 'done', 'result'):
+        assert_same(out[k], ref[k], f'wrap {k}')
+    assert_state_same(eng, orc, 'wrap')
+    assert int(eng.cycle.min()) < -2 ** 31 + 200
