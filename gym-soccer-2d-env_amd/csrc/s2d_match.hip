@@ -413,7 +413,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
     }
   }
   // ---- 5. referee (every lane of the half evaluates the same decisions)
-  g.cycle += 1;
+  g.cycle = (int)((uint32_t)g.cycle + 1u);               // wrap-defined (a finished match without auto-restart keeps counting)
   // inputs that need shuffles are gathered unconditionally (uniform control flow)
   const float bx = hbcast(o.x, BALL), by = hbcast(o.y, BALL);
   float first = -1.0e9f, second = -1.0e9f;      // two largest dirS*x0 among the kicker's opponents

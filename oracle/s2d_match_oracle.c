@@ -423,7 +423,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     }
   }
   /* 5. referee */
-  m->cycle += 1;
+  m->cycle = (int32_t)((uint32_t)m->cycle + 1u);
   if (mode0 != S2D_GM_TIME_OVER) {
     if (is_setplay(mode0)) {
       if (any_kick) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; }
