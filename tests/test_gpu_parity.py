@@ -373,3 +373,45 @@ def test_cycle_counter_wraps_past_int32():
         assert_same(out[k], ref[k], f'wrap {k}')
     assert_state_same(eng, orc, 'wrap')
     assert int(eng.cycle.min()) < -2 ** 31 + 200
+
+
+@pytest.mark.parametrize('ws', ['0', '1'])
+@pytest.mark.parametrize('seed', list(range(6)))
+def test_random_server_parameters_parity(seed, ws, monkeypatch):
+    """Parity must not hinge on the stock parameter values: random ServerParam / task settings (speeds and
+    accelerations that make the clamps fire, a player as large as the ball-collision radius needs, no stamina
+    capacity, continuous dash directions, short episodes, ...) -- rollouts, per-step launches and resets stay
+    bit-identical to the oracle."""
+    monkeypatch.setenv('S2D_ROLLOUT_WS', ws)
+    rs = np.random.RandomState(100 + seed)
+    server = dict(
+        player_decay=float(rs.uniform(0.2, 0.7)), ball_decay=float(rs.uniform(0.85, 0.99)),
+        player_speed_max=float(rs.uniform(0.3, 1.2)), player_accel_max=float(rs.uniform(0.2, 1.0)),
+        ball_speed_max=float(rs.uniform(1.0, 3.0)), player_size=float(rs.uniform(0.2, 2.5)), ball_size=float(rs.uniform(0.05, 0.5)),
+        dash_power_rate=float(rs.uniform(0.003, 0.012)), side_dash_rate=float(rs.uniform(0.2, 0.6)),
+        back_dash_rate=float(rs.uniform(0.4, 0.8)), dash_angle_step=float(rs.choice([0.0, 1.0, 22.5, 45.0])),
+        min_dash_power=float(rs.choice([0.0, -100.0])), max_dash_power=float(rs.choice([100.0, 60.0])),
+        stamina_max=float(rs.uniform(2000, 8000)), stamina_inc_max=float(rs.uniform(10, 60)),
+        stamina_capacity=float(rs.choice([-1.0, 5000.0, 130600.0])), extra_stamina=float(rs.uniform(0, 100)),
+        effort_min=float(rs.uniform(0.3, 0.8)), recover_min=float(rs.uniform(0.3, 0.7)),
+        collision_vel_rate=float(rs.uniform(-0.5, -0.05)), player_rand=float(rs.uniform(0, 0.2)), ball_rand=float(rs.uniform(0, 0.1)))
+    mode = seed % 3
+    kw = dict(server=server, max_steps=int(rs.randint(5, 40)), min_distance_to_ball=float(rs.uniform(0.5, 8.0)),
+              change_ball_velocity=bool(rs.randint(2)), change_ball_position=bool(rs.randint(2)),
+              ball_position_x=float(rs.uniform(-20, 20)), ball_position_y=float(rs.uniform(-10, 10)),
+              ball_speed=float(rs.uniform(0, 2.5)), ball_direction=float(rs.uniform(-180, 180)),
+              use_continuous_action=mode != 0, use_turning=mode == 2, action_space_size=int(rs.choice([3, 8, 16, 36])),
+              noise=bool(seed & 1), seed=int(rs.randint(1, 2 ** 31)))
+    n = 257
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    assert_state_same(eng, orc, f'cfg{seed} reset')
+    out, ref = eng.rollout(70), orc.rollout(70)
+    torch.cuda.synchronize()
+    for k in ('obs', 'action', 'reward', 'done', 'result'):
+        assert_same(out[k], ref[k], f'cfg{seed} rollout.{k}')
+    for t in range(25):
+        eng.step(None); orc.step(None)
+    assert_state_same(eng, orc, f'cfg{seed} after steps')
+    assert_same(eng.obs, orc.obs(), f'cfg{seed} obs')
+    assert int(eng.stats[1:4].sum()) > 0
