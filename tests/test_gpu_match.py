@@ -271,3 +271,36 @@ def test_population_based_training_on_the_league():
     gl2, gr2 = LG.play_round(eng, [init[0], champ], ids_l, ids_r, 600)     # sides swapped
     champ_goals = int(gl.sum() + gr2.sum()); poor_goals = int(gr.sum() + gl2.sum())
     assert champ_goals > poor_goals and champ_goals > 0
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_match_random_parameters_parity(seed):
+    """The match engine under random server / match parameters and generated player types: bit-exact."""
+    rs = np.random.RandomState(300 + seed)
+    server = dict(player_decay=float(rs.uniform(0.3, 0.6)), ball_decay=float(rs.uniform(0.9, 0.97)),
+                  player_speed_max=float(rs.uniform(0.6, 1.2)), player_accel_max=float(rs.uniform(0.3, 1.0)),
+                  ball_speed_max=float(rs.uniform(1.5, 3.0)), ball_accel_max=float(rs.uniform(1.0, 2.7)),
+                  player_size=float(rs.uniform(0.25, 0.8)), ball_size=float(rs.uniform(0.05, 0.3)),
+                  dash_angle_step=float(rs.choice([0.0, 1.0, 45.0])), min_dash_power=float(rs.choice([0.0, -100.0])),
+                  stamina_capacity=float(rs.choice([-1.0, 20000.0, 130600.0])), collision_vel_rate=float(rs.uniform(-0.4, -0.05)))
+    kw = dict(server=server, half_time_cycles=int(rs.randint(40, 90)), drop_ball_time=int(rs.randint(2, 30)),
+              tackle_cycles=int(rs.randint(1, 6)), tackle_dist=float(rs.uniform(1.0, 3.0)),
+              tackle_back_dist=float(rs.choice([0.0, 0.5])), kickable_margin=float(rs.uniform(0.5, 1.5)),
+              kick_power_rate=float(rs.uniform(0.02, 0.04)), free_kick_distance=float(rs.uniform(3.0, 9.15)),
+              offside_active_area_size=float(rs.uniform(1.0, 5.0)), use_offside=int(rs.randint(2)),
+              catch_probability=float(rs.choice([1.0, 0.6])), catch_ban_cycle=int(rs.randint(0, 6)),
+              noise=bool(seed & 1), seed=int(rs.randint(1, 2 ** 31)), hetero_seed=int(rs.randint(1, 1000)),
+              player_type_id=[0] + [int(v) for v in rs.randint(0, 18, 10)] + [0] + [int(v) for v in rs.randint(0, 18, 10)])
+    n = 33
+    eng, orc = _pair(n, **kw)
+    assert_match_same(eng, orc, f'mcfg{seed} reset')
+    for t in range(200):
+        a = orc.random_actions()
+        cmds = a[:, :, 0]
+        flip = rs.rand(*cmds.shape) < 0.08                       # sprinkle catch / move commands over the random policy
+        a[:, :, 0] = np.where(flip, rs.choice([5.0, 6.0], size=cmds.shape), cmds)
+        a[:, :, 1] = np.where(flip, rs.uniform(-60, 60, cmds.shape), a[:, :, 1])
+        eng.step(torch.as_tensor(a, device='cuda:0')); orc.step(a)
+        if t % 20 == 19:
+            assert_match_same(eng, orc, f'mcfg{seed} t={t}')
+    assert list(eng.stats.cpu().numpy()) == list(orc.stats())
