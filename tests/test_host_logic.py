@@ -221,3 +221,26 @@ def test_bench_step_units(monkeypatch):
     monkeypatch.setattr(_sys, 'argv', ['bench.py', '--steps', '0'])
     with pytest.raises(SystemExit):
         bench.parse()
+
+
+def test_logger_utils_mirror(tmp_path, monkeypatch):
+    """utils.logger_utils.setup_logger as the reference's scripts use it (dqn_stable_baselines3.py:12-14)."""
+    import logging
+    from utils.logger_utils import setup_logger
+    # like the reference, "already configured" is Logger.hasHandlers(), which also looks at the root logger:
+    # pytest hangs its capture handlers there, a training script does not
+    monkeypatch.setattr(logging.getLogger(), 'handlers', [])
+    d = tmp_path / 'logs' / 'run1'
+    lg = setup_logger('S2DTestLogger', str(d), console_level=logging.DEBUG, file_level=logging.DEBUG)
+    assert lg is logging.getLogger('S2DTestLogger') and len(lg.handlers) == 2 and d.is_dir()
+    lg.info('hello %d', 7)
+    for h in lg.handlers:
+        h.flush()
+    text = (d / 'S2DTestLogger.log').read_text()
+    assert 'S2DTestLogger - INFO - hello 7' in text
+    assert setup_logger('S2DTestLogger', str(d)) is lg and len(lg.handlers) == 2      # configured once
+    only_file = setup_logger('S2DTestLogger2', str(d), console_level=None)
+    assert len(only_file.handlers) == 1 and isinstance(only_file.handlers[0], logging.FileHandler)
+    for name in ('S2DTestLogger', 'S2DTestLogger2'):
+        for h in list(logging.getLogger(name).handlers):
+            h.close(); logging.getLogger(name).removeHandler(h)
