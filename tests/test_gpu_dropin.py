@@ -203,3 +203,41 @@ def test_league_rollout_exchange_single_rank_overlaps_streams():
         assert g['obs'].shape == (1, 16, 4096, 10)
         for k in ('obs', 'action', 'reward', 'done', 'result'):
             assert torch.equal(g[k][0], ref[k]), k
+
+
+def test_factory_single_env_flow_like_the_ddpg_script():
+    """ddpg_stable_baselines3.py:18-31, 36, 44-56: continuous 1-D action space, fixed ball, the script's own
+    test() loop -- `action = model.predict(obs)` (a tuple) goes straight into env.step()."""
+    from sample_environments.environment_factory import EnvironmentFactory
+    from utils.logger_utils import setup_logger
+    import logging
+    import tempfile
+    kw = dict(change_ball_position=False, change_ball_velocity=False, ball_position_x=0, ball_position_y=0, ball_speed=0,
+              ball_direction=0, min_distance_to_ball=5.0, max_steps=200, action_space_size=16, use_continuous_action=True,
+              use_turning=False)
+    log_dir = tempfile.mkdtemp()
+    logger = setup_logger('SampleRL-test', log_dir, console_level=None, file_level=logging.DEBUG)
+    env = EnvironmentFactory().create('reachball', render_mode=False, logger=logger, log_dir=log_dir, **kw)
+    assert env.action_space.shape == (1,) and float(env.action_space.low[0]) == -1.0 and float(env.action_space.high[0]) == 1.0
+    orc = O.OracleEngine(O.make_config(auto_reset=0, **kw), 1, 'f32')
+    obs = env.reset()
+    assert np.array_equal(obs.astype(np.float32), orc.reset()[0])
+    assert obs[4] == 0.0 and obs[5] == 0.0 and obs[6] == 0.0          # the ball rests at the centre spot
+    rs = np.random.RandomState(1)
+    results = {'Goal': 0, 'Out': 0, 'Timeout': 0}
+
+    def predict(o):                                                    # stand-in for model.predict: (action, state)
+        to_ball = float(o[0])                                          # obs[0] = angle to the ball / 180: dash towards it
+        return np.array([np.clip(to_ball + rs.normal(0, 0.05), -1, 1)], dtype=np.float32), None
+    for _ in range(500):
+        action = predict(obs)
+        obs, reward, done, info = env.step(action)
+        oo, orw, od, ores = orc.step(np.asarray(action[0], dtype=np.float32).reshape(1, 1))
+        assert np.array_equal(obs.astype(np.float32), oo[0]) and np.float32(reward) == orw[0] and done == bool(od[0])
+        if done:
+            if info['result']:
+                results[info['result']] += 1
+            obs = env.reset()
+            assert np.array_equal(obs.astype(np.float32), orc.reset()[0])
+    assert results['Goal'] >= 3 and results['Goal'] > results['Out'] + results['Timeout']   # steering at the ball reaches it
+    env.close()
