@@ -570,6 +570,25 @@ S2D_DEV float reset_apply(const S2DHot& p, const S2DRare* __restrict__ rp, Env& 
   if (NOISE) nz = noise_prepare(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_NOISE_RESET, false);
   return sim_cycle<NOISE, false>(p, rp, e, S2D_CMD_NONE, CmdPrep{0.0f, 0.0f, 0.0f}, nz);
 }
+// Without noise the env a reset leaves behind -- trainer moves + recover + the command-less cycle -- is a pure
+// function of the sample, so it can be prepared together with the sample (batched, off the critical path) and
+// a reset becomes a register copy plus the cycle's tick.  NextEpisode = that prepared state; with noise the
+// command-less cycle draws from the cycle at which the reset happens, and reset_apply stays.
+struct NextEpisode { float px, py, vx, vy, body, stamina, effort, recovery, capacity, bx, by, bvx, bvy; };
+S2D_DEV NextEpisode episode_prepare(const S2DHot& p, const S2DRare* __restrict__ rp, const S2DRare& r, uint32_t gid_lo,
+                                    uint32_t gid_hi, uint32_t key) {
+  const ResetSample o = reset_sample(p, r, gid_lo, gid_hi, key);
+  Env t{};
+  reset_apply<false>(p, rp, t, gid_lo, gid_hi, o, r.recover_init);
+  return NextEpisode{t.px, t.py, t.vx, t.vy, t.body, t.stamina, t.effort, t.recovery, t.capacity, t.bx, t.by, t.bvx, t.bvy};
+}
+S2D_DEV void episode_begin(Env& e, const NextEpisode& q) {
+  e.px = q.px; e.py = q.py; e.vx = q.vx; e.vy = q.vy; e.body = q.body;
+  e.stamina = q.stamina; e.effort = q.effort; e.recovery = q.recovery; e.capacity = q.capacity;
+  e.bx = q.bx; e.by = q.by; e.bvx = q.bvx; e.bvy = q.bvy;
+  e.step_number = 0;                                     // reach_ball_env.py:172
+  e.cycle = (int)((uint32_t)e.cycle + 1u);               // the command-less cycle (soccer_2d_env.py:190)
+}
 template <bool NOISE>
 S2D_DEV float env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo,
                         uint32_t gid_hi) {

@@ -179,19 +179,32 @@ S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int ki
 // rollout kernel draws them for many lanes at once -- a full wave at launch, then whenever
 // kRefillMin lanes have used theirs -- instead of running the Philox + rejection loop with one
 // or two active lanes each time an episode ends.
-struct PrepTile { float v[7][kWave]; };
+// Without noise the tile holds the whole post-reset state (NextEpisode, 13 words), with noise the sample (7).
+struct PrepTile { float v[13][kWave]; };
 static constexpr int kRefillMin = 8;
 
+template <bool NOISE>
 S2D_DEV void prep_fill(const S2DHot& p, const S2DRare* __restrict__ rp, PrepTile& t, int lane, const Env& e,
                        uint32_t gid_lo, uint32_t gid_hi) {
   const S2DRare r = *rp;
-  ResetSample o = reset_sample(p, r, gid_lo, gid_hi, reset_key(e));
-  t.v[0][lane] = o.px; t.v[1][lane] = o.py; t.v[2][lane] = o.body; t.v[3][lane] = o.bx;
-  t.v[4][lane] = o.by; t.v[5][lane] = o.bvx; t.v[6][lane] = o.bvy;
+  if (NOISE) {
+    const ResetSample o = reset_sample(p, r, gid_lo, gid_hi, reset_key(e));
+    t.v[0][lane] = o.px; t.v[1][lane] = o.py; t.v[2][lane] = o.body; t.v[3][lane] = o.bx;
+    t.v[4][lane] = o.by; t.v[5][lane] = o.bvx; t.v[6][lane] = o.bvy;
+  } else {
+    const NextEpisode q = episode_prepare(p, rp, r, gid_lo, gid_hi, reset_key(e));
+    t.v[0][lane] = q.px; t.v[1][lane] = q.py; t.v[2][lane] = q.vx; t.v[3][lane] = q.vy; t.v[4][lane] = q.body;
+    t.v[5][lane] = q.stamina; t.v[6][lane] = q.effort; t.v[7][lane] = q.recovery; t.v[8][lane] = q.capacity;
+    t.v[9][lane] = q.bx; t.v[10][lane] = q.by; t.v[11][lane] = q.bvx; t.v[12][lane] = q.bvy;
+  }
 }
-S2D_DEV ResetSample prep_take(const PrepTile& t, int lane) {
+S2D_DEV ResetSample prep_take_sample(const PrepTile& t, int lane) {
   return ResetSample{t.v[0][lane], t.v[1][lane], t.v[2][lane], t.v[3][lane], t.v[4][lane], t.v[5][lane],
                      t.v[6][lane]};
+}
+S2D_DEV NextEpisode prep_take_episode(const PrepTile& t, int lane) {
+  return NextEpisode{t.v[0][lane], t.v[1][lane], t.v[2][lane], t.v[3][lane], t.v[4][lane], t.v[5][lane], t.v[6][lane],
+                     t.v[7][lane], t.v[8][lane], t.v[9][lane], t.v[10][lane], t.v[11][lane], t.v[12][lane]};
 }
 
 // A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269) for the env held in registers, given the
@@ -210,8 +223,13 @@ S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, u
 #pragma unroll
     for (int k = 0; k < S2D_OBS_DIM; ++k) terminal_row[k] = ob.o[k];
     if (prep) {
-      if (!have_prep) prep_fill(p, rp, *prep, lane, e, gid_lo, gid_hi);   // episode shorter than the refill cadence
-      d2 = reset_apply<NOISE>(p, rp, e, gid_lo, gid_hi, prep_take(*prep, lane), p.recover_init);
+      if (!have_prep) prep_fill<NOISE>(p, rp, *prep, lane, e, gid_lo, gid_hi);   // episode shorter than the refill cadence
+      if (NOISE) {
+        d2 = reset_apply<true>(p, rp, e, gid_lo, gid_hi, prep_take_sample(*prep, lane), p.recover_init);
+      } else {
+        episode_begin(e, prep_take_episode(*prep, lane));
+        d2 = sq2(e.bx - e.px, e.by - e.py);              // the same expression the cycle ends with
+      }
       have_prep = false;
     } else {
       d2 = env_reset<NOISE>(p, rp, e, gid_lo, gid_hi);
@@ -351,13 +369,13 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
   float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
   U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
   bool have_prep = false;
-  if (active && p.auto_reset) { prep_fill(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }   // full wave
+  if (active && p.auto_reset) { prep_fill<NOISE>(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }   // full wave
   int n_missing = 0;                                       // wave-uniform: lanes whose prepared sample is used up
   int64_t row = 0;
   for (int t = 0; t < n_steps; ++t, row += n) {
     res = 0;
     if (n_missing >= kRefillMin) {                         // batched refill (wave-uniform counter: no ballot per cycle)
-      if (active && !have_prep) { prep_fill(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }
+      if (active && !have_prep) { prep_fill<NOISE>(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }
       n_missing = 0;
     }
     if (active) {
@@ -500,9 +518,16 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     }
     // the prepared sample of this env's next episode lives in registers here (VGPRs are plentiful in this
     // wave), refilled for >= kRefillMin lanes at a time like the LDS tile of the unified kernel
+    // (without noise: the whole post-reset state, see episode_prepare)
     bool have_prep = false;
     ResetSample nxt{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (active && p.auto_reset) { const S2DRare r = *rp; nxt = reset_sample(p, r, gl, gh, reset_key(e)); have_prep = true; }
+    NextEpisode nep{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto prepare = [&]() {
+      const S2DRare r = *rp;
+      if (NOISE) nxt = reset_sample(p, r, gl, gh, reset_key(e));
+      else nep = episode_prepare(p, rp, r, gl, gh, reset_key(e));
+    };
+    if (active && p.auto_reset) { prepare(); have_prep = true; }
     int cmd_cur = S2D_CMD_DASH, cmd_nxt = S2D_CMD_DASH;
     CmdPrep c_cur{0.0f, 0.0f, 0.0f}, c_nxt{0.0f, 0.0f, 0.0f};
     NoiseIn nz_cur{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, nz_nxt = nz_cur;
@@ -522,7 +547,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       if (s >= 2 && s <= n_steps + 1) {                    // step s - 2
         const int b = s & 1;
         if (n_missing >= kRefillMin) {                     // batched refill (scalar counter: no ballot in the hot path)
-          if (active && !have_prep) { const S2DRare r = *rp; nxt = reset_sample(p, r, gl, gh, reset_key(e)); have_prep = true; }
+          if (active && !have_prep) { prepare(); have_prep = true; }
           n_missing = 0;
         }
         if (active) {
@@ -539,8 +564,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           snap[b][WS_BVX][lane] = e.bvx; snap[b][WS_BVY][lane] = e.bvy;
           snap[b][WS_FLAGS][lane] = __int_as_float(flags);
           if (flags && p.auto_reset) {                     // rare
-            if (!have_prep) { const S2DRare r = *rp; nxt = reset_sample(p, r, gl, gh, reset_key(e)); }   // episode shorter than the refill cadence
-            reset_apply<NOISE>(p, rp, e, gl, gh, nxt, p.recover_init);
+            if (!have_prep) prepare();                     // episode shorter than the refill cadence
+            if (NOISE) reset_apply<true>(p, rp, e, gl, gh, nxt, p.recover_init);
+            else episode_begin(e, nep);
             have_prep = false;
             n_missing += __popcll(__ballot(true));         // lanes of this wave that consumed their sample now
             post[b][WS_PX][lane] = e.px; post[b][WS_PY][lane] = e.py; post[b][WS_BODY][lane] = e.body;
