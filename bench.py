@@ -237,7 +237,7 @@ def bench_match(args):
                            'envs_per_gpu': n, 'mode': args.mode, 'cycles_per_launch': per_launch_steps,
                            'player_steps_per_s': world * n * K * 22 / elapsed},
                 'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 's2d_match_rollout_kernel',
+                             'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic('match-' + args.mode, T, n), 'kernel': 's2d_match_rollout_kernel',
                              'launch_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg,
                              'algorithmic_bytes_per_env_step': alg / (n * per_launch_steps)},
                 'events': {'goals_left': st[1], 'goals_right': st[2], 'matches': st[3], 'kicks': st[4], 'tackles': st[5],

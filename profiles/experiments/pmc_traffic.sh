@@ -18,6 +18,7 @@ run() { # name, bench args...
 run rollout64k --steps 16 --warmup 1
 run rollout1m --steps 16 --warmup 1 --envs 1048576
 run step64k --steps 1024 --warmup 64 --mode step
+run match8k --task match --steps 8 --warmup 1
 python3 - <<PY
 import csv, glob, json, collections
 def avg(tag, counter, kern):
@@ -30,7 +31,8 @@ def avg(tag, counter, kern):
 rows = []
 for name, mode, fuse, envs, kern in (('rollout64k', 'rollout', 64, 65536, 'rollout_'),
                                      ('rollout1m', 'rollout', 64, 1048576, 'rollout_'),
-                                     ('step64k', 'step', 64, 65536, 'step_kernel')):
+                                     ('step64k', 'step', 64, 65536, 'step_kernel'),
+                                     ('match8k', 'match-rollout', 64, 8192, 'match_rollout')):
     f, nf = avg(name + '_fetch', 'FETCH_SIZE', kern)
     w, nw = avg(name + '_write', 'WRITE_SIZE', kern)
     if f is None or w is None: continue
