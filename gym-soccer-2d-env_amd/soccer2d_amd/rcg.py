@@ -27,6 +27,15 @@ class RcgWriter:
         self._mode = None
         self._score = None
 
+    def header(self, server_params=None, player_types=None):
+        """The parameter records rcssserver puts in front of a version-5 log: ``(server_param (name value)...)``
+        and one ``(player_type (id N)(name value)...)`` per heterogeneous type (idl/service.proto:1435-1732 names).
+        server_params: dict name -> value; player_types: list of dicts (index = type id)."""
+        if server_params:
+            self.f.write('(server_param ' + ''.join(f'({k} {float(v):.8g})' for k, v in server_params.items()) + ')\n')
+        for tid, t in enumerate(player_types or []):
+            self.f.write(f'(player_type (id {tid})' + ''.join(f'({k} {float(v):.8g})' for k, v in t.items()) + ')\n')
+
     def playmode(self, cycle, mode, side=0):
         name = playmode_name(mode, side)
         if name != self._mode:
@@ -40,11 +49,11 @@ class RcgWriter:
 
     def show(self, cycle, ball, players):
         """ball = (x,y,vx,vy); players = iterable of dicts(side 'l'|'r', unum, x,y,vx,vy,body,stamina,effort,
-        recovery,capacity[,tackling])."""
+        recovery,capacity[,tackling,type,goalie])."""
         parts = [f'(show {int(cycle)} ((b) {_f(ball[0])} {_f(ball[1])} {_f(ball[2])} {_f(ball[3])})']
         for p in players:
-            state = 0x1 | (0x1000 if p.get('tackling') else 0)       # STAND [| TACKLE]
-            parts.append(f"(({p['side']} {int(p['unum'])}) 0 {hex(state)} {_f(p['x'])} {_f(p['y'])} {_f(p['vx'])} {_f(p['vy'])} "
+            state = 0x1 | (0x8 if p.get('goalie') else 0) | (0x1000 if p.get('tackling') else 0)   # STAND [| GOALIE] [| TACKLE]
+            parts.append(f"(({p['side']} {int(p['unum'])}) {int(p.get('type', 0))} {hex(state)} {_f(p['x'])} {_f(p['y'])} {_f(p['vx'])} {_f(p['vy'])} "
                          f"{_f(p['body'])} 0 (v h 90) (s {_f(p['stamina'])} {_f(p['effort'])} {_f(p['recovery'])} "
                          f"{_f(p['capacity'])}) (c 0 0 0 0 0 0 0 0 0 0 0))")
         self.f.write(' '.join(parts) + ')\n')
@@ -71,6 +80,9 @@ def read_rcg(path):
             if line.startswith('(playmode'):
                 _, c, name = line.strip('()').split()
                 out.append(('playmode', int(c), name))
+            elif line.startswith('(server_param') or line.startswith('(player_type'):
+                kind = line[1:line.index(' ')]
+                out.append((kind, {k: float(v) for k, v in re.findall(r'\((\w+) ([-+\d.e]+)\)', line)}))
             elif line.startswith('(team'):
                 _, c, l, r, sl, sr = line.strip('()').split()
                 out.append(('team', int(c), l, r, int(sl), int(sr)))
@@ -78,12 +90,12 @@ def read_rcg(path):
                 c = int(line.split()[1])
                 b = re.search(r'\(\(b\) ([^)]*)\)', line).group(1).split()
                 pl = []
-                for m in re.finditer(r'\(\(([lr]) (\d+)\) \d+ (0x[0-9a-f]+) ([-\d.e]+) ([-\d.e]+) ([-\d.e]+) ([-\d.e]+) ([-\d.e]+) '
+                for m in re.finditer(r'\(\(([lr]) (\d+)\) (\d+) (0x[0-9a-f]+) ([-\d.e]+) ([-\d.e]+) ([-\d.e]+) ([-\d.e]+) ([-\d.e]+) '
                                      r'[-\d.e]+ \(v h 90\) \(s ([-\d.e]+) ([-\d.e]+) ([-\d.e]+) ([-\d.e]+)\)', line):
                     g = m.groups()
-                    pl.append(dict(side=g[0], unum=int(g[1]), state=int(g[2], 16), x=float(g[3]), y=float(g[4]), vx=float(g[5]),
-                                   vy=float(g[6]), body=float(g[7]), stamina=float(g[8]), effort=float(g[9]),
-                                   recovery=float(g[10]), capacity=float(g[11])))
+                    pl.append(dict(side=g[0], unum=int(g[1]), type=int(g[2]), state=int(g[3], 16), x=float(g[4]), y=float(g[5]),
+                                   vx=float(g[6]), vy=float(g[7]), body=float(g[8]), stamina=float(g[9]), effort=float(g[10]),
+                                   recovery=float(g[11]), capacity=float(g[12])))
                 out.append(('show', c, tuple(float(v) for v in b), pl))
     return out
 
@@ -91,7 +103,12 @@ def read_rcg(path):
 def record_match(engine, index, n_cycles, path, actions=None):
     """Step `engine` (MatchEngine) n_cycles times (random policy unless `actions(t)` returns a tensor) and log
     match `index` to `path`.  Host copies of ONE match per cycle: a debugging / viewing aid, not a hot path."""
+    from . import _capi_match as M
+    cfg = engine.cfg
+    types = list(cfg.player_type_id)[:22]
     with RcgWriter(path) as w:
+        w.header({n: getattr(cfg.sp, n) for n, _ in cfg.sp._fields_},
+                 [{f: getattr(cfg.player_types[t], f) for f in M.PLAYER_TYPE_FIELDS} for t in range(M.MATCH_PLAYER_TYPES)])
         for t in range(n_cycles):
             engine.step(actions(t) if actions else None)
             x, y, vx, vy, body = (a[index].tolist() for a in (engine.x, engine.y, engine.vx, engine.vy, engine.body))
@@ -102,7 +119,8 @@ def record_match(engine, index, n_cycles, path, actions=None):
             w.team(cyc, int(engine.score_left[index]), int(engine.score_right[index]))
             w.show(cyc, (x[22], y[22], vx[22], vy[22]),
                    [dict(side='l' if i < 11 else 'r', unum=i % 11 + 1, x=x[i], y=y[i], vx=vx[i], vy=vy[i], body=body[i],
-                         stamina=st[i], effort=ef[i], recovery=rc[i], capacity=cp[i], tackling=tk[i] > 0) for i in range(22)])
+                         stamina=st[i], effort=ef[i], recovery=rc[i], capacity=cp[i], tackling=tk[i] > 0, type=types[i],
+                         goalie=i % 11 == 0) for i in range(22)])
 
 
 def record_reach_ball(vec_env, index, n_cycles, path, actions=None):

@@ -58,6 +58,7 @@ def test_rcg_round_trip(tmp_path):
     rs = np.random.RandomState(0)
     frames = []
     with rcg.RcgWriter(path) as w:
+        w.header({'ball_decay': 0.94, 'effort_dec': 0.005}, [{'player_decay': 0.4}, {'player_decay': 0.4321987, 'kick_rand': 1e-05}])
         for c in range(1, 6):
             mode, side = (3, 1) if c < 3 else (2, 0)
             w.playmode(c, mode, side)
@@ -65,7 +66,7 @@ def test_rcg_round_trip(tmp_path):
             ball = tuple(round(float(v), 4) for v in rs.uniform(-30, 30, 4))
             pl = [dict(side='l' if i < 11 else 'r', unum=i % 11 + 1, x=round(float(rs.uniform(-50, 50)), 4), y=round(float(rs.uniform(-30, 30)), 4),
                        vx=0.25, vy=-0.5, body=round(float(rs.uniform(-180, 180)), 4), stamina=7945.0, effort=1.0, recovery=1.0,
-                       capacity=130555.0, tackling=(i == 4)) for i in range(22)]
+                       capacity=130555.0, tackling=(i == 4), type=i % 7, goalie=(i % 11 == 0)) for i in range(22)]
             w.show(c, ball, pl)
             frames.append((c, ball, pl))
     recs = rcg.read_rcg(path)
@@ -77,7 +78,10 @@ def test_rcg_round_trip(tmp_path):
         assert c == c2 and ball == pytest.approx(ball2) and len(pl2) == 22
         for a, b in zip(pl, pl2):
             assert (a['side'], a['unum']) == (b['side'], b['unum']) and a['x'] == pytest.approx(b['x']) and a['body'] == pytest.approx(b['body'])
-            assert bool(b['state'] & 0x1000) == a['tackling']
+            assert bool(b['state'] & 0x1000) == a['tackling'] and bool(b['state'] & 0x8) == a['goalie'] and b['type'] == a['type']
+    assert recs[0] == ('server_param', {'ball_decay': 0.94, 'effort_dec': 0.005})
+    assert recs[1] == ('player_type', {'id': 0.0, 'player_decay': 0.4})
+    assert recs[2] == ('player_type', {'id': 1.0, 'player_decay': 0.4321987, 'kick_rand': 1e-05})
     assert open(path).readline().strip() == 'ULG5'
 
 
@@ -101,6 +105,9 @@ def test_engine_states_as_protobuf_and_rcg(tmp_path):
     recs = rcg.read_rcg(tmp_path / 'match.rcg')
     shows = [r for r in recs if r[0] == 'show']
     assert len(shows) == 60 and all(len(r[3]) == 22 for r in shows)
+    assert recs[0][0] == 'server_param' and recs[0][1]['ball_decay'] == pytest.approx(eng.cfg.sp.ball_decay)
+    assert sum(r[0] == 'player_type' for r in recs) == 18
+    assert [p['type'] for p in shows[0][3]] == list(eng.cfg.player_type_id)[:22] and shows[0][3][11]['state'] & 0x8
     assert ('playmode', 1, 'kick_off_l') in recs or any(r[0] == 'playmode' for r in recs)
     sb = wire.match_state_bytes(eng, 3, 15)
     wmm = wire.decode(wire.decode(sb)[0][2])
