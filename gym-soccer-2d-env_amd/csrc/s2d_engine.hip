@@ -437,6 +437,20 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 // instead and is kept.
 enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_FLAGS, WS_WORDS };
 enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_NPM, WA_NPS, WA_NPC, WA_NBM, WA_NBS, WA_NBC, WA_NTU, WA_WORDS };   // command + prepared noise
+// Issue priority of the four role waves of a group (s_setprio): a SIMD holds one wave of each role (of four
+// different groups, profiles/r01/wave_placement.txt), and the arbiter should prefer them in the order of their
+// slack -- simulate (none), agent, ball, policy (half a cycle).  Measured on one device, 256 launches:
+// 1/0/0/0 57.0 G env-steps/s, 2/1/0/0 58.5, 2/1/1/0 59.9, 3/1/2/0 60.5, 3/2/2/0 59.7, 3/3/1/0 59.8,
+// 3/2/1/0 60.9 (noise on: 43.5 -> 47.5).  Overridable for experiments.
+#ifndef S2D_PRIO_S
+#define S2D_PRIO_S 3
+#endif
+#ifndef S2D_PRIO_A
+#define S2D_PRIO_A 2
+#endif
+#ifndef S2D_PRIO_B
+#define S2D_PRIO_B 1
+#endif
 static constexpr int kWsBlock = 4 * kWave;
 
 template <int MODE, bool NOISE>
@@ -504,7 +518,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     }
   } else if (role == 1) {
     // ------------------------------------------------------------------ S-wave
-    __builtin_amdgcn_s_setprio(1);                         // the simulate wave is the critical stream of the group (+3 %)
+    __builtin_amdgcn_s_setprio(S2D_PRIO_S);                // the critical stream of the group
     const S2DHot p = hot_in_vgprs(p_sgpr);
     Env e;
     uint32_t gl = 0, gh = 0;
@@ -596,6 +610,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       S[F_CYCLE * stride + i] = __int_as_float(e.cycle);
     }
   } else if (role == 2) {
+    __builtin_amdgcn_s_setprio(S2D_PRIO_A);
     // ------------------------------------------------------------------ A-wave (player half, reward, labels)
     const S2DHot& p = p_sgpr;
     float prev_dist = 0.0f, prev_angle = 0.0f;
@@ -673,6 +688,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n * (unsigned long long)n_steps);
   } else {
     // ------------------------------------------------------------------ B-wave (ball half, observation stream)
+    __builtin_amdgcn_s_setprio(S2D_PRIO_B);
     const S2DHot& p = p_sgpr;
     float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;

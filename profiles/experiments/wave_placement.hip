@@ -50,6 +50,20 @@ int main(int argc, char** argv) {
     for (int b = 0; b < blocks; ++b) cnt[(h[2 * (b * wpb + k)] >> 4) & 3]++;
     printf("  wave %d of a workgroup -> SIMD0 %d, SIMD1 %d, SIMD2 %d, SIMD3 %d\n", k, cnt[0], cnt[1], cnt[2], cnt[3]);
   }
+  // per CU: how many waves with the SAME index k share a SIMD (k = role in the pipeline kernel), and the TG_ID values
+  std::map<std::tuple<int, int, int, int, int>, int> same_k;  // xcc, se, cu, simd, k
+  std::map<std::tuple<int, int, int>, std::map<int, int>> tg_of_cu;
+  for (int w = 0; w < waves; ++w) {
+    uint32_t hw = h[2 * w], xcc = h[2 * w + 1] & 0xf;
+    int simd = (hw >> 4) & 3, cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7, tg = (hw >> 16) & 0xf;
+    same_k[{(int)xcc, se * 2 + sh, cu, simd, w % wpb}]++;
+    if (w % wpb == 0) tg_of_cu[{(int)xcc, se * 2 + sh, cu}][tg]++;
+  }
+  std::map<int, int> hist_same, hist_tg;
+  for (auto& kv : same_k) hist_same[kv.second]++;
+  for (auto& kv : hist_same) printf("  (SIMD, wave index) pairs holding %d waves of that index: %d\n", kv.first, kv.second);
+  for (auto& kv : tg_of_cu) { int key = 0; for (auto& t : kv.second) key |= 1 << t.first; hist_tg[key]++; }
+  for (auto& kv : hist_tg) printf("  CUs whose workgroups have TG_ID set 0x%x: %d\n", kv.first, kv.second);
   std::map<int, int> hist_simd, hist_cu;
   for (auto& kv : per_simd) hist_simd[kv.second]++;
   for (auto& kv : per_cu) hist_cu[kv.second]++;
