@@ -589,6 +589,16 @@ S2D_DEV void episode_begin(Env& e, const NextEpisode& q) {
   e.step_number = 0;                                     // reach_ball_env.py:172
   e.cycle = (int)((uint32_t)e.cycle + 1u);               // the command-less cycle (soccer_2d_env.py:190)
 }
+// The observation a reset returns and the carry it seeds (reach_ball_env.py:163-168) are functions of that
+// prepared state alone, so they are prepared with it: o[0..9] = the new episode's first row, dist / rel = the carry.
+struct FirstObs { float o[S2D_OBS_DIM], dist, rel; };
+S2D_DEV FirstObs first_obs(const S2DHot& p, const NextEpisode& q) {
+  FirstObs f;
+  observe_ball(p, q.bx, q.by, q.bvx, q.bvy, f.o);
+  f.rel = observe_player(p, q.px, q.py, q.body, q.bx, q.by, f.o);
+  f.dist = hypot2(q.bx - q.px, q.by - q.py);
+  return f;
+}
 template <bool NOISE>
 S2D_DEV float env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo,
                         uint32_t gid_hi) {

@@ -180,7 +180,7 @@ S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int ki
 // kRefillMin lanes have used theirs -- instead of running the Philox + rejection loop with one
 // or two active lanes each time an episode ends.
 // Without noise the tile holds the whole post-reset state (NextEpisode, 13 words), with noise the sample (7).
-struct PrepTile { float v[13][kWave]; };
+struct PrepTile { float v[13 + S2D_OBS_DIM + 2][kWave]; };   // ResetSample | NextEpisode + FirstObs
 static constexpr int kRefillMin = 8;
 
 template <bool NOISE>
@@ -196,6 +196,10 @@ S2D_DEV void prep_fill(const S2DHot& p, const S2DRare* __restrict__ rp, PrepTile
     t.v[0][lane] = q.px; t.v[1][lane] = q.py; t.v[2][lane] = q.vx; t.v[3][lane] = q.vy; t.v[4][lane] = q.body;
     t.v[5][lane] = q.stamina; t.v[6][lane] = q.effort; t.v[7][lane] = q.recovery; t.v[8][lane] = q.capacity;
     t.v[9][lane] = q.bx; t.v[10][lane] = q.by; t.v[11][lane] = q.bvx; t.v[12][lane] = q.bvy;
+    const FirstObs f = first_obs(p, q);
+#pragma unroll
+    for (int k = 0; k < S2D_OBS_DIM; ++k) t.v[13 + k][lane] = f.o[k];
+    t.v[13 + S2D_OBS_DIM][lane] = f.dist; t.v[14 + S2D_OBS_DIM][lane] = f.rel;
   }
 }
 S2D_DEV ResetSample prep_take_sample(const PrepTile& t, int lane) {
@@ -224,13 +228,15 @@ S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, u
     for (int k = 0; k < S2D_OBS_DIM; ++k) terminal_row[k] = ob.o[k];
     if (prep) {
       if (!have_prep) prep_fill<NOISE>(p, rp, *prep, lane, e, gid_lo, gid_hi);   // episode shorter than the refill cadence
-      if (NOISE) {
-        d2 = reset_apply<true>(p, rp, e, gid_lo, gid_hi, prep_take_sample(*prep, lane), p.recover_init);
-      } else {
-        episode_begin(e, prep_take_episode(*prep, lane));
-        d2 = sq2(e.bx - e.px, e.by - e.py);              // the same expression the cycle ends with
-      }
       have_prep = false;
+      if (!NOISE) {                            // state, first observation and carry were prepared together
+        episode_begin(e, prep_take_episode(*prep, lane));
+#pragma unroll
+        for (int k = 0; k < S2D_OBS_DIM; ++k) ob.o[k] = prep->v[13 + k][lane];
+        e.prev_dist = prep->v[13 + S2D_OBS_DIM][lane]; e.prev_angle = prep->v[14 + S2D_OBS_DIM][lane];
+        return;
+      }
+      d2 = reset_apply<true>(p, rp, e, gid_lo, gid_hi, prep_take_sample(*prep, lane), p.recover_init);
     } else {
       d2 = env_reset<NOISE>(p, rp, e, gid_lo, gid_hi);
     }
@@ -436,6 +442,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 // Used for small batches; with more env groups per SIMD the unified kernel overlaps whole waves
 // instead and is kept.
 enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_FLAGS, WS_WORDS };
+enum { WP_DIST = S2D_OBS_DIM, WP_REL, WP_WORDS };             // post[] rows without noise
 enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_NPM, WA_NPS, WA_NPC, WA_NBM, WA_NBS, WA_NBC, WA_NTU, WA_WORDS };   // command + prepared noise
 // Issue priority of the four role waves of a group (s_setprio): a SIMD holds one wave of each role (of four
 // different groups, profiles/r01/wave_placement.txt), and the arbiter should prefer them in the order of their
@@ -461,7 +468,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
                                                                         RolloutOut ro, StepOut o) {
   __shared__ float act[2][WA_WORDS][kWave];                // decoded command of step t, double-buffered
   __shared__ float snap[2][WS_WORDS][kWave];               // post-cycle snapshot of step t, double-buffered
-  __shared__ float post[2][WS_FLAGS][kWave];               // post-reset state of the envs that finished
+  // envs that finished: with noise their post-reset state (WS_PX..WS_BVY), without noise the prepared first
+  // observation of the new episode and the carry it seeds (FirstObs: o[0..9], dist, rel)
+  __shared__ float post[2][WP_WORDS][kWave];
   __shared__ __attribute__((aligned(16))) float tile[2][kObsTile];   // observation rows of step t, double-buffered
   const int lane = threadIdx.x & (kWave - 1);
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 agent, 3 ball
@@ -536,10 +545,11 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     bool have_prep = false;
     ResetSample nxt{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     NextEpisode nep{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    FirstObs fo{};
     auto prepare = [&]() {
       const S2DRare r = *rp;
       if (NOISE) nxt = reset_sample(p, r, gl, gh, reset_key(e));
-      else nep = episode_prepare(p, rp, r, gl, gh, reset_key(e));
+      else { nep = episode_prepare(p, rp, r, gl, gh, reset_key(e)); fo = first_obs(p, nep); }
     };
     if (active && p.auto_reset) { prepare(); have_prep = true; }
     int cmd_cur = S2D_CMD_DASH, cmd_nxt = S2D_CMD_DASH;
@@ -583,9 +593,15 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
             else episode_begin(e, nep);
             have_prep = false;
             n_missing += __popcll(__ballot(true));         // lanes of this wave that consumed their sample now
-            post[b][WS_PX][lane] = e.px; post[b][WS_PY][lane] = e.py; post[b][WS_BODY][lane] = e.body;
-            post[b][WS_BX][lane] = e.bx; post[b][WS_BY][lane] = e.by;
-            post[b][WS_BVX][lane] = e.bvx; post[b][WS_BVY][lane] = e.bvy;
+            if (NOISE) {
+              post[b][WS_PX][lane] = e.px; post[b][WS_PY][lane] = e.py; post[b][WS_BODY][lane] = e.body;
+              post[b][WS_BX][lane] = e.bx; post[b][WS_BY][lane] = e.by;
+              post[b][WS_BVX][lane] = e.bvx; post[b][WS_BVY][lane] = e.bvy;
+            } else {
+#pragma unroll
+              for (int k = 0; k < S2D_OBS_DIM; ++k) post[b][k][lane] = fo.o[k];
+              post[b][WP_DIST][lane] = fo.dist; post[b][WP_REL][lane] = fo.rel;
+            }
           }
         }
       }
@@ -644,10 +660,16 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           if (flags && p.auto_reset) {                     // rare: terminal row, then the new episode's first obs
 #pragma unroll
             for (int k = 0; k < 4; ++k) term_row[k] = oa[k];
-            px = post[b][WS_PX][lane]; py = post[b][WS_PY][lane]; body = post[b][WS_BODY][lane];
-            bx = post[b][WS_BX][lane]; by = post[b][WS_BY][lane];
-            prev_angle = observe_player(p, px, py, body, bx, by, oa);      // reach_ball_env.py:166 carry seeded
-            prev_dist = hypot2(bx - px, by - py);
+            if (NOISE) {
+              px = post[b][WS_PX][lane]; py = post[b][WS_PY][lane]; body = post[b][WS_BODY][lane];
+              bx = post[b][WS_BX][lane]; by = post[b][WS_BY][lane];
+              prev_angle = observe_player(p, px, py, body, bx, by, oa);    // reach_ball_env.py:166 carry seeded
+              prev_dist = hypot2(bx - px, by - py);
+            } else {                                       // prepared with the episode by the simulate wave
+#pragma unroll
+              for (int k = 0; k < 4; ++k) oa[k] = post[b][k][lane];
+              prev_dist = post[b][WP_DIST][lane]; prev_angle = post[b][WP_REL][lane];
+            }
           }
           if (ro.reward) ro.reward[row + i] = reward;
           if (ro.done) ro.done[row + i] = (uint8_t)done;
@@ -704,9 +726,14 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         if (flags && p.auto_reset) {                       // rare: terminal row, then the new episode's first obs
 #pragma unroll
           for (int k = 4; k < S2D_OBS_DIM; ++k) term_row[k] = ob6[k];
-          bx = post[b][WS_BX][lane]; by = post[b][WS_BY][lane];
-          bvx = post[b][WS_BVX][lane]; bvy = post[b][WS_BVY][lane];
-          observe_ball(p, bx, by, bvx, bvy, ob6);
+          if (NOISE) {
+            bx = post[b][WS_BX][lane]; by = post[b][WS_BY][lane];
+            bvx = post[b][WS_BVX][lane]; bvy = post[b][WS_BVY][lane];
+            observe_ball(p, bx, by, bvx, bvy, ob6);
+          } else {
+#pragma unroll
+            for (int k = 4; k < S2D_OBS_DIM; ++k) ob6[k] = post[b][k][lane];
+          }
         }
         if (ro.obs) {
           float* t = &tile[b][lane * S2D_OBS_DIM];
