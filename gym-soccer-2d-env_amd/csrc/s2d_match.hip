@@ -65,6 +65,7 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
   float goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
   float catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle, goalie_max_moves;
+  int after_goal_wait;
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
 };
@@ -259,7 +260,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   if (!is_player || o.tackle > 0 || mode0 == S2D_GM_TIME_OVER) cmd = S2D_MCMD_NONE;
   U4 nz{0, 0, 0, 0}, nk{0, 0, 0, 0};
   if (p.noise) { nz = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, (uint32_t)l); nk = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, 32u + (uint32_t)l); }
-  const bool may_touch = !is_setplay(mode0) || side_of(l) == side0;
+  const bool may_touch = !is_setplay(mode0) || (side_of(l) == side0 && mode0 != S2D_GM_AFTER_GOAL);   // after a goal the ball is dead
   bool caught = false, hold_moved = false;
   if (cmd == S2D_MCMD_DASH) m_dash(p, pt, l, o, a, bb, ax, ay);
   else if (cmd == S2D_MCMD_TURN) m_turn(p, pt[PT_INERTIA][l], o, a, rnd_u01(nz.z));
@@ -276,7 +277,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
     // while holding a caught ball, goalie_max_moves times inside the own penalty area
     const float sgn = side_of(l) == SIDE_LEFT ? 1.0f : -1.0f;
     const bool holds = mode0 == S2D_GM_FREE_KICK && g.holder == l + 1 && g.moves > 0;
-    if (mode0 == S2D_GM_KICK_OFF || holds) {
+    if (mode0 == S2D_GM_KICK_OFF || mode0 == S2D_GM_AFTER_GOAL || holds) {
       float tx = clampf(a, -p.half_l, holds ? -p.pen_x : 0.0f);
       float ty = holds ? clampf(bb, -p.pen_half_w, p.pen_half_w) : clampf(bb, -p.half_w, p.half_w);
       o.x = sgn * tx; o.y = sgn * ty; o.vx = 0.0f; o.vy = 0.0f;
@@ -403,7 +404,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   // ---- 4. set play: opponents keep their distance
   {
     float bxn = hbcast(o.x, BALL), byn = hbcast(o.y, BALL);
-    if (is_setplay(mode0) && is_player && side_of(l) != side0) {
+    if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && is_player && side_of(l) != side0) {
       float dx = o.x - bxn, dy = o.y - byn, d = hypot2(dx, dy);
       if (d < p.free_kick_distance) {
         float ux, uy;
@@ -430,7 +431,14 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   bool place_ball = false; float pbx = 0.0f, pby = 0.0f;     // ball placement requested
   bool recover_half = false;
   if (mode0 != S2D_GM_TIME_OVER) {
-    if (is_setplay(mode0)) {
+    if (mode0 == S2D_GM_AFTER_GOAL) {                      // dead ball until the wait is over, then the conceding side kicks off
+      g.timer += 1;
+      if (g.timer >= p.after_goal_wait) {
+        const int ks = other_side(side0);
+        restart_form = true; form_side = ks;
+        g.mode = S2D_GM_KICK_OFF; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+      }
+    } else if (is_setplay(mode0)) {
       if (any_kick) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; }
       else { g.timer += 1; if (g.timer > p.drop_ball_time) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; } }
     }
@@ -460,12 +468,14 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
         if (in_area) { g.holder = caught_by + 1; g.moves = p.goalie_max_moves; }
       } else if (bx > p.half_l && fabsf(by) < p.goal_half_width) {
         g.score_l += 1; g.reward = 1.0f; if (is_ball) cnt.goals_l++;
-        restart_form = true; form_side = SIDE_RIGHT;
-        g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_RIGHT; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        if (p.after_goal_wait > 0) { place_ball = true; pbx = bx; pby = by; g.mode = S2D_GM_AFTER_GOAL; g.mode_side = SIDE_LEFT; }
+        else { restart_form = true; form_side = SIDE_RIGHT; g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_RIGHT; }
       } else if (bx < -p.half_l && fabsf(by) < p.goal_half_width) {
         g.score_r += 1; g.reward = -1.0f; if (is_ball) cnt.goals_r++;
-        restart_form = true; form_side = SIDE_LEFT;
-        g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_LEFT; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        if (p.after_goal_wait > 0) { place_ball = true; pbx = bx; pby = by; g.mode = S2D_GM_AFTER_GOAL; g.mode_side = SIDE_RIGHT; }
+        else { restart_form = true; form_side = SIDE_LEFT; g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_LEFT; }
       } else if (fabsf(bx) > p.half_l || fabsf(by) > p.half_w) {
         if (is_ball) cnt.outs++;
         int toucher = g.last_touch == SIDE_NONE ? SIDE_LEFT : g.last_touch;
@@ -847,7 +857,7 @@ S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
   m.tackle_cycles = 10; m.half_time_cycles = 3000; m.nr_normal_halfs = 2; m.drop_ball_time = 100; m.use_offside = 1;
   m.catch_ban_cycle = 5; m.catchable_area_l = 1.2; m.catch_area_w = 1.0; m.catch_probability = 1.0;
   m.max_catch_angle = 90.0; m.min_catch_angle = -90.0; m.penalty_area_length = 16.5; m.penalty_area_half_width = 20.16;
-  m.goalie_max_moves = 2;
+  m.goalie_max_moves = 2; m.after_goal_wait = 50;
   c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
   for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) c->player_types[t] = m_default_type(c->sp, m);   // homogeneous
 }
@@ -862,7 +872,7 @@ S2D_API int s2d_match_validate_config(const S2DMatchConfig* c) {
   if (c->mp.half_time_cycles < 1 || c->mp.nr_normal_halfs < 1) return mfail(S2D_EINVAL, "half_time_cycles and nr_normal_halfs must be >= 1");
   if (c->mp.tackle_cycles < 0 || c->mp.drop_ball_time < 0) return mfail(S2D_EINVAL, "tackle_cycles / drop_ball_time must be >= 0");
   if (c->env_id_offset < 0) return mfail(S2D_EINVAL, "env_id_offset must be >= 0");
-  if (c->mp.goalie_max_moves < 0) return mfail(S2D_EINVAL, "goalie_max_moves must be >= 0");
+  if (c->mp.goalie_max_moves < 0 || c->mp.after_goal_wait < 0) return mfail(S2D_EINVAL, "goalie_max_moves / after_goal_wait must be >= 0");
   if (c->mp.catch_ban_cycle < 0 || !(c->mp.catch_area_w > 0) || !(c->mp.catchable_area_l > 0))
     return mfail(S2D_EINVAL, "catch_ban_cycle must be >= 0, catch_area_w and catchable_area_l > 0");
   for (int i = 0; i < S2D_MATCH_PLAYERS; ++i)
@@ -916,7 +926,7 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   p.pen_x = (float)(s.pitch_half_length - m.penalty_area_length); p.pen_half_w = (float)m.penalty_area_half_width;
   p.tackle_cycles = m.tackle_cycles; p.half_time_cycles = m.half_time_cycles;
   p.nr_normal_halfs = m.nr_normal_halfs; p.drop_ball_time = m.drop_ball_time; p.use_offside = m.use_offside;
-  p.catch_ban_cycle = m.catch_ban_cycle; p.goalie_max_moves = m.goalie_max_moves;
+  p.catch_ban_cycle = m.catch_ban_cycle; p.goalie_max_moves = m.goalie_max_moves; p.after_goal_wait = m.after_goal_wait;
   p.auto_reset = c.auto_reset; p.noise = c.noise;
   p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
   p.gid_lo = (uint32_t)(uint64_t)c.env_id_offset; p.gid_hi = (uint32_t)((uint64_t)c.env_id_offset >> 32);

@@ -6,8 +6,8 @@ from . import _capi
 MATCH_PLAYERS, MATCH_SLOTS, MATCH_BALL, MATCH_OBJ_WORDS = 22, 24, 22, 5
 MCMD_NONE, MCMD_DASH, MCMD_TURN, MCMD_KICK, MCMD_TACKLE, MCMD_CATCH, MCMD_MOVE = 0, 1, 2, 3, 4, 5, 6
 MATCH_PLAYER_TYPES, GOALIE_LEFT, GOALIE_RIGHT = 18, 0, 11
-GM_TIME_OVER, GM_PLAY_ON, GM_KICK_OFF, GM_KICK_IN, GM_FREE_KICK, GM_CORNER_KICK, GM_GOAL_KICK, GM_OFF_SIDE = 1, 2, 3, 4, 5, 6, 7, 9
-GM_NAMES = {1: 'TimeOver', 2: 'PlayOn', 3: 'KickOff_', 4: 'KickIn_', 5: 'FreeKick_', 6: 'CornerKick_', 7: 'GoalKick_', 9: 'OffSide_'}
+GM_TIME_OVER, GM_PLAY_ON, GM_KICK_OFF, GM_KICK_IN, GM_FREE_KICK, GM_CORNER_KICK, GM_GOAL_KICK, GM_AFTER_GOAL, GM_OFF_SIDE = 1, 2, 3, 4, 5, 6, 7, 8, 9
+GM_NAMES = {1: 'TimeOver', 2: 'PlayOn', 3: 'KickOff_', 4: 'KickIn_', 5: 'FreeKick_', 6: 'CornerKick_', 7: 'GoalKick_', 8: 'AfterGoal_', 9: 'OffSide_'}
 
 
 class S2DMatchParams(C.Structure):
@@ -19,7 +19,7 @@ class S2DMatchParams(C.Structure):
             'tackle_cycles', 'half_time_cycles', 'nr_normal_halfs', 'drop_ball_time', 'use_offside', 'catch_ban_cycle')] + [
                 (n, C.c_double) for n in ('catchable_area_l', 'catch_area_w', 'catch_probability', 'max_catch_angle',
                                           'min_catch_angle', 'penalty_area_length', 'penalty_area_half_width')] + [
-                    ('goalie_max_moves', C.c_int32), ('reserved1', C.c_int32)]
+                    ('goalie_max_moves', C.c_int32), ('after_goal_wait', C.c_int32)]
 
 
 PLAYER_TYPE_FIELDS = ('player_speed_max', 'stamina_inc_max', 'player_decay', 'inertia_moment', 'dash_power_rate',

@@ -38,7 +38,7 @@ enum { S2D_MCMD_NONE = 0, S2D_MCMD_DASH = 1, S2D_MCMD_TURN = 2, S2D_MCMD_KICK = 
 /* GameModeType values used (idl/service.proto:267-301); the taking side is in mode_side */
 enum {
   S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4, S2D_GM_FREE_KICK = 5,
-  S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_OFF_SIDE = 9
+  S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_AFTER_GOAL = 8, S2D_GM_OFF_SIDE = 9
 };
 
 /* ServerParam fields the match needs beyond S2DServerParams (same names as idl/service.proto:
@@ -54,7 +54,9 @@ typedef struct S2DMatchParams {
    * PlayerType.catchable_area_l_stretch long, catch_area_w wide, rooted at the goalie */
   double catchable_area_l, catch_area_w, catch_probability, max_catch_angle, min_catch_angle;  /* 1.2 1 1 90 -90 */
   double penalty_area_length, penalty_area_half_width;                             /* 16.5 20.16 */
-  int32_t goalie_max_moves, reserved1;    /* 2: Move commands a goalie may issue while he holds a caught ball */
+  int32_t goalie_max_moves;               /* 2: Move commands a goalie may issue while he holds a caught ball */
+  int32_t after_goal_wait;                /* 50: cycles of AfterGoal_ (mode side = the scorer) between a goal and the
+                                             kick-off formation; 0 = kick-off at once */
 } S2DMatchParams;
 
 /* PlayerType (idl/service.proto:1697-1732): the members that enter the dynamics.  Type 0 is the

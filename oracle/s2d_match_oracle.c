@@ -38,6 +38,7 @@ typedef struct MP {
   REAL tackle_dist, tackle_back_dist, tackle_width, tackle_power_rate, max_tackle_power, max_back_tackle_power;
   REAL goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
   int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle, goalie_max_moves;
+  int after_goal_wait;
   REAL catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
   /* heterogeneous players: the parameters of every player slot's PlayerType (idl/service.proto:1697-1732) */
@@ -89,6 +90,7 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   p->tackle_cycles = m->tackle_cycles; p->half_time_cycles = m->half_time_cycles;
   p->nr_normal_halfs = m->nr_normal_halfs; p->drop_ball_time = m->drop_ball_time; p->use_offside = m->use_offside;
   p->catch_ban_cycle = m->catch_ban_cycle; p->goalie_max_moves = m->goalie_max_moves;
+  p->after_goal_wait = m->after_goal_wait;
   p->catch_half_w = (REAL)(m->catch_area_w * 0.5); p->catch_probability = (REAL)m->catch_probability;
   p->max_catch_angle = (REAL)m->max_catch_angle; p->min_catch_angle = (REAL)m->min_catch_angle;
   p->pen_x = (REAL)(s->pitch_half_length - m->penalty_area_length); p->pen_half_w = (REAL)m->penalty_area_half_width;
@@ -304,7 +306,8 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     if (o->tackle > 0 || mode0 == S2D_GM_TIME_OVER) cmd = S2D_MCMD_NONE;
     uint32_t nz[4] = {0, 0, 0, 0}, nk[4] = {0, 0, 0, 0};
     if (p->noise) { draw(p->seed, gid, cyc, ST_NOISE, (uint32_t)i, nz); draw(p->seed, gid, cyc, ST_NOISE, 32u + (uint32_t)i, nk); }
-    int may_touch = !is_setplay(mode0) || side_of(i) == side0;      /* set play: only the taking side plays the ball */
+    /* set play: only the taking side plays the ball; after a goal nobody does */
+    int may_touch = !is_setplay(mode0) || (side_of(i) == side0 && mode0 != S2D_GM_AFTER_GOAL);
     if (cmd == S2D_MCMD_DASH) m_dash(p, t, o, a, bb, &ax[i], &ay[i]);
     else if (cmd == S2D_MCMD_TURN) m_turn(p, t, o, a, rnd_u01(nz[2]));
     else if (cmd == S2D_MCMD_CATCH) {
@@ -320,7 +323,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
        * half; while holding a caught ball, goalie_max_moves times inside the own penalty area */
       REAL sgn = side_of(i) == SIDE_LEFT ? R(1.0) : R(-1.0);
       int holds = mode0 == S2D_GM_FREE_KICK && m->ball_holder == i + 1 && m->goalie_moves > 0;
-      if (mode0 == S2D_GM_KICK_OFF || holds) {
+      if (mode0 == S2D_GM_KICK_OFF || mode0 == S2D_GM_AFTER_GOAL || holds) {
         REAL tx = clampr(a, -p->half_l, holds ? -p->pen_x : R(0.0));
         REAL ty = holds ? clampr(bb, -p->pen_half_w, p->pen_half_w) : clampr(bb, -p->half_w, p->half_w);
         o->x = sgn * tx; o->y = sgn * ty; o->vx = R(0.0); o->vy = R(0.0);
@@ -410,8 +413,8 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     coll_touch_side = side_of(touch_player);
     m->last_touch_side = coll_touch_side;
   }
-  /* 4. set play: opponents keep free_kick_distance from the ball */
-  if (is_setplay(mode0)) {
+  /* 4. set play: opponents keep free_kick_distance from the ball (nobody has to after a goal) */
+  if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL) {
     for (int i = 0; i < NP; ++i) if (side_of(i) != side0) {
       Obj *o = &m->o[i];
       REAL dx = o->x - b->x, dy = o->y - b->y, d = hypot2(dx, dy);
@@ -425,7 +428,14 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   /* 5. referee */
   m->cycle = (int32_t)((uint32_t)m->cycle + 1u);
   if (mode0 != S2D_GM_TIME_OVER) {
-    if (is_setplay(mode0)) {
+    if (mode0 == S2D_GM_AFTER_GOAL) {                   /* the ball is dead until the wait is over, then the conceding side kicks off */
+      m->setplay_timer += 1;
+      if (m->setplay_timer >= p->after_goal_wait) {
+        int ks = other_side(side0);
+        place_formation(m, ks);
+        restart(m, S2D_GM_KICK_OFF, ks, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
+      }
+    } else if (is_setplay(mode0)) {
       if (any_kick) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; }
       else { m->setplay_timer += 1; if (m->setplay_timer > p->drop_ball_time) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; } }
     }
@@ -464,12 +474,14 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
         if (in_area) { m->ball_holder = caught_by + 1; m->goalie_moves = p->goalie_max_moves; }
       } else if (bx > p->half_l && R(fabs)(by) < p->goal_half_width) {       /* goal for the left team */
         m->score_left += 1; m->reward_left = R(1.0); st->v[1]++;
-        place_formation(m, SIDE_RIGHT);
-        restart(m, S2D_GM_KICK_OFF, SIDE_RIGHT, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
+        if (p->after_goal_wait > 0) restart(m, S2D_GM_AFTER_GOAL, SIDE_LEFT, bx, by);   /* the ball rests in the net */
+        else { place_formation(m, SIDE_RIGHT); restart(m, S2D_GM_KICK_OFF, SIDE_RIGHT, R(0.0), R(0.0)); }
+        m->last_touch_side = SIDE_NONE;
       } else if (bx < -p->half_l && R(fabs)(by) < p->goal_half_width) {      /* goal for the right team */
         m->score_right += 1; m->reward_left = R(-1.0); st->v[2]++;
-        place_formation(m, SIDE_LEFT);
-        restart(m, S2D_GM_KICK_OFF, SIDE_LEFT, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
+        if (p->after_goal_wait > 0) restart(m, S2D_GM_AFTER_GOAL, SIDE_RIGHT, bx, by);
+        else { place_formation(m, SIDE_LEFT); restart(m, S2D_GM_KICK_OFF, SIDE_LEFT, R(0.0), R(0.0)); }
+        m->last_touch_side = SIDE_NONE;
       } else if (R(fabs)(bx) > p->half_l || R(fabs)(by) > p->half_w) {       /* ball out */
         st->v[7]++;
         int toucher = m->last_touch_side == SIDE_NONE ? SIDE_LEFT : m->last_touch_side;

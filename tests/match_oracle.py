@@ -15,7 +15,7 @@ MATCH_DEFAULTS = dict(
     goal_width=14.02, offside_active_area_size=2.5, free_kick_distance=9.15,
     tackle_cycles=10, half_time_cycles=3000, nr_normal_halfs=2, drop_ball_time=100, use_offside=1, catch_ban_cycle=5,
     catchable_area_l=1.2, catch_area_w=1.0, catch_probability=1.0, max_catch_angle=90.0, min_catch_angle=-90.0,
-    penalty_area_length=16.5, penalty_area_half_width=20.16, goalie_max_moves=2, reserved1=0)
+    penalty_area_length=16.5, penalty_area_half_width=20.16, goalie_max_moves=2, after_goal_wait=50)
 
 
 def default_player_type(sp, mp):

@@ -219,6 +219,42 @@ def test_match_heterogeneous_types_and_catch_parity():
     assert free_kicks > 0 and moves > 0
 
 
+def test_match_after_goal_pause_parity():
+    """Goals forced in a third of the matches (ball shot into either net): AfterGoal_ for after_goal_wait cycles with the
+    ball dead, kicks of the scorers dropped, Move commands of both sides honoured, then formation + kick-off for the
+    conceding side -- every word equal to the oracle after every cycle; after_goal_wait = 0 keeps the immediate restart."""
+    from soccer2d_amd._capi_match import GM_AFTER_GOAL, GM_KICK_OFF, MCMD_KICK, MCMD_MOVE
+    for wait in (7, 0, 50):
+        n, T = 37, 75
+        eng, orc = _pair(n, after_goal_wait=wait, noise=True, half_time_cycles=60)
+        rs = np.random.RandomState(wait)
+        seen_after = seen_kickoff_after = 0
+        for t in range(T):
+            a = orc.random_actions()
+            mode = orc.get('mode')
+            for e in np.nonzero(mode == GM_AFTER_GOAL)[0]:
+                for pl in rs.choice(22, 4, replace=False):
+                    a[e, pl] = [MCMD_MOVE, rs.uniform(-60, 10), rs.uniform(-40, 40)] if rs.rand() < 0.5 else [MCMD_KICK, 100.0, 0.0]
+            if t in (2, 30):                                             # shoot: ball one step from a goal line
+                for e in range(t % 3, n, 3):
+                    sx = 1.0 if (e + t) % 2 else -1.0
+                    orc.set_obj(e, 22, x=sx * 52.0, y=3.0, vx=sx * 1.5, vy=0.0)
+                    eng.x[e, 22] = sx * 52.0; eng.y[e, 22] = 3.0; eng.vx[e, 22] = sx * 1.5; eng.vy[e, 22] = 0.0
+                    orc.set_game(e, mode=2, mode_side=0); eng.mode[e] = 2; eng.mode_side[e] = 0
+            before = orc.get('mode').copy()
+            eng.step(torch.as_tensor(a, device='cuda:0')); orc.step(a)
+            after = orc.get('mode')
+            seen_after += int((after == GM_AFTER_GOAL).sum())
+            seen_kickoff_after += int(((before == GM_AFTER_GOAL) & (after == GM_KICK_OFF)).sum())
+            assert_match_same(eng, orc, f'after-goal wait={wait} t={t}')
+        assert list(eng.stats.cpu().numpy()) == list(orc.stats())
+        assert int(orc.stats()[1]) + int(orc.stats()[2]) >= n // 3
+        if wait:
+            assert seen_after > 0 and (seen_kickoff_after > 0 or wait == 50)
+        else:
+            assert seen_after == 0
+
+
 def test_match_hetero_rollout_random_policy_parity():
     n, T = 64, 96
     ids = [0] + list(range(1, 11)) + [0] + list(range(8, 18))

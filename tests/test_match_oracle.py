@@ -5,8 +5,8 @@ import numpy as np
 import pytest
 
 import match_oracle as MO
-from soccer2d_amd._capi_match import (GM_CORNER_KICK, GM_GOAL_KICK, GM_KICK_IN, GM_KICK_OFF, GM_OFF_SIDE, GM_PLAY_ON,
-                                      GM_TIME_OVER, MCMD_DASH, MCMD_KICK, MCMD_NONE, MCMD_TACKLE, MCMD_TURN)
+from soccer2d_amd._capi_match import (GM_AFTER_GOAL, GM_CORNER_KICK, GM_GOAL_KICK, GM_KICK_IN, GM_KICK_OFF, GM_OFF_SIDE, GM_PLAY_ON,
+                                      GM_TIME_OVER, MCMD_DASH, MCMD_KICK, MCMD_MOVE, MCMD_NONE, MCMD_TACKLE, MCMD_TURN)
 
 LEFT, RIGHT = 1, 2
 
@@ -65,17 +65,48 @@ def test_drop_ball_after_timeout():
 
 
 def test_goal_and_kickoff_for_conceding_side():
-    m = fresh()
+    # after_goal_wait = 0: the kick-off formation follows the goal at once
+    m = fresh(after_goal_wait=0)
     play_on(m)
     m.set_obj(0, 22, x=52.0, y=1.0, vx=1.5, vy=0.0)
     m.step(acts())
     assert m.get('score_left')[0] == 1 and m.get('reward_left')[0] == 1.0
     assert m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == RIGHT
     assert m.get('x')[0][22] == 0 and m.get('x')[0][21] == pytest.approx(0.4) and m.get('x')[0][10] == pytest.approx(-10.5)
-    m2 = fresh(); play_on(m2)
+    m2 = fresh(after_goal_wait=0); play_on(m2)
     m2.set_obj(0, 22, x=-52.0, y=-6.9, vx=-1.5, vy=0.0)
     m2.step(acts())
     assert m2.get('score_right')[0] == 1 and m2.get('reward_left')[0] == -1.0 and m2.get('mode_side')[0] == LEFT
+
+
+def test_after_goal_pause():
+    # AfterGoal_ (idl/service.proto:276) for after_goal_wait cycles: mode side = the scorer, the ball rests in the net and
+    # is dead for both sides, players may walk and Move inside their own half; then formation + kick-off for the conceding side
+    m = fresh(after_goal_wait=4)
+    play_on(m)
+    m.set_obj(0, 22, x=52.0, y=1.0, vx=1.5, vy=0.0)
+    m.set_obj(0, 9, x=52.9, y=1.0, body=0.0)                # a left attacker next to where the ball comes to rest
+    m.step(acts())
+    assert m.get('score_left')[0] == 1 and m.get('reward_left')[0] == 1.0
+    assert m.get('mode')[0] == GM_AFTER_GOAL and m.get('mode_side')[0] == LEFT
+    assert m.get('x')[0][22] == pytest.approx(53.5) and m.get('vx')[0][22] == 0 and m.get('x')[0][10] != pytest.approx(-10.5)
+    for k in range(3):
+        # the scorer's kick is dropped (dead ball); a Move of the conceding side inside its own half (own frame) is executed
+        m.step(acts(p9=(MCMD_KICK, 100.0, 0.0), p15=(MCMD_MOVE, -20.0, 5.0)))
+        assert m.get('mode')[0] == GM_AFTER_GOAL and m.get('reward_left')[0] == 0.0 and m.stats()[4] == 0
+        assert m.get('x')[0][22] == pytest.approx(53.5) and m.get('vx')[0][22] == 0
+        assert m.get('x')[0][15] == pytest.approx(20.0) and m.get('y')[0][15] == pytest.approx(-5.0)
+    m.step(acts())
+    assert m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == RIGHT and m.get('score_left')[0] == 1
+    assert m.get('x')[0][22] == 0 and m.get('x')[0][21] == pytest.approx(0.4) and m.get('x')[0][10] == pytest.approx(-10.5)
+    # the default is rcssserver's 50 cycles
+    d = fresh(); play_on(d)
+    d.set_obj(0, 22, x=-52.0, y=-6.9, vx=-1.5, vy=0.0)
+    for k in range(50):
+        d.step(acts())
+        assert d.get('mode')[0] == GM_AFTER_GOAL and d.get('mode_side')[0] == RIGHT and d.get('score_right')[0] == 1
+    d.step(acts())
+    assert d.get('mode')[0] == GM_KICK_OFF and d.get('mode_side')[0] == LEFT
 
 
 def test_ball_out_restarts():
