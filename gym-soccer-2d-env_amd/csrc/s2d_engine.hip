@@ -432,9 +432,9 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 //                      labels, reward / done / result stores, episode counters, reward carry
 //   B-wave (ball):     ball half of the observation (speed, direction), and the transposed
 //                      observation block of the PREVIOUS step streamed out of LDS
-// In iteration s the P-wave works on step s, the S-wave on step s-2 (it fetches the command of
-// step s-1 from LDS while it simulates, so that latency is never exposed), the A- and B-waves on
-// step s-3 (the B-wave also stores the observations of step s-4); the hand-offs are
+// In iteration s the P-wave works on step s, the S-wave on step s-1 (prefetching the command one
+// iteration ahead bought nothing and cost a fill cycle per launch), the A- and B-waves on
+// step s-2 (the B-wave also stores the observations of step s-3); the hand-offs are
 // double-buffered in LDS and ONE s_barrier per iteration separates them.  There is no feedback edge: policy
 // draws are keyed by policy_step (not by the cycle, which resets advance), the S-wave evaluates
 // the done conditions itself, the A-wave owns the reward carry.  The arithmetic is the same
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   const bool active = i < n;
   int64_t rows = n - wave_first; rows = rows > kWave ? kWave : rows;
   const int valid = (int)rows * S2D_OBS_DIM;
-  const int n_iter = n_steps + 4;
+  const int n_iter = n_steps + 3;
 
   if (role == 0) {
     // ------------------------------------------------------------------ P-wave
@@ -552,32 +552,28 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       else { nep = episode_prepare(p, rp, r, gl, gh, reset_key(e)); fo = first_obs(p, nep); }
     };
     if (active && p.auto_reset) { prepare(); have_prep = true; }
-    int cmd_cur = S2D_CMD_DASH, cmd_nxt = S2D_CMD_DASH;
-    CmdPrep c_cur{0.0f, 0.0f, 0.0f}, c_nxt{0.0f, 0.0f, 0.0f};
-    NoiseIn nz_cur{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, nz_nxt = nz_cur;
     int n_missing = 0;                                     // wave-uniform: active lanes without a prepared sample
     S2D_TICK_INIT(2);
     for (int s = 0; s < n_iter; ++s) {
-      if (s >= 1 && s <= n_steps && active) {              // command of step s - 1: used in the NEXT iteration
-        const int bn = (s - 1) & 1;
-        if (MODE == S2D_MODE_TURN4) cmd_nxt = __float_as_int(act[bn][WA_CMD][lane]);   // other modes always dash
-        c_nxt = CmdPrep{act[bn][WA_POWER][lane], act[bn][WA_DIR][lane], act[bn][WA_RATE][lane]};
-        if (NOISE) {
-          nz_nxt = NoiseIn{act[bn][WA_NPM][lane], act[bn][WA_NPS][lane], act[bn][WA_NPC][lane], act[bn][WA_NBM][lane],
-                           act[bn][WA_NBS][lane], act[bn][WA_NBC][lane], 0.0f};
-          if (MODE == S2D_MODE_TURN4) nz_nxt.tu = act[bn][WA_NTU][lane];
-        }
-      }
-      if (s >= 2 && s <= n_steps + 1) {                    // step s - 2
-        const int b = s & 1;
+      if (s >= 1 && s <= n_steps) {                        // step s - 1
+        const int b = (s - 1) & 1;
         if (n_missing >= kRefillMin) {                     // batched refill (scalar counter: no ballot in the hot path)
           if (active && !have_prep) { prepare(); have_prep = true; }
           n_missing = 0;
         }
         if (active) {
           S2D_TICK(0);                                     // refill check
+          int cmd = S2D_CMD_DASH;                          // only the turning mode has another command
+          if (MODE == S2D_MODE_TURN4) cmd = __float_as_int(act[b][WA_CMD][lane]);
+          const CmdPrep c{act[b][WA_POWER][lane], act[b][WA_DIR][lane], act[b][WA_RATE][lane]};
+          NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+          if (NOISE) {
+            nz = NoiseIn{act[b][WA_NPM][lane], act[b][WA_NPS][lane], act[b][WA_NPC][lane], act[b][WA_NBM][lane],
+                         act[b][WA_NBS][lane], act[b][WA_NBC][lane], 0.0f};
+            if (MODE == S2D_MODE_TURN4) nz.tu = act[b][WA_NTU][lane];
+          }
           e.step_number += 1;                              // reach_ball_env.py:55
-          const float d2 = sim_cycle<NOISE, true>(p, rp, e, cmd_cur, c_cur, nz_cur);
+          const float d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);
 #if S2D_PROFILE
           asm volatile("" ::"v"(e.px), "v"(e.py), "v"(e.bx), "v"(e.by), "v"(e.stamina), "v"(e.effort), "v"(e.vx), "v"(e.vy));
           S2D_TICK(1);                                     // simulator cycle
@@ -605,7 +601,6 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           }
         }
       }
-      cmd_cur = cmd_nxt; c_cur = c_nxt; nz_cur = nz_nxt;
 #if S2D_PROFILE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -641,8 +636,8 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     int64_t row = 0;
     S2D_TICK_INIT(3);
     for (int s = 0; s < n_iter; ++s) {
-      if (s >= 3 && s < n_steps + 3) {                     // step s - 3
-        const int b = (s - 1) & 1;
+      if (s >= 2 && s < n_steps + 2) {                     // step s - 2
+        const int b = s & 1;
         res = 0;
         if (active) {
           float px = snap[b][WS_PX][lane], py = snap[b][WS_PY][lane], body = snap[b][WS_BODY][lane];
@@ -715,10 +710,10 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
     for (int s = 0; s < n_iter; ++s) {
-      if (s >= 4 && ro.obs)                                // observation block of step s - 4, completed in iteration s - 1
-        tile_flush(tile[s & 1], lane, ro.obs + ((int64_t)(s - 4) * n + wave_first) * S2D_OBS_DIM, valid);
-      if (s >= 3 && s < n_steps + 3 && active) {           // step s - 3
-        const int b = (s - 1) & 1;
+      if (s >= 3 && ro.obs)                                // observation block of step s - 3, completed in iteration s - 1
+        tile_flush(tile[(s - 1) & 1], lane, ro.obs + ((int64_t)(s - 3) * n + wave_first) * S2D_OBS_DIM, valid);
+      if (s >= 2 && s < n_steps + 2 && active) {           // step s - 2
+        const int b = s & 1;
         float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
         float bvx = snap[b][WS_BVX][lane], bvy = snap[b][WS_BVY][lane];
         int flags = __float_as_int(snap[b][WS_FLAGS][lane]);
