@@ -54,6 +54,9 @@ def parse():
                     help='reach_ball = the BASELINE.json metric (default); match = 11v11 engine, configs[3] (8 192 matches)')
     ap.add_argument('--variant', choices=('dqn', 'no-auto-reset', 'never-done'), default='dqn',
                     help='experiments only: dqn = the benchmark workload; the others switch episode ends off')
+    ap.add_argument('--settle-ms', type=float, default=200.0,
+                    help='untimed load before the W warm-up steps so that the chip\'s clock has settled (it takes tens of ms '
+                         'of sustained load; a 4 ms run measures the ramp: 66 G instead of 80 G env-steps/s); 0 = off')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-steps', type=int, default=0, help='0 = auto (about 10-20 s of CPU work)')
     args = ap.parse_args()
@@ -126,6 +129,19 @@ def numpy_baseline(n_envs):
     dt = time.perf_counter() - t0
     return {'value': n_envs * steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port-numpy',
             'sample': f'{n_envs} envs x {steps} steps ({dt:.2f} s), float64 NumPy, same kwargs/seed'}
+
+
+def settle(run_cycles, chunk_cycles, ms):
+    """Keep the device under the bench's own load for `ms` milliseconds (untimed) -- see --settle-ms."""
+    import torch
+    if ms <= 0:
+        return 0
+    t0, n = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        run_cycles(chunk_cycles)
+        torch.cuda.synchronize()
+        n += chunk_cycles
+    return n
 
 
 def init_distributed(rank, local_rank, world):
@@ -209,6 +225,7 @@ def bench_match(args):
         for _ in range(k):
             eng.step(None)
         return k
+    settle(run, 8 * T if args.mode == 'rollout' else 512, args.settle_ms)
     run(W)
     torch.cuda.synchronize()
     if dist is not None:
@@ -234,7 +251,7 @@ def bench_match(args):
                 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': f'11v11 match, {n} matches per GPU, random policy (BASELINE.json configs[3])',
-                           'envs_per_gpu': n, 'mode': args.mode, 'cycles_per_launch': per_launch_steps,
+                           'envs_per_gpu': n, 'mode': args.mode, 'cycles_per_launch': per_launch_steps, 'settle_ms': args.settle_ms,
                            'player_steps_per_s': world * n * K * 22 / elapsed},
                 'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic('match-' + args.mode, T, n), 'kernel': 's2d_match_rollout_kernel',
@@ -334,6 +351,7 @@ def main():
             eng.step(None)
         return k
 
+    settle(launch, 16 * T if args.mode != 'step' else 2048, args.settle_ms)
     launch(W)
     torch.cuda.synchronize()
     if dist is not None:
@@ -404,6 +422,7 @@ def main():
                                    f'(BASELINE.json configs[2]; kwargs of dqn_stable_baselines3.py:18-31)',
                        'envs_per_gpu': n, 'global_envs': world * n, 'mode': args.mode, 'variant': args.variant,
                        'cycles_per_launch': steps_per_launch if args.mode != 'graph' else f'1 ({T} per graph replay)',
+                       'settle_ms': args.settle_ms,
                        'noise': bool(args.noise), 'parallelism': f'env-shard x{world} (no collective)',
                        'launches': n_launches},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -445,15 +445,15 @@ enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_FLAGS, WS_WORDS }
 enum { WP_DIST = S2D_OBS_DIM, WP_REL, WP_WORDS };             // post[] rows without noise
 enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_NPM, WA_NPS, WA_NPC, WA_NBM, WA_NBS, WA_NBC, WA_NTU, WA_WORDS };   // command + prepared noise
 // Issue priority of the four role waves of a group (s_setprio): a SIMD holds one wave of each role (of four
-// different groups, profiles/r01/wave_placement.txt), and the arbiter should prefer them in the order of their
-// slack -- simulate (none), agent, ball, policy (half a cycle).  Measured on one device, 256 launches:
-// 1/0/0/0 57.0 G env-steps/s, 2/1/0/0 58.5, 2/1/1/0 59.9, 3/1/2/0 60.5, 3/2/2/0 59.7, 3/3/1/0 59.8,
-// 3/2/1/0 60.9 (noise on: 43.5 -> 47.5).  Overridable for experiments.
+// different groups, profiles/r01/wave_placement.txt), and the arbiter should prefer them by their slack --
+// simulate (none) first, the policy wave (half a cycle of slack) last.  Steady clocks, 65 536 envs, G env-steps/s
+// (simulate/agent/ball/policy): 0/0/0/0 71.3, 1/0/0/0 75.2, 1/1/1/0 76.5, 2/2/1/0 78.5, 2/1/2/0 79.8, 3/2/1/0 80.0,
+// 3/1/1/0 80.3, 2/1/1/0 80.2 (noise on: 54.4 for 1/1/1/0, 56.1 for 3/2/1/0, 56.9 for 2/1/1/0).  Overridable for experiments.
 #ifndef S2D_PRIO_S
-#define S2D_PRIO_S 3
+#define S2D_PRIO_S 2
 #endif
 #ifndef S2D_PRIO_A
-#define S2D_PRIO_A 2
+#define S2D_PRIO_A 1
 #endif
 #ifndef S2D_PRIO_B
 #define S2D_PRIO_B 1
