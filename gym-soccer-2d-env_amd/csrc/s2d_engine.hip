@@ -42,7 +42,7 @@ static constexpr int kBlock = S2D_BLOCK;
 static constexpr int kWave = 64;
 static constexpr int kWavesPerBlock = kBlock / kWave;
 static constexpr int kObsTile = kWave * S2D_OBS_DIM;  // 640 floats per wave
-static constexpr int64_t kWsMaxEnvs = 131072;         // up to 2 env groups per SIMD the wave-specialised rollout wins (measured)
+static constexpr int64_t kWsMaxEnvs = 524288;         // the wave-specialised rollout wins or ties up to here at steady clocks (profiles/r01/ws_vs_unified_sweep.txt)
 
 // ------------------------------------------------------------------------------------------
 // device helpers
