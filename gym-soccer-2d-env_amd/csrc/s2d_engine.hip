@@ -181,7 +181,10 @@ S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int ki
 // or two active lanes each time an episode ends.
 // Without noise the tile holds the whole post-reset state (NextEpisode, 13 words), with noise the sample (7).
 struct PrepTile { float v[13 + S2D_OBS_DIM + 2][kWave]; };   // ResetSample | NextEpisode + FirstObs
-static constexpr int kRefillMin = 8;
+#ifndef S2D_REFILL_MIN
+#define S2D_REFILL_MIN 8
+#endif
+static constexpr int kRefillMin = S2D_REFILL_MIN;
 
 template <bool NOISE>
 S2D_DEV void prep_fill(const S2DHot& p, const S2DRare* __restrict__ rp, PrepTile& t, int lane, const Env& e,
