@@ -221,6 +221,13 @@ def test_bench_step_units(monkeypatch):
     monkeypatch.setattr(_sys, 'argv', ['bench.py', '--steps', '0'])
     with pytest.raises(SystemExit):
         bench.parse()
+    # the untimed settle phase (steady clocks before the W warm-up steps): on by default, 0 switches it off
+    monkeypatch.setattr(_sys, 'argv', ['bench.py'])
+    assert bench.parse().settle_ms == 200.0
+    monkeypatch.setattr(_sys, 'argv', ['bench.py', '--settle-ms', '0'])
+    assert bench.parse().settle_ms == 0.0
+    calls = []
+    assert bench.settle(lambda k: calls.append(k), 64, 0) == 0 and calls == []
 
 
 def test_logger_utils_mirror(tmp_path, monkeypatch):
