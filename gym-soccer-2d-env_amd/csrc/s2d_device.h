@@ -382,7 +382,7 @@ S2D_DEV void cmd_turn(const S2DHot& p, Env& e, float moment, bool noise, float n
 }
 // Velocity noise of MPObject::_inc: polar(U(0, rand * |vel|), U(-180, 180)).  The uniforms and the sine /
 // cosine of the two directions do not depend on the state, so -- like the policy draw -- they are keyed by
-// the env's policy_step (stream NOISE; the command-less cycle of a reset uses stream NOISE_RESET at the
+// the env's policy_step (stream NOISE; the command-less cycle of a reset uses stream NOISE_RESET with the reset's own key, at the
 // cycle) and can be prepared ahead of the simulation by another wave.
 struct NoiseIn { float pm, ps, pc, bm, bs, bc, tu; };   // player: magnitude uniform, sin, cos; ball: same; turn uniform
 S2D_DEV NoiseIn noise_prepare(const S2DHot& p, uint32_t gid_lo, uint32_t gid_hi, uint32_t ctr, uint32_t stream,
@@ -560,26 +560,26 @@ S2D_DEV ResetSample reset_sample(const S2DHot& p, const S2DRare& r, uint32_t gid
 // trainer (move ball) (move player) (recover), then the command-less cycle (soccer_2d_env.py:186-197)
 template <bool NOISE>
 S2D_DEV float reset_apply(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
-                          const ResetSample& o, float recover_init) {
+                          const ResetSample& o, float recover_init, uint32_t key) {
   e.step_number = 0;                                     // :172
   e.bx = o.bx; e.by = o.by; e.bvx = o.bvx; e.bvy = o.bvy;
   e.px = o.px; e.py = o.py; e.body = o.body; e.vx = 0.0f; e.vy = 0.0f;
   e.stamina = p.stamina_max; e.recovery = recover_init;
   e.effort = p.effort_init; e.capacity = p.stamina_capacity;
   NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  if (NOISE) nz = noise_prepare(p, gid_lo, gid_hi, (uint32_t)e.cycle, S2D_ST_NOISE_RESET, false);
+  if (NOISE) nz = noise_prepare(p, gid_lo, gid_hi, key, S2D_ST_NOISE_RESET, false);   // keyed like the sample itself
   return sim_cycle<NOISE, false>(p, rp, e, S2D_CMD_NONE, CmdPrep{0.0f, 0.0f, 0.0f}, nz);
 }
-// Without noise the env a reset leaves behind -- trainer moves + recover + the command-less cycle -- is a pure
-// function of the sample, so it can be prepared together with the sample (batched, off the critical path) and
-// a reset becomes a register copy plus the cycle's tick.  NextEpisode = that prepared state; with noise the
-// command-less cycle draws from the cycle at which the reset happens, and reset_apply stays.
+// The env a reset leaves behind -- trainer moves + recover + the command-less cycle, whose noise is keyed by the
+// reset's own key -- is a pure function of (env id, key), so it can be prepared together with the sample (batched,
+// off the critical path) and a reset becomes a register copy plus the cycle's tick.  NextEpisode = that prepared state.
 struct NextEpisode { float px, py, vx, vy, body, stamina, effort, recovery, capacity, bx, by, bvx, bvy; };
+template <bool NOISE>
 S2D_DEV NextEpisode episode_prepare(const S2DHot& p, const S2DRare* __restrict__ rp, const S2DRare& r, uint32_t gid_lo,
                                     uint32_t gid_hi, uint32_t key) {
   const ResetSample o = reset_sample(p, r, gid_lo, gid_hi, key);
   Env t{};
-  reset_apply<false>(p, rp, t, gid_lo, gid_hi, o, r.recover_init);
+  reset_apply<NOISE>(p, rp, t, gid_lo, gid_hi, o, r.recover_init, key);
   return NextEpisode{t.px, t.py, t.vx, t.vy, t.body, t.stamina, t.effort, t.recovery, t.capacity, t.bx, t.by, t.bvx, t.bvy};
 }
 S2D_DEV void episode_begin(Env& e, const NextEpisode& q) {
@@ -603,6 +603,7 @@ template <bool NOISE>
 S2D_DEV float env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo,
                         uint32_t gid_hi) {
   const S2DRare r = *rp;                                 // one bulk scalar load for the whole path
-  ResetSample o = reset_sample(p, r, gid_lo, gid_hi, reset_key(e));
-  return reset_apply<NOISE>(p, rp, e, gid_lo, gid_hi, o, r.recover_init);
+  const uint32_t key = reset_key(e);
+  ResetSample o = reset_sample(p, r, gid_lo, gid_hi, key);
+  return reset_apply<NOISE>(p, rp, e, gid_lo, gid_hi, o, r.recover_init, key);
 }

@@ -180,7 +180,7 @@ S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int ki
 // kRefillMin lanes have used theirs -- instead of running the Philox + rejection loop with one
 // or two active lanes each time an episode ends.
 // Without noise the tile holds the whole post-reset state (NextEpisode, 13 words), with noise the sample (7).
-struct PrepTile { float v[13 + S2D_OBS_DIM + 2][kWave]; };   // ResetSample | NextEpisode + FirstObs
+struct PrepTile { float v[13 + S2D_OBS_DIM + 2][kWave]; };   // NextEpisode + FirstObs
 #ifndef S2D_REFILL_MIN
 #define S2D_REFILL_MIN 8
 #endif
@@ -190,24 +190,14 @@ template <bool NOISE>
 S2D_DEV void prep_fill(const S2DHot& p, const S2DRare* __restrict__ rp, PrepTile& t, int lane, const Env& e,
                        uint32_t gid_lo, uint32_t gid_hi) {
   const S2DRare r = *rp;
-  if (NOISE) {
-    const ResetSample o = reset_sample(p, r, gid_lo, gid_hi, reset_key(e));
-    t.v[0][lane] = o.px; t.v[1][lane] = o.py; t.v[2][lane] = o.body; t.v[3][lane] = o.bx;
-    t.v[4][lane] = o.by; t.v[5][lane] = o.bvx; t.v[6][lane] = o.bvy;
-  } else {
-    const NextEpisode q = episode_prepare(p, rp, r, gid_lo, gid_hi, reset_key(e));
-    t.v[0][lane] = q.px; t.v[1][lane] = q.py; t.v[2][lane] = q.vx; t.v[3][lane] = q.vy; t.v[4][lane] = q.body;
-    t.v[5][lane] = q.stamina; t.v[6][lane] = q.effort; t.v[7][lane] = q.recovery; t.v[8][lane] = q.capacity;
-    t.v[9][lane] = q.bx; t.v[10][lane] = q.by; t.v[11][lane] = q.bvx; t.v[12][lane] = q.bvy;
-    const FirstObs f = first_obs(p, q);
+  const NextEpisode q = episode_prepare<NOISE>(p, rp, r, gid_lo, gid_hi, reset_key(e));
+  t.v[0][lane] = q.px; t.v[1][lane] = q.py; t.v[2][lane] = q.vx; t.v[3][lane] = q.vy; t.v[4][lane] = q.body;
+  t.v[5][lane] = q.stamina; t.v[6][lane] = q.effort; t.v[7][lane] = q.recovery; t.v[8][lane] = q.capacity;
+  t.v[9][lane] = q.bx; t.v[10][lane] = q.by; t.v[11][lane] = q.bvx; t.v[12][lane] = q.bvy;
+  const FirstObs f = first_obs(p, q);
 #pragma unroll
-    for (int k = 0; k < S2D_OBS_DIM; ++k) t.v[13 + k][lane] = f.o[k];
-    t.v[13 + S2D_OBS_DIM][lane] = f.dist; t.v[14 + S2D_OBS_DIM][lane] = f.rel;
-  }
-}
-S2D_DEV ResetSample prep_take_sample(const PrepTile& t, int lane) {
-  return ResetSample{t.v[0][lane], t.v[1][lane], t.v[2][lane], t.v[3][lane], t.v[4][lane], t.v[5][lane],
-                     t.v[6][lane]};
+  for (int k = 0; k < S2D_OBS_DIM; ++k) t.v[13 + k][lane] = f.o[k];
+  t.v[13 + S2D_OBS_DIM][lane] = f.dist; t.v[14 + S2D_OBS_DIM][lane] = f.rel;
 }
 S2D_DEV NextEpisode prep_take_episode(const PrepTile& t, int lane) {
   return NextEpisode{t.v[0][lane], t.v[1][lane], t.v[2][lane], t.v[3][lane], t.v[4][lane], t.v[5][lane], t.v[6][lane],
@@ -232,14 +222,11 @@ S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, u
     if (prep) {
       if (!have_prep) prep_fill<NOISE>(p, rp, *prep, lane, e, gid_lo, gid_hi);   // episode shorter than the refill cadence
       have_prep = false;
-      if (!NOISE) {                            // state, first observation and carry were prepared together
-        episode_begin(e, prep_take_episode(*prep, lane));
+      episode_begin(e, prep_take_episode(*prep, lane));    // state, first observation and carry were prepared together
 #pragma unroll
-        for (int k = 0; k < S2D_OBS_DIM; ++k) ob.o[k] = prep->v[13 + k][lane];
-        e.prev_dist = prep->v[13 + S2D_OBS_DIM][lane]; e.prev_angle = prep->v[14 + S2D_OBS_DIM][lane];
-        return;
-      }
-      d2 = reset_apply<true>(p, rp, e, gid_lo, gid_hi, prep_take_sample(*prep, lane), p.recover_init);
+      for (int k = 0; k < S2D_OBS_DIM; ++k) ob.o[k] = prep->v[13 + k][lane];
+      e.prev_dist = prep->v[13 + S2D_OBS_DIM][lane]; e.prev_angle = prep->v[14 + S2D_OBS_DIM][lane];
+      return;
     } else {
       d2 = env_reset<NOISE>(p, rp, e, gid_lo, gid_hi);
     }
@@ -471,8 +458,8 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
                                                                         RolloutOut ro, StepOut o) {
   __shared__ float act[2][WA_WORDS][kWave];                // decoded command of step t, double-buffered
   __shared__ float snap[2][WS_WORDS][kWave];               // post-cycle snapshot of step t, double-buffered
-  // envs that finished: with noise their post-reset state (WS_PX..WS_BVY), without noise the prepared first
-  // observation of the new episode and the carry it seeds (FirstObs: o[0..9], dist, rel)
+  // envs that finished: the prepared first observation of the new episode and the carry it seeds
+  // (FirstObs: o[0..9], dist, rel)
   __shared__ float post[2][WP_WORDS][kWave];
   __shared__ __attribute__((aligned(16))) float tile[2][kObsTile];   // observation rows of step t, double-buffered
   const int lane = threadIdx.x & (kWave - 1);
@@ -542,17 +529,16 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
                    "v"(e.recovery), "v"(e.capacity), "v"(e.bx), "v"(e.by), "v"(e.bvx), "v"(e.bvy),
                    "v"(e.step_number), "v"(e.cycle));
     }
-    // the prepared sample of this env's next episode lives in registers here (VGPRs are plentiful in this
-    // wave), refilled for >= kRefillMin lanes at a time like the LDS tile of the unified kernel
-    // (without noise: the whole post-reset state, see episode_prepare)
+    // the prepared next episode of this env (state + first observation, see episode_prepare) lives in registers
+    // here (VGPRs are plentiful in this wave), refilled for >= kRefillMin lanes at a time like the LDS tile of
+    // the unified kernel
     bool have_prep = false;
-    ResetSample nxt{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     NextEpisode nep{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     FirstObs fo{};
     auto prepare = [&]() {
       const S2DRare r = *rp;
-      if (NOISE) nxt = reset_sample(p, r, gl, gh, reset_key(e));
-      else { nep = episode_prepare(p, rp, r, gl, gh, reset_key(e)); fo = first_obs(p, nep); }
+      nep = episode_prepare<NOISE>(p, rp, r, gl, gh, reset_key(e));
+      fo = first_obs(p, nep);
     };
     if (active && p.auto_reset) { prepare(); have_prep = true; }
     int n_missing = 0;                                     // wave-uniform: active lanes without a prepared sample
@@ -588,19 +574,12 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           snap[b][WS_FLAGS][lane] = __int_as_float(flags);
           if (flags && p.auto_reset) {                     // rare
             if (!have_prep) prepare();                     // episode shorter than the refill cadence
-            if (NOISE) reset_apply<true>(p, rp, e, gl, gh, nxt, p.recover_init);
-            else episode_begin(e, nep);
+            episode_begin(e, nep);
             have_prep = false;
             n_missing += __popcll(__ballot(true));         // lanes of this wave that consumed their sample now
-            if (NOISE) {
-              post[b][WS_PX][lane] = e.px; post[b][WS_PY][lane] = e.py; post[b][WS_BODY][lane] = e.body;
-              post[b][WS_BX][lane] = e.bx; post[b][WS_BY][lane] = e.by;
-              post[b][WS_BVX][lane] = e.bvx; post[b][WS_BVY][lane] = e.bvy;
-            } else {
 #pragma unroll
-              for (int k = 0; k < S2D_OBS_DIM; ++k) post[b][k][lane] = fo.o[k];
-              post[b][WP_DIST][lane] = fo.dist; post[b][WP_REL][lane] = fo.rel;
-            }
+            for (int k = 0; k < S2D_OBS_DIM; ++k) post[b][k][lane] = fo.o[k];
+            post[b][WP_DIST][lane] = fo.dist; post[b][WP_REL][lane] = fo.rel;
           }
         }
       }
@@ -658,16 +637,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           if (flags && p.auto_reset) {                     // rare: terminal row, then the new episode's first obs
 #pragma unroll
             for (int k = 0; k < 4; ++k) term_row[k] = oa[k];
-            if (NOISE) {
-              px = post[b][WS_PX][lane]; py = post[b][WS_PY][lane]; body = post[b][WS_BODY][lane];
-              bx = post[b][WS_BX][lane]; by = post[b][WS_BY][lane];
-              prev_angle = observe_player(p, px, py, body, bx, by, oa);    // reach_ball_env.py:166 carry seeded
-              prev_dist = hypot2(bx - px, by - py);
-            } else {                                       // prepared with the episode by the simulate wave
 #pragma unroll
-              for (int k = 0; k < 4; ++k) oa[k] = post[b][k][lane];
-              prev_dist = post[b][WP_DIST][lane]; prev_angle = post[b][WP_REL][lane];
-            }
+            for (int k = 0; k < 4; ++k) oa[k] = post[b][k][lane];          // prepared with the episode by the simulate wave
+            prev_dist = post[b][WP_DIST][lane]; prev_angle = post[b][WP_REL][lane];   // reach_ball_env.py:166 carry seeded
           }
           if (ro.reward) ro.reward[row + i] = reward;
           if (ro.done) ro.done[row + i] = (uint8_t)done;
@@ -724,14 +696,8 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         if (flags && p.auto_reset) {                       // rare: terminal row, then the new episode's first obs
 #pragma unroll
           for (int k = 4; k < S2D_OBS_DIM; ++k) term_row[k] = ob6[k];
-          if (NOISE) {
-            bx = post[b][WS_BX][lane]; by = post[b][WS_BY][lane];
-            bvx = post[b][WS_BVX][lane]; bvy = post[b][WS_BVY][lane];
-            observe_ball(p, bx, by, bvx, bvy, ob6);
-          } else {
 #pragma unroll
-            for (int k = 4; k < S2D_OBS_DIM; ++k) ob6[k] = post[b][k][lane];
-          }
+          for (int k = 4; k < S2D_OBS_DIM; ++k) ob6[k] = post[b][k][lane];
         }
         if (ro.obs) {
           float* t = &tile[b][lane * S2D_OBS_DIM];

@@ -401,8 +401,9 @@ static void update_stamina(const P *p, Env *e) {
 /* One simulator cycle (appendix A "Per-cycle order", play_on, referee off in coach mode:
  * soccer_2d_env.py:363-366 starts rcssserver with coach=true and no coach_w_referee). */
 /* Noise draws (player_rand / ball_rand / turn) of a commanded cycle are keyed by the env's policy_step
- * (stream NOISE), those of the command-less cycle a reset consumes by the cycle (stream NOISE_RESET):
- * like the policy draws they must not depend on whether an episode ended earlier. */
+ * (stream NOISE), those of the command-less cycle a reset consumes by the reset's own key (stream NOISE_RESET,
+ * the RESET stream's counter word): like the policy draws they must not depend on whether an episode ended
+ * earlier, and the state a reset leaves behind is a function of (env id, key) alone. */
 static void sim_cycle(const P *p, Env *e, uint64_t gid, int cmd, REAL power, REAL dir, uint32_t noise_ctr,
                       uint32_t noise_stream) {
   uint32_t nz[4] = {0, 0, 0, 0}, nz2[4] = {0, 0, 0, 0};
@@ -439,7 +440,7 @@ static void env_reset(const P *p, Env *e, uint64_t gid, REAL *obs) {
   e->px = o.px; e->py = o.py; e->body = norm_deg(o.body); e->vx = R(0.0); e->vy = R(0.0); /* (move (player..)) */
   e->stamina = p->stamina_max; e->recovery = p->recover_init;     /* (recover) */
   e->effort = p->effort_init; e->capacity = p->stamina_capacity;
-  sim_cycle(p, e, gid, S2D_CMD_NONE, R(0.0), R(0.0), (uint32_t)e->cycle, ST_NOISE_RESET);
+  sim_cycle(p, e, gid, S2D_CMD_NONE, R(0.0), R(0.0), s.cycle, ST_NOISE_RESET);   /* noise keyed like the sample */
   observation(p, e->bx, e->by, e->bvx, e->bvy, e->px, e->py, e->body, obs);
   int d, res; REAL rw;
   check_trainer(p, e->bx, e->by, e->px, e->py, e->body, e->step_number, &e->prev_dist, &e->prev_angle, &d, &rw, &res);
