@@ -558,11 +558,15 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   }
 }
 
-// benchmark policy: Philox POLICY stream, block = player
-S2D_DEV void m_random_action(const MParams& p, uint32_t gl, uint32_t gh, uint32_t cyc, int l, int& cmd, float& a, float& b) {
-  U4 w = m_draw(p, gl, gh, cyc, S2D_ST_POLICY, (uint32_t)l);
-  cmd = 1 + rnd_below(w.x, 4);
-  float u = rnd_u01(w.y), s = rnd_u01(w.z) * 2.0f - 1.0f;
+// benchmark policy: Philox POLICY stream, block = player, counter = cycle / 2 -- one call serves two cycles (words
+// 0,1 the even one, 2,3 the odd one): command = the two top bits of the first word, magnitude = the bits below them,
+// direction = the second word.  `w` caches the block between the cycles of a fused rollout (`fresh` = draw it).
+S2D_DEV void m_random_action(const MParams& p, uint32_t gl, uint32_t gh, uint32_t cyc, int l, bool fresh, U4& w, int& cmd,
+                             float& a, float& b) {
+  if (fresh || (cyc & 1u) == 0u) w = m_draw(p, gl, gh, cyc >> 1, S2D_ST_POLICY, (uint32_t)l);
+  const uint32_t w0 = (cyc & 1u) ? w.z : w.x, w1 = (cyc & 1u) ? w.w : w.y;
+  cmd = 1 + (int)(w0 >> 30);
+  float u = rnd_u01(w0 << 2), s = rnd_u01(w1) * 2.0f - 1.0f;
   b = 0.0f;
   if (cmd == S2D_MCMD_DASH || cmd == S2D_MCMD_KICK) { a = u * 100.0f; b = s * 180.0f; }
   else { a = s * 180.0f; }
@@ -670,6 +674,7 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
   const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)ec;
   const uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
   MCounts cnt{0, 0, 0, 0, 0, 0, 0};
+  U4 pol{0, 0, 0, 0};                                     // the policy block of the current pair of cycles
   for (int t = 0; t < n_steps; ++t) {
     int cmd = S2D_MCMD_NONE; float a = 0.0f, b = 0.0f;
     if (l < NP) {
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
         const float* ap = actions + (((int64_t)t * n + ec) * NP + l) * 3;
         cmd = (int)ap[0]; a = ap[1]; b = ap[2];
       } else {
-        m_random_action(p, gl, gh, (uint32_t)g.cycle, l, cmd, a, b);
+        m_random_action(p, gl, gh, (uint32_t)g.cycle, l, t == 0, pol, cmd, a, b);
       }
     }
     match_cycle(p, pt, o, g, l, half, gl, gh, cmd, a, b, cnt, pos_tile[threadIdx.x / kHalf], t == n_steps - 1);

@@ -543,13 +543,16 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   }
 }
 
-/* uniform random policy of the benchmark: Philox POLICY stream, block = player */
+/* uniform random policy of the benchmark: Philox POLICY stream, block = player, counter = cycle / 2 (words 0,1 serve
+ * the even cycle, 2,3 the odd one): command = the two top bits of the first word, magnitude = the bits below them,
+ * direction = the second word */
 static void random_actions(const MP *p, uint64_t gid, uint32_t cyc, float *act) {
   for (int i = 0; i < NP; ++i) {
     uint32_t w[4];
-    draw(p->seed, gid, cyc, ST_POLICY, (uint32_t)i, w);
-    int cmd = 1 + rnd_below(w[0], 4);
-    REAL u = rnd_u01(w[1]), s = rnd_u01(w[2]) * R(2.0) - R(1.0);
+    draw(p->seed, gid, cyc >> 1, ST_POLICY, (uint32_t)i, w);
+    uint32_t w0 = (cyc & 1u) ? w[2] : w[0], w1 = (cyc & 1u) ? w[3] : w[1];
+    int cmd = 1 + (int)(w0 >> 30);
+    REAL u = rnd_u01(w0 << 2), s = rnd_u01(w1) * R(2.0) - R(1.0);
     REAL a, b = R(0.0);
     if (cmd == S2D_MCMD_DASH || cmd == S2D_MCMD_KICK) { a = u * R(100.0); b = s * R(180.0); }
     else { a = s * R(180.0); }
