@@ -462,6 +462,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   // (FirstObs: o[0..9], dist, rel)
   __shared__ float post[2][WP_WORDS][kWave];
   __shared__ __attribute__((aligned(16))) float tile[2][kObsTile];   // observation rows of step t, double-buffered
+  __shared__ float4 act_lut[kWave];                        // decoded commands of a small discrete action space
   const int lane = threadIdx.x & (kWave - 1);
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 agent, 3 ball
   const int64_t wave_first = (int64_t)blockIdx.x * kWave;
@@ -485,12 +486,30 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
     float dir = 0.0f; int cmd = 0;
     int64_t row = 0;
+    // The in-engine policy of a small discrete action space picks one of n_actions decoded commands: the action map and
+    // the command-only half of the dash are evaluated once per launch into a table (one LDS read per step instead of
+    // ~27 VALU instructions; the entries are the values decide<> computes, so nothing changes bit-wise).
+    const bool lut = MODE == S2D_MODE_DISCRETE && kind == S2D_ACT_RANDOM && p.n_actions <= kWave;
+    if (lut && lane < p.n_actions) {
+      int c0; float pw, d0;
+      action_map<MODE>(p, Action4{(float)lane, 0.0f, 0.0f, 0.0f}, 0.0f, c0, pw, d0);
+      const CmdPrep c = cmd_prepare(p, c0, pw, d0);
+      act_lut[lane] = make_float4(c.power, c.dir, c.dir_rate, d0);
+    }
     S2D_TICK_INIT(1);
     for (int s = 0; s < n_iter; ++s) {
       if (s < n_steps && active) {
         const uint32_t k = k0 + (uint32_t)s;
-        CmdPrep c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, s == 0 || (k & 3u) == 0u, quad, squad,
-                                 ro.action, cmd, dir);
+        CmdPrep c;
+        if (lut) {
+          if (s == 0 || (k & 3u) == 0u) quad = policy_quad(p, gl, gh, k, S2D_ST_POLICY);
+          const int a = (int)rnd_below(quad_word(quad, k), (uint32_t)p.n_actions);
+          if (ro.action) static_cast<int32_t*>(ro.action)[row + i] = a;
+          const float4 e4 = act_lut[a];
+          c = CmdPrep{e4.x, e4.y, e4.z}; dir = e4.w; cmd = S2D_CMD_DASH;
+        } else {
+          c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, s == 0 || (k & 3u) == 0u, quad, squad, ro.action, cmd, dir);
+        }
         const int b = s & 1;
         if (MODE == S2D_MODE_TURN4) act[b][WA_CMD][lane] = __int_as_float(cmd);
         act[b][WA_POWER][lane] = c.power;
