@@ -335,6 +335,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
                                                                    int kind, RolloutOut ro, StepOut o) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
   __shared__ PrepTile prep[kWavesPerBlock];
+  __shared__ float4 act_lut[kWavesPerBlock][kWave];        // decoded commands of a small discrete action space (per wave)
   const S2DHot p = hot_in_vgprs(p_sgpr);
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -368,6 +369,15 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
   if (active && p.auto_reset) { prep_fill<NOISE>(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }   // full wave
   int n_missing = 0;                                       // wave-uniform: lanes whose prepared sample is used up
   int64_t row = 0;
+  // in-engine policy of a small discrete action space: one table entry per action (see the pipeline kernel's P-wave).
+  // Measured at 1 M envs: +6 % with noise on, -1 % with noise off -- so only the noise build uses it here.
+  const bool lut = NOISE && MODE == S2D_MODE_DISCRETE && kind == S2D_ACT_RANDOM && p.n_actions <= kWave;
+  if (lut && lane < p.n_actions) {
+    int c0; float pw, d0;
+    action_map<MODE>(p, Action4{(float)lane, 0.0f, 0.0f, 0.0f}, 0.0f, c0, pw, d0);
+    const CmdPrep c = cmd_prepare(p, c0, pw, d0);
+    act_lut[wv][lane] = make_float4(c.power, c.dir, c.dir_rate, d0);
+  }
   for (int t = 0; t < n_steps; ++t, row += n) {
     res = 0;
     if (n_missing >= kRefillMin) {                         // batched refill (wave-uniform counter: no ballot per cycle)
@@ -376,8 +386,16 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
     }
     if (active) {
       const uint32_t k = k0 + (uint32_t)t;
-      CmdPrep c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, t == 0 || (k & 3u) == 0u, quad, squad,
-                               ro.action, cmd, dir);
+      CmdPrep c;
+      if (lut) {
+        if (t == 0 || (k & 3u) == 0u) quad = policy_quad(p, gl, gh, k, S2D_ST_POLICY);
+        const int a = (int)rnd_below(quad_word(quad, k), (uint32_t)p.n_actions);
+        if (ro.action) static_cast<int32_t*>(ro.action)[row + i] = a;
+        const float4 e4 = act_lut[wv][a];
+        c = CmdPrep{e4.x, e4.y, e4.z}; dir = e4.w; cmd = S2D_CMD_DASH;
+      } else {
+        c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, t == 0 || (k & 3u) == 0u, quad, squad, ro.action, cmd, dir);
+      }
       step_env<NOISE>(p, rp, e, gl, gh, k, cmd, c, ob, reward, done, res, term_row, &prep[wv], lane, have_prep);
       if (p.auto_reset) n_missing += __popcll(__ballot(done != 0));   // samples consumed by this cycle's resets
       if (ro.reward) ro.reward[row + i] = reward;
