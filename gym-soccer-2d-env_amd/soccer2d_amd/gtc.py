@@ -13,7 +13,8 @@ class S2DGtcConfig(C.Structure):
     _fields_ = [('abi_version', C.c_uint32), ('struct_bytes', C.c_uint32),
                 ('x_min', C.c_double), ('x_max', C.c_double), ('y_min', C.c_double), ('y_max', C.c_double),
                 ('min_distance_to_center', C.c_double), ('max_steps', C.c_int32), ('continuous', C.c_int32),
-                ('seed', C.c_uint64), ('env_id_offset', C.c_int64), ('auto_reset', C.c_int32), ('reserved', C.c_int32 * 3)]
+                ('seed', C.c_uint64), ('env_id_offset', C.c_int64), ('auto_reset', C.c_int32),
+                ('turn', C.c_int32), ('use_turn', C.c_int32), ('actor_out_size', C.c_int32)]
 
 
 class S2DGtcRollout(C.Structure):
@@ -28,6 +29,7 @@ GTC_PROTOTYPES = (
     ('s2d_gtc_buffer_offsets', C.c_int, (C.c_void_p, C.POINTER(C.c_int64), C.c_int)),
     ('s2d_gtc_reset', C.c_int, (C.c_void_p, C.c_void_p, C.c_void_p)),
     ('s2d_gtc_step', C.c_int, (C.c_void_p, C.c_void_p, C.c_void_p)),
+    ('s2d_gtc_step_u', C.c_int, (C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)),
     ('s2d_gtc_rollout', C.c_int, (C.c_void_p, C.c_int, C.POINTER(S2DGtcRollout), C.c_void_p)),
 )
 _FIELDS = (('x', 'float32', ()), ('y', 'float32', ()), ('body', 'float32', ()), ('prev_distance', 'float32', ()),
@@ -84,7 +86,13 @@ class GoToCenterVecEnv:
             setattr(self, name, self.arena[off[k + 1]:off[k + 1] + cnt * item].view(td).view(shape))
         from .spaces import Box, Discrete
         import numpy as np
-        self.action_space = Box(low=-1.0, high=1.0, shape=(1,), dtype=np.float32) if self.cfg.continuous else Discrete(16)
+        # python_sample_soccer_env.py:70-86
+        self.turn_mode = bool(self.cfg.turn and self.cfg.continuous)
+        self.action_dim = int(self.cfg.actor_out_size) if self.turn_mode else 1
+        if self.turn_mode:
+            self.action_space = Box(low=-1.0, high=1.0, shape=(self.action_dim,), dtype=np.float32)
+        else:
+            self.action_space = Box(low=-1.0, high=1.0, shape=(1,), dtype=np.float32) if self.cfg.continuous else Discrete(16)
         self.observation_space = Box(low=-1.0, high=1.0, shape=(4,), dtype=np.float32)
 
     def _stream(self):
@@ -103,19 +111,31 @@ class GoToCenterVecEnv:
         self._keep = mask
         return self.obs
 
-    def step(self, actions=None):
-        ptr = None
+    def step(self, actions=None, select_u=None):
+        """actions: int[N] (discrete) / float[N] (continuous) / float[N, actor_out_size] (turn mode) or None
+        (in-engine uniform random policy).  select_u: optional float[N] uniforms for the turn / dash selection
+        (python_sample_soccer_env.py:151) in place of the engine's Philox stream."""
+        ptr, uptr = None, None
         if actions is not None:
             a = torch.as_tensor(actions, device=self.device)
-            a = (a.to(torch.float32) if self.cfg.continuous else a.to(torch.int32)).reshape(self.num_envs).contiguous()
+            if self.cfg.continuous:
+                a = a.to(torch.float32).reshape(self.num_envs, self.action_dim).contiguous()
+            else:
+                a = a.to(torch.int32).reshape(self.num_envs).contiguous()
             ptr, self._keep = C.c_void_p(a.data_ptr()), a
-        _capi.check(self.lib, self.lib.s2d_gtc_step(self._h, ptr, self._stream()), 's2d_gtc_step')
+        if select_u is not None:
+            u = torch.as_tensor(select_u, device=self.device).to(torch.float32).reshape(self.num_envs).contiguous()
+            uptr, self._keep_u = C.c_void_p(u.data_ptr()), u
+            _capi.check(self.lib, self.lib.s2d_gtc_step_u(self._h, ptr, uptr, self._stream()), 's2d_gtc_step_u')
+        else:
+            _capi.check(self.lib, self.lib.s2d_gtc_step(self._h, ptr, self._stream()), 's2d_gtc_step')
         return self.obs, self.reward, self.done, {'result': self.result, 'terminal_observation': self.terminal_obs}
 
     def rollout(self, n_steps, with_obs=True):
         T, n, dev = int(n_steps), self.num_envs, self.device
         out = dict(obs=torch.empty((T, n, 4), device=dev) if with_obs else None,
-                   action=torch.empty((T, n), dtype=torch.float32 if self.cfg.continuous else torch.int32, device=dev),
+                   action=(torch.empty((T, n, self.action_dim) if self.turn_mode else (T, n), dtype=torch.float32, device=dev)
+                           if self.cfg.continuous else torch.empty((T, n), dtype=torch.int32, device=dev)),
                    reward=torch.empty((T, n), device=dev), done=torch.empty((T, n), dtype=torch.uint8, device=dev),
                    result=torch.empty((T, n), dtype=torch.uint8, device=dev))
         ro = S2DGtcRollout()

@@ -4,8 +4,8 @@
  * as a second built-in batched task of libs2d_hip.so.  Same conventions as s2d.h.
  *
  *   s2d_gtc_reset   GoToCenterEnv.reset   python_sample_soccer_env.py:115-134
- *   s2d_gtc_step    GoToCenterEnv.step    python_sample_soccer_env.py:136-234
- *   obs             GoToCenterEnv._get_obs :236-255  [angle_diff/180, body/180, x/52.5, y/34]
+ *   s2d_gtc_step    GoToCenterEnv.step    python_sample_soccer_env.py:136-233
+ *   obs             GoToCenterEnv._get_obs :235-255  [angle_diff/180, body/180, x/52.5, y/34]
  */
 #ifndef S2D_GTC_H_
 #define S2D_GTC_H_
@@ -18,14 +18,18 @@ extern "C" {
 
 typedef struct S2DGtcConfig {
   uint32_t abi_version, struct_bytes;
-  double x_min, x_max, y_min, y_max;      /* -52.5 52.5 -34 34      :91-92  */
-  double min_distance_to_center;          /* 5.0                    :96     */
-  int32_t max_steps;                      /* 200                    :95     */
-  int32_t continuous;                     /* 0: Discrete(16) dash_r = (a/16 - .5)*2  :171-174; 1: Box(-1,1,(1,)) clipped :167-170 */
+  double x_min, x_max, y_min, y_max;      /* -52.5 52.5 -34 34      :93-94  */
+  double min_distance_to_center;          /* 5.0                    :98     */
+  int32_t max_steps;                      /* 200                    :97     */
+  int32_t continuous;                     /* 0: Discrete(16) dash_r = (a/16 - .5)*2  :163-166; 1: Box(-1,1,(1,)) clipped :159-162 */
   uint64_t seed;
   int64_t env_id_offset;
   int32_t auto_reset;
-  int32_t reserved[3];
+  /* the script's --turn / --useturn / --actor_out_size switches (:70-79, :142-158; argparse defaults
+   * True / True / 4, :356-359).  turn && continuous: Box(-1,1,(actor_out_size,)), actions[0] = dash angle;
+   * with use_turn also actions[1] = turn angle, [2] = dash logit, [3] = turn logit, softmax([turn, dash]),
+   * turn chosen iff U(0,1) < p[0] (:149-152); a turn changes the body, a dash does not. */
+  int32_t turn, use_turn, actor_out_size;   /* 0, 0, 1 by default (the class's own defaults, :66) */
 } S2DGtcConfig;
 
 typedef struct S2DGtcBuffers {
@@ -35,7 +39,7 @@ typedef struct S2DGtcBuffers {
   float *obs;            /* [N][4] */
   float *reward;         /* [N] */
   uint8_t *done;         /* [N] terminated or truncated */
-  uint8_t *result;       /* [N] S2D_RESULT_* ('' / 'Goal' / 'Out' / 'Timeout', :199-214) */
+  uint8_t *result;       /* [N] S2D_RESULT_* ('' / 'Goal' / 'Out' / 'Timeout', :198-217) */
   float *terminal_obs;   /* [N][4] */
   unsigned long long *stats;   /* [S2D_STATS_STRIPES][8]: env-steps, Goal, Out, Timeout */
 } S2DGtcBuffers;
@@ -50,8 +54,12 @@ int s2d_gtc_create(const S2DGtcConfig *cfg, int64_t n_envs, int device, void *ar
 void s2d_gtc_destroy(S2DGtcHandle h);
 int s2d_gtc_buffer_offsets(S2DGtcHandle h, int64_t *offsets, int n_offsets);
 int s2d_gtc_reset(S2DGtcHandle h, const uint8_t *mask_dev, void *stream);
-/* actions: int32[N] (discrete) or float[N] (continuous); NULL = uniform random policy */
+/* actions: int32[N] (discrete), float[N] (continuous) or float[N][actor_out_size] (turn && continuous);
+ * NULL = uniform random policy */
 int s2d_gtc_step(S2DGtcHandle h, const void *actions_dev, void *stream);
+/* same, with the turn / dash selection uniforms of :151 supplied by the caller (float[N] in [0,1)) instead of
+ * the engine's Philox SELECT stream -- for callers that own the RNG, and for the reference-fixture tests */
+int s2d_gtc_step_u(S2DGtcHandle h, const void *actions_dev, const float *select_u_dev, void *stream);
 int s2d_gtc_rollout(S2DGtcHandle h, int n_steps, const S2DGtcRollout *out, void *stream);   /* random policy */
 
 #ifdef __cplusplus

@@ -141,6 +141,34 @@ class Discrete(_Space):
 class Env:
     metadata = {}
 
+    def reset(self, seed=None, options=None):      # gym.Env.reset: seeds self.np_random only; nothing the path reads
+        return None
+
+
+def install_sb3():
+    """``stable_baselines3`` is imported at module level by python_sample_soccer_env.py (:9) and by
+    utils/info_collector_callback.py; GoToCenterEnv itself never touches it.  Attribute holders only."""
+    if "stable_baselines3" in sys.modules:
+        return
+    sb3 = types.ModuleType("stable_baselines3")
+
+    class _Algo:
+        def __init__(self, *a, **k):
+            raise RuntimeError("stand-in: stable_baselines3 is not installed")
+
+    class BaseCallback:
+        def __init__(self, verbose=0):
+            self.verbose = verbose
+
+    common = types.ModuleType("stable_baselines3.common")
+    cb = types.ModuleType("stable_baselines3.common.callbacks")
+    cb.BaseCallback = BaseCallback
+    sb3.DQN = sb3.DDPG = _Algo
+    sb3.common, common.callbacks = common, cb
+    sys.modules["stable_baselines3"] = sb3
+    sys.modules["stable_baselines3.common"] = common
+    sys.modules["stable_baselines3.common.callbacks"] = cb
+
 
 def install():
     """Put the stand-ins into sys.modules (idempotent)."""

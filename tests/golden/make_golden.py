@@ -15,6 +15,12 @@ gRPC processes, soccer_2d_env.py:71-95 -- never runs):
 part of their published behaviour the path touches (see its docstring).  The fixtures
 are DATA ONLY (inputs + expected outputs); no reference source is copied.
 
+  GTC GoToCenterEnv.reset / step / _get_obs      python_sample_soccer_env.py:115-255
+      (the module is imported with sys.argv = ['x'] and cwd = a temp dir: it runs argparse and creates
+      a logs/ directory at import, :355-372; stable_baselines3 is a stand-in, only imported, never used)
+  reset_dist.json: histograms of >= 100 000 runs of the reference's trainer_reset_actions (distributional
+      fixture for the engine's Philox samplers)
+
 Run (in the build container, where /root/reference exists):
     python tests/golden/make_golden.py
 The GPU box never runs this; it only reads the committed JSON.
@@ -385,6 +391,212 @@ def gen_wire():
     return out
 
 
+# ----------------------------------------------------------------------------- GoToCenterEnv (python_sample_soccer_env.py)
+def import_gtc_module():
+    """Import the reference's python_sample_soccer_env.py.  It parses sys.argv and creates ./logs/<stamp>/ at
+    import (:355-372), so argv is patched and the cwd is a temp dir for the duration of the import."""
+    import tempfile
+    _standins.install_sb3()
+    old_argv, old_cwd = sys.argv, os.getcwd()
+    tmp = tempfile.mkdtemp(prefix='gtc_golden_')
+    try:
+        sys.argv = ['x']
+        os.chdir(tmp)
+        import python_sample_soccer_env as gm
+    finally:
+        sys.argv = old_argv
+        os.chdir(old_cwd)
+    for name in ('SampleRL', 'Train', 'Test'):
+        lg = logging.getLogger(name)
+        lg.handlers[:] = []
+        lg.addHandler(logging.NullHandler())
+        lg.propagate = False
+        lg.setLevel(logging.CRITICAL)
+    return gm
+
+
+class _UniformRecorder:
+    """np.random.uniform of a seeded RandomState, recording what the reference asked for and got."""
+
+    def __init__(self, seed):
+        self.rs, self.draws = np.random.RandomState(seed), []
+
+    def __call__(self, low, high):
+        v = float(self.rs.uniform(low, high))
+        self.draws.append({'low': float(low), 'high': float(high), 'v': v})
+        return v
+
+
+def gen_gtc():
+    gm = import_gtc_module()
+    GoToCenterEnv = gm.GoToCenterEnv
+    real_uniform, real_rand = np.random.uniform, np.random.rand
+    out = {'numpy': np.__version__, 'resets': [], 'sequences': []}
+
+    def snapshot(env):
+        return {'x': float(env.x), 'y': float(env.y), 'body': float(env.body_angle_deg), 'step_count': int(env.step_count),
+                'prev_distance': float(env.prev_distance), 'prev_angle_diff': float(env.prev_angle_diff)}
+
+    def do_reset(env, seed):
+        rec = _UniformRecorder(seed)
+        np.random.uniform = rec
+        try:
+            obs, info = env.reset()
+        finally:
+            np.random.uniform = real_uniform
+        assert info == {} and obs.dtype == np.float32 and obs.shape == (4,)
+        return rec.draws, obs
+
+    # ---- resets :115-134
+    for i in range(96):
+        env = GoToCenterEnv()
+        draws, obs = do_reset(env, 7000 + i)
+        assert [d['low'] for d in draws] == [-52.5, -34.0, -180.0]
+        out['resets'].append({'draws': draws, 'state': snapshot(env), 'obs': [float(v) for v in obs]})
+
+    # ---- step sequences :136-233
+    MODES = {
+        'discrete': dict(continuous=False, turn=False, actor_out_size=1, use_turn=False),
+        'continuous': dict(continuous=True, turn=False, actor_out_size=1, use_turn=False),
+        'turn1': dict(continuous=True, turn=True, actor_out_size=1, use_turn=False),
+        'turn4': dict(continuous=True, turn=True, actor_out_size=4, use_turn=False),
+        'turn4_useturn': dict(continuous=True, turn=True, actor_out_size=4, use_turn=True),   # the script's default (:356-359)
+    }
+
+    def run_sequence(mode, start, actions, us=None, note='', attrs=None, f32=False):
+        """start = (x, y, body, step_count); returns the fixture row or None if a decision is too close to call in fp32."""
+        kw = MODES[mode]
+        env = GoToCenterEnv(**kw)
+        do_reset(env, 1)
+        for k, v in (attrs or {}).items():
+            setattr(env, k, v)
+        env.x, env.y, env.body_angle_deg, env.step_count = float(start[0]), float(start[1]), float(start[2]), int(start[3])
+        env.prev_distance = np.sqrt(env.x ** 2 + env.y ** 2)                       # as reset does, :127-129
+        env.prev_angle_diff = gm.diff_angle_deg_abs(env.body_angle_deg, gm.angle_to_point_deg(env.x, env.y, 0.0, 0.0))
+        row = {'mode': mode, 'note': note, 'kwargs': kw, 'attrs': attrs or {}, 'f32_actions': bool(f32),
+               'start': snapshot(env), 'obs0': [float(v) for v in env._get_obs()], 'steps': []}
+        safe = True
+        for t, a in enumerate(actions):
+            u = None if us is None else us[t]
+            if kw['continuous']:
+                arg = np.asarray(a, dtype=np.float32 if f32 else np.float64).reshape(-1)
+            else:
+                arg = int(a)
+            if u is not None:
+                np.random.rand = lambda u=u: u
+            try:
+                obs, reward, done, done2, info = env.step(arg)
+            finally:
+                np.random.rand = real_rand
+            assert done == done2 and obs.dtype == np.float32
+            if mode == 'turn4_useturn':
+                cl = np.clip(np.asarray(a, dtype=np.float64), -1, 1)
+                p0 = np.exp(cl[3]) / (np.exp(cl[3]) + np.exp(cl[2]))
+                safe &= abs(u - p0) > 1e-3
+            d = float(np.hypot(env.x, env.y))
+            edge = min(abs(d - env.min_distance_to_center), abs(env.x - env.x_min), abs(env.x - env.x_max),
+                       abs(env.y - env.y_min), abs(env.y - env.y_max))
+            if 'exact' not in note:
+                safe &= edge > 2e-3
+            row['steps'].append({'a': [float(v) for v in np.asarray(a, dtype=np.float64).reshape(-1)], 'u': u,
+                                 'obs': [float(v) for v in obs], 'reward': float(reward), 'done': bool(done),
+                                 'result': info['result'], **snapshot(env)})
+            if done:
+                break
+        return row if safe else None
+
+    def rand_action(rs, mode):
+        if mode == 'discrete':
+            return int(rs.randint(0, 16))
+        n = MODES[mode]['actor_out_size']
+        return [float(v) for v in rs.uniform(-1.3, 1.3, size=n)]          # beyond [-1, 1]: the clip is pinned
+
+    rs = np.random.RandomState(31)
+    for mode in MODES:
+        got = 0
+        while got < 16:
+            start = (rs.uniform(-50, 50), rs.uniform(-32, 32), rs.uniform(-180, 180), 0)
+            L = int(rs.randint(5, 60))
+            acts = [rand_action(rs, mode) for _ in range(L)]
+            us = [float(rs.uniform()) for _ in range(L)] if mode == 'turn4_useturn' else None
+            row = run_sequence(mode, start, acts, us, note=f'random {got}', f32=(got % 4 == 3 and mode != 'discrete'))
+            if row is not None:
+                out['sequences'].append(row)
+                got += 1
+    seq = out['sequences']
+    # terminal cases and the if / elif priority of :203-217  (Out > Goal > Timeout)
+    seq.append(run_sequence('discrete', (5.9, 0.0, 180.0, 0), [8], note='goal'))
+    seq.append(run_sequence('discrete', (6.0, 0.0, 180.0, 0), [8, 8], note='exact: d == 5 is not a goal, then goal'))
+    seq.append(run_sequence('discrete', (52.0, 0.0, 0.0, 0), [8], note='out +x'))
+    seq.append(run_sequence('discrete', (51.5, 0.0, 0.0, 0), [8, 8], note='exact: x == 52.5 is not out, then out'))
+    seq.append(run_sequence('discrete', (0.0, -33.5, -90.0, 50), [8], attrs={'min_distance_to_center': 1.0}, note='out -y'))
+    seq.append(run_sequence('discrete', (30.0, 0.0, 180.0, 198), [8, 8], note='timeout: step_count 199 no, 200 yes (>=)'))
+    seq.append(run_sequence('discrete', (30.0, 0.0, 180.0, 199), [8], note='timeout at 200'))
+    seq.append(run_sequence('discrete', (30.0, 0.0, 180.0, 0), [8] * 6, attrs={'max_steps': 4}, note='max_steps attr = 4'))
+    seq.append(run_sequence('discrete', (5.9, 0.0, 180.0, 199), [8], note='priority: goal beats timeout'))
+    seq.append(run_sequence('discrete', (52.0, 0.0, 0.0, 199), [8], note='priority: out beats timeout'))
+    seq.append(run_sequence('discrete', (3.5, 0.0, 0.0, 199), [8], attrs={'x_max': 4.0}, note='priority: out beats goal and timeout'))
+    seq.append(run_sequence('continuous', (20.0, 10.0, 45.0, 0), [[2.0], [-3.0], [1.0], [-1.0], [0.0]], note='clip'))
+    # the use_turn mode: forced turns (u = 0) never move -> a natural 200-step timeout; forced dashes (u -> 1)
+    seq.append(run_sequence('turn4_useturn', (20.0, 10.0, 45.0, 0), [[0.3, 0.05, -0.5, 0.5]] * 200, [0.0] * 200, note='turn only: natural timeout'))
+    seq.append(run_sequence('turn4_useturn', (20.0, 10.0, 45.0, 0), [[0.0, 0.9, 0.5, -0.5]] * 40, [0.999] * 40, note='dash only'))
+    seq.append(run_sequence('turn4_useturn', (-30.0, -20.0, -120.0, 0),
+                            [[0.1 * k - 1.0, 0.7 - 0.1 * k, 1.0, 1.0] for k in range(20)], [0.25, 0.75] * 10, note='p0 = 0.5, alternating'))
+    assert all(r is not None for r in seq)
+    res = {r['steps'][-1]['result'] for r in seq}
+    assert res >= {'', 'Goal', 'Out', 'Timeout'}, res
+    assert any(st['u'] is not None and st['body'] != r['start']['body'] for r in seq for st in r['steps'])
+    return out
+
+
+# ----------------------------------------------------------------------------- distribution of the reset sampler
+def gen_reset_dist(n_runs=120000):
+    """Run the reference's trainer_reset_actions n_runs times with its own (seeded) `random` module and keep
+    histograms: the integer grids of :173-181 and the accepted ball velocity of :202-212 (speed in 30 bins of 0.1,
+    direction in 36 bins of 10 degrees, number of tries).  Pins the DISTRIBUTION of the engine's Philox samplers."""
+    import sample_environments.reach_ball_env as mod
+
+    class _Counting:
+        def __init__(self, seed):
+            self.r, self.tries = random.Random(seed), 0
+
+        def randint(self, a, b):
+            return self.r.randint(a, b)
+
+        def random(self):
+            self.tries += 1
+            return self.r.random()
+
+    env = make_env(use_continuous_action=False, change_ball_position=True, change_ball_velocity=True)
+    rec = _Counting(20261004)
+    real = mod.random
+    mod.random = rec
+    h = {'px': np.zeros(101, np.int64), 'py': np.zeros(61, np.int64), 'body': np.zeros(361, np.int64),
+         'bx': np.zeros(101, np.int64), 'by': np.zeros(61, np.int64), 'speed': np.zeros(30, np.int64),
+         'dir': np.zeros(36, np.int64), 'tries': np.zeros(16, np.int64)}
+    try:
+        for _ in range(n_runs):
+            rec.tries = 0
+            acts = env.trainer_reset_actions()
+            mb, mp = acts[0].do_move_ball, acts[1].do_move_player
+            h['px'][int(round(mp.position.x)) + 50] += 1
+            h['py'][int(round(mp.position.y)) + 30] += 1
+            h['body'][int(round(mp.body_direction))] += 1            # randint(0, 360), sent un-normalised (:175, :193)
+            h['bx'][int(round(mb.position.x)) + 50] += 1
+            h['by'][int(round(mb.position.y)) + 30] += 1
+            vx, vy = float(mb.velocity.x), float(mb.velocity.y)
+            sp = math.hypot(vx, vy)
+            h['speed'][min(29, int(sp / 0.1))] += 1
+            h['dir'][int(((math.degrees(math.atan2(vy, vx)) + 360.0 + 5.0) % 360.0) // 10.0)] += 1   # bins centred on multiples of 10
+            h['tries'][min(15, rec.tries - 1)] += 1
+    finally:
+        mod.random = real
+    return {'runs': n_runs, 'seed': 20261004, 'kwargs': {'change_ball_position': True, 'change_ball_velocity': True, 'max_steps': 200},
+            'bins': {'speed': '30 bins of 0.1 over [0, 3)', 'dir': '36 bins of 10 deg centred on 0, 10, ..., 350 (direction of the accepted velocity)',
+                     'tries': 'number of candidates drawn, 1..15, last bin = 16 and more', 'body': 'randint(0, 360) as sent'},
+            'hist': {k: v.tolist() for k, v in h.items()}}
+
+
 def main():
     out = {
         'wire.json': gen_wire(),
@@ -392,6 +604,8 @@ def main():
         'obs.json': gen_obs(),
         'reward.json': gen_reward(),
         'reset.json': gen_reset(),
+        'reset_dist.json': gen_reset_dist(),
+        'gtc.json': gen_gtc(),
     }
     for name, data in out.items():
         with open(os.path.join(HERE, name), 'w') as f:
