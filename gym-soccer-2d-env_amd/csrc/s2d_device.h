@@ -26,6 +26,11 @@
 #include "../../include/s2d.h"
 
 #define S2D_DEV __device__ __forceinline__
+// S2D_XSKIP: timing-only experiment builds (profiles/experiments/ab_rollout.py) that drop one piece of the cycle
+// to bound what it costs -- WRONG results by construction; never defined in the product build.
+#ifndef S2D_XSKIP
+#define S2D_XSKIP 0
+#endif
 
 // action decoding mode (template parameter): reach_ball_env.py:39-47
 enum { S2D_MODE_DISCRETE = 0, S2D_MODE_CONT1 = 1, S2D_MODE_TURN4 = 2 };
@@ -51,7 +56,9 @@ struct S2DRare {  // device memory, read inside rare branches only
   float recover_init;
   float ball_position_x, ball_position_y, ball_speed, ball_direction, travel_factor;
   int change_ball_position, change_ball_velocity;
-  int pad[3];
+  int tab_len;        // entries of S2DTables (0: the dash-only fast path is off for this configuration)
+  float tab_power;    // the clamped power of every Dash(100, .) the tables were built with
+  int pad[1];
 };
 
 // The loop-invariant float parameters arrive in SGPRs (kernarg).  A rollout loop keeps ~45 of
@@ -198,11 +205,13 @@ struct Env {
   float px, py, vx, vy, body, stamina, effort, recovery, capacity;
   float bx, by, bvx, bvy, prev_dist, prev_angle;
   int step_number, cycle;
+  int episode;   // resets so far = index of the current episode: the RESET stream's counter word
 };
 enum {  // SoA plane order == S2DBuffers state pointers
   F_PX, F_PY, F_VX, F_VY, F_BODY, F_STAMINA, F_EFFORT, F_RECOVERY, F_CAPACITY,
   F_BX, F_BY, F_BVX, F_BVY, F_PREV_DIST, F_PREV_ANGLE, F_STEP, F_CYCLE,
   F_POLICY,   // policy_step: touched only by launches that draw in-engine policy randomness
+  F_EPISODE,  // episode index (read by every launch that can reset, written when it did)
   F_COUNT
 };
 
@@ -217,6 +226,7 @@ S2D_DEV void env_load(Env& e, const float* __restrict__ S, int64_t stride, int64
   e.prev_dist = S[F_PREV_DIST * stride + i]; e.prev_angle = S[F_PREV_ANGLE * stride + i];
   e.step_number = __float_as_int(S[F_STEP * stride + i]);
   e.cycle = __float_as_int(S[F_CYCLE * stride + i]);
+  e.episode = __float_as_int(S[F_EPISODE * stride + i]);
 }
 S2D_DEV void env_store(const Env& e, float* __restrict__ S, int64_t stride, int64_t i) {
   S[F_PX * stride + i] = e.px; S[F_PY * stride + i] = e.py;
@@ -229,6 +239,7 @@ S2D_DEV void env_store(const Env& e, float* __restrict__ S, int64_t stride, int6
   S[F_PREV_DIST * stride + i] = e.prev_dist; S[F_PREV_ANGLE * stride + i] = e.prev_angle;
   S[F_STEP * stride + i] = __int_as_float(e.step_number);
   S[F_CYCLE * stride + i] = __int_as_float(e.cycle);
+  S[F_EPISODE * stride + i] = __int_as_float(e.episode);
 }
 
 // ------------------------------------------------------------------ A2 action map
@@ -290,7 +301,11 @@ S2D_DEV int judge_sq(const S2DHot& p, float px, float py, float d2, int step_num
 // ball half (o[4..9]).
 S2D_DEV float observe_player(const S2DHot& p, float px, float py, float body, float bx, float by, float* o) {
   float dx = bx - px, dy = by - py;
+#if S2D_XSKIP & 4
+  float player_to_ball = dx + dy;
+#else
   float player_to_ball = atan2_deg(dy, dx);              // :95 / :123
+#endif
   float rel = norm_deg(player_to_ball - body);           // :96 / :124
   o[0] = rel * 0.005555555555555556f;                    // :98-101  (x/180, x/52.5, x/34)
   o[1] = body * 0.005555555555555556f;
@@ -299,8 +314,12 @@ S2D_DEV float observe_player(const S2DHot& p, float px, float py, float body, fl
   return rel;
 }
 S2D_DEV void observe_ball(const S2DHot& p, float bx, float by, float bvx, float bvy, float* o) {
+#if S2D_XSKIP & 8
+  float ball_speed = bvx + bvy, ball_direction = bvx - bvy;
+#else
   float ball_speed = hypot2(bvx, bvy);                   // :91
   float ball_direction = atan2_deg(bvy, bvx);            // :92
+#endif
   o[4] = bx * p.inv_half_l;                              // :102-107  (x/52.5, x/34, x/3, x/360)
   o[5] = by * p.inv_half_w;
   o[6] = ball_speed * 0.3333333333333333f;
@@ -366,7 +385,11 @@ S2D_DEV void dash_apply(const S2DHot& p, Env& e, const CmdPrep& c, float& ax, fl
   float acc = fabsf(e.effort * power * c.dir_rate * p.dash_power_rate);
   float dir = back ? c.dir + 180.0f : c.dir;
   float sn, cs;
+#if S2D_XSKIP & 2
+  sn = dir * 0.001f; cs = 0.8f;
+#else
   sincos_deg(norm_deg(e.body + dir), sn, cs);
+#endif
   ax = acc * cs;
   ay = acc * sn;
 }
@@ -401,6 +424,9 @@ S2D_DEV void add_noise(float& vx, float& vy, float rnd, float u_mag, float sn, f
   vx += mag * cs; vy += mag * sn;
 }
 S2D_DEV void update_stamina(const S2DHot& p, Env& e) {
+#if S2D_XSKIP & 1
+  return;
+#endif
   float st = e.stamina;
   float rdec = e.recovery - p.recover_dec;
   rdec = rdec > p.recover_min ? rdec : p.recover_min;
@@ -464,19 +490,10 @@ S2D_DEV float move_sequential(const S2DHot& p, const S2DRare* __restrict__ rp, E
 // on the unclamped values -- which are the sequential conditions as long as none fires -- and
 // only a wave with a lane that trips one re-runs those lanes through move_sequential: one
 // branch per cycle instead of four.  Returns |ball - player|^2 after the cycle (judge_sq).
-template <bool NOISE, bool HAS_CMD>
-S2D_DEV float sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, int cmd, const CmdPrep& c,
-                        const NoiseIn& nz) {
-  float ax = 0.0f, ay = 0.0f;
-  bool accel = false;
-  if (HAS_CMD) {
-    if (cmd == S2D_CMD_DASH) {
-      dash_apply(p, e, c, ax, ay);
-      accel = true;
-    } else if (cmd == S2D_CMD_TURN) {
-      cmd_turn(p, e, c.dir, NOISE, nz.tu);
-    }
-  }
+// the integration of one cycle for given player acceleration: MPObject::_inc for player and ball + the collision
+template <bool NOISE>
+S2D_DEV float sim_move(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, bool accel, float ax, float ay,
+                       const NoiseIn& nz) {
   float d2;
   if (NOISE) {
     d2 = move_sequential<true>(p, rp, e, accel, ax, ay, nz);
@@ -496,10 +513,63 @@ S2D_DEV float sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e,
       d2 = move_sequential<false>(p, rp, e, accel, ax, ay, nz);
     }
   }
+  return d2;
+}
+// referee tick + MPObject::_turn (decay) of both objects
+S2D_DEV void sim_tick_decay(const S2DHot& p, Env& e) {
   e.cycle = (int)((uint32_t)e.cycle + 1u);               // wraps after 2^31 cycles (~47 min of fused rollouts) without UB
   e.vx *= p.player_decay; e.vy *= p.player_decay;
   e.bvx *= p.ball_decay; e.bvy *= p.ball_decay;
+}
+template <bool NOISE, bool HAS_CMD>
+S2D_DEV float sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, int cmd, const CmdPrep& c,
+                        const NoiseIn& nz) {
+  float ax = 0.0f, ay = 0.0f;
+  bool accel = false;
+  if (HAS_CMD) {
+    if (cmd == S2D_CMD_DASH) {
+      dash_apply(p, e, c, ax, ay);
+      accel = true;
+    } else if (cmd == S2D_CMD_TURN) {
+      cmd_turn(p, e, c.dir, NOISE, nz.tu);
+    }
+  }
+  const float d2 = sim_move<NOISE>(p, rp, e, accel, ax, ay, nz);
+  sim_tick_decay(p, e);
   update_stamina(p, e);
+  return d2;
+}
+
+// ---- the dash-only fast path of the rollout pipeline ------------------------------------------------------------------
+// In the discrete and 1-D continuous action modes every command is Dash(100, dir) (reach_ball_env.py:79-85), so stamina,
+// effort, recovery and capacity are functions of the episode's step number alone, and -- with an integer dash_angle_step
+// and the integer body angles the reset grid produces (:175; nothing but a Turn changes the body) -- the dash direction is
+// a whole number of degrees.  S2DTables (built once per engine by the very functions above) holds, per step number s:
+// the stamina words BEFORE the step and ep[s] = effort * spent power of the dash (dash_apply's operands, in its order).
+// A group whose envs all sit on that table (checked when the launch starts) simulates a cycle without the stamina model
+// and reads sine / cosine from a 361-entry table of sincos_deg at whole degrees: same values, ~110 instructions fewer.
+#define S2D_TAB_MAX 256
+struct S2DTables { float ep[S2D_TAB_MAX], stamina[S2D_TAB_MAX], effort[S2D_TAB_MAX], recovery[S2D_TAB_MAX], capacity[S2D_TAB_MAX]; };
+S2D_DEV void tables_build(const S2DHot& p, float recover_init, float cmd_power, int len, S2DTables& t) {
+  Env e{};
+  e.stamina = p.stamina_max; e.recovery = recover_init; e.effort = p.effort_init; e.capacity = p.stamina_capacity;   // (recover)
+  update_stamina(p, e);                                  // the command-less cycle a reset consumes
+  for (int s = 0; s < len; ++s) {
+    t.stamina[s] = e.stamina; t.effort[s] = e.effort; t.recovery[s] = e.recovery; t.capacity[s] = e.capacity;
+    const float avail = e.stamina + p.extra_stamina;     // dash_apply with power = cmd_power > 0 (never a back dash)
+    const float need = (cmd_power > avail) ? avail : cmd_power;
+    const float st = e.stamina - need;
+    t.ep[s] = e.effort * need;
+    e.stamina = st > 0.0f ? st : 0.0f;
+    update_stamina(p, e);
+  }
+}
+template <bool NOISE>
+S2D_DEV float sim_cycle_dash_fast(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, float ep, float dir_rate,
+                                  float sn, float cs, const NoiseIn& nz) {
+  const float acc = fabsf(ep * dir_rate * p.dash_power_rate);   // dash_apply: |effort * power * dir_rate * dash_power_rate|
+  const float d2 = sim_move<NOISE>(p, rp, e, true, acc * cs, acc * sn, nz);
+  sim_tick_decay(p, e);
   return d2;
 }
 
@@ -511,11 +581,11 @@ S2D_DEV float sim_cycle(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e,
 #define S2D_MAX_VEL_TRIES 255
 struct ResetSample { float px, py, body, bx, by, bvx, bvy; };
 
-// RESET stream counter word = the cycle at which the CURRENT episode began
-// (cycle - step_number - 1: constant during an episode, unique per episode).  The sample of the
-// NEXT episode is therefore computable at any time during the current one, which lets the
-// rollout kernels prepare samples for many lanes at once instead of one lane at a time.
-S2D_DEV uint32_t reset_key(const Env& e) { return (uint32_t)e.cycle - (uint32_t)e.step_number - 1u; }
+// RESET stream counter word = the index of the episode the reset STARTS (1, 2, ...; Env::episode counts the resets so
+// far).  The state a reset leaves behind is therefore a function of (env id, episode index) alone -- it does not depend on
+// how long earlier episodes lasted -- so the rollout kernels prepare the next few episodes of every env ahead of the
+// simulation, off the simulating wave, and a reset becomes a copy.
+S2D_DEV uint32_t reset_key(const Env& e) { return (uint32_t)e.episode + 1u; }
 
 S2D_DEV ResetSample reset_sample(const S2DHot& p, const S2DRare& r, uint32_t gid_lo, uint32_t gid_hi, uint32_t c0) {
   U4 w = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 0);
@@ -588,6 +658,7 @@ S2D_DEV void episode_begin(Env& e, const NextEpisode& q) {
   e.bx = q.bx; e.by = q.by; e.bvx = q.bvx; e.bvy = q.bvy;
   e.step_number = 0;                                     // reach_ball_env.py:172
   e.cycle = (int)((uint32_t)e.cycle + 1u);               // the command-less cycle (soccer_2d_env.py:190)
+  e.episode = (int)((uint32_t)e.episode + 1u);
 }
 // The observation a reset returns and the carry it seeds (reach_ball_env.py:163-168) are functions of that
 // prepared state alone, so they are prepared with it: o[0..9] = the new episode's first row, dist / rel = the carry.
@@ -605,5 +676,6 @@ S2D_DEV float env_reset(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e,
   const S2DRare r = *rp;                                 // one bulk scalar load for the whole path
   const uint32_t key = reset_key(e);
   ResetSample o = reset_sample(p, r, gid_lo, gid_hi, key);
+  e.episode = (int)key;
   return reset_apply<NOISE>(p, rp, e, gid_lo, gid_hi, o, r.recover_init, key);
 }

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "s2d_device.h"
 
@@ -23,20 +24,6 @@
 
 #ifndef S2D_BLOCK
 #define S2D_BLOCK 256
-#endif
-// S2D_PROFILE = 1 / 2 / 3: timing-only builds (profiles/experiments/ws_sections.py) that sum
-// s_memtime section timers of the policy / simulate / observe wave into statistics counters 4..7.
-#ifndef S2D_PROFILE
-#define S2D_PROFILE 0
-#endif
-#if S2D_PROFILE
-#define S2D_TICK_INIT(role_) unsigned long long tk_ = __builtin_readcyclecounter(), tacc_[4] = {0, 0, 0, 0}; const bool tick_on_ = (S2D_PROFILE == (role_))
-#define S2D_TICK(j) do { if (tick_on_) { unsigned long long now_ = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); tacc_[j] += now_ - tk_; tk_ = now_; } } while (0)
-#define S2D_TICK_FLUSH(stats_, lane_) do { if (tick_on_ && (lane_) == 0) { for (int j_ = 0; j_ < 4; ++j_) atomicAdd(&stats_stripe(stats_)[4 + j_], tacc_[j_]); } } while (0)
-#else
-#define S2D_TICK_INIT(role_) do { } while (0)
-#define S2D_TICK(j) do { } while (0)
-#define S2D_TICK_FLUSH(stats_, lane_) do { } while (0)
 #endif
 static constexpr int kBlock = S2D_BLOCK;
 static constexpr int kWave = 64;
@@ -238,6 +225,12 @@ S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, u
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
+S2D_DEV const S2DTables* tables_of(const S2DRare* rp) {
+  return reinterpret_cast<const S2DTables*>(reinterpret_cast<const char*>(rp) + 256);
+}
+__global__ void s2d_tables_kernel(S2DHot p, const S2DRare* __restrict__ rp, S2DTables* __restrict__ t) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && rp->tab_len > 0) tables_build(p, rp->recover_init, rp->tab_power, rp->tab_len, *t);
+}
 __global__ __launch_bounds__(kBlock) void s2d_init_kernel(S2DHot p, const S2DRare* __restrict__ rp,
                                                           float* __restrict__ S, int64_t stride, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -430,33 +423,40 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 // Wave-specialised rollout: a software pipeline of four waves through LDS.
 //
 // At N = 65 536 the unified kernel leaves ONE wave per SIMD: its ~560 instructions per cycle are a
-// single dependent stream (one instruction per ~4 clocks) plus LDS / store latencies, while the SIMD
-// could issue twice as fast (profiles/r01/instr_rate_gfx950.txt).  Here every group of 64 envs is a
-// workgroup of four waves, each one stage of the cycle:
+// single dependent stream, and one wave issues at most one instruction per ~5 clocks
+// (profiles/r01/instr_rate_gfx950.txt).  Here every group of 64 envs is a workgroup of four waves,
+// each one stage of the cycle:
 //   P-wave (policy):   action of step t (caller's, or Philox policy) -> decoded command, the
 //                      command-only half of the dash (clamps, direction rate), action record
-//   S-wave (simulate): command -> dash/turn -> integrate -> stamina -> done test -> reset
+//   S-wave (simulate): command -> dash/turn -> integrate -> stamina -> done test -> reset (a copy)
 //   A-wave (agent):    player half of the observation (angle to the ball), distance, reward,
 //                      labels, reward / done / result stores, episode counters, reward carry
 //   B-wave (ball):     ball half of the observation (speed, direction), and the transposed
 //                      observation block of the PREVIOUS step streamed out of LDS
-// In iteration s the P-wave works on step s, the S-wave on step s-1 (prefetching the command one
-// iteration ahead bought nothing and cost a fill cycle per launch), the A- and B-waves on
-// step s-2 (the B-wave also stores the observations of step s-3); the hand-offs are
-// double-buffered in LDS and ONE s_barrier per iteration separates them.  There is no feedback edge: policy
-// draws are keyed by policy_step (not by the cycle, which resets advance), the S-wave evaluates
-// the done conditions itself, the A-wave owns the reward carry.  The arithmetic is the same
-// functions in the same order as in the unified kernel, so the results are bit-identical.
-// Used for small batches; with more env groups per SIMD the unified kernel overlaps whole waves
-// instead and is kept.
+// In iteration s the P-wave works on step s, the S-wave on step s-1, the A- and B-waves on step s-2
+// (the B-wave also stores the observations of step s-3); the hand-offs are double-buffered in LDS and
+// ONE s_barrier per iteration separates them.  There is no feedback edge: policy draws are keyed by
+// policy_step (not by the cycle, which resets advance), the S-wave evaluates the done conditions
+// itself, the A-wave owns the reward carry.
+//
+// Resets.  What a reset leaves behind (trainer moves + recover + the command-less cycle + the first
+// observation and reward carry) is a function of (env id, episode index) alone, and drawing it -- two or more
+// Philox blocks, a rejection loop with sine / cosine, one simulator cycle, two atan2 -- costs ~1 us of a
+// single wave.  Round 1 did that on the simulating wave whenever an episode ended (in ~30 % of the
+// iterations), i.e. on the critical path of the whole group.  Now the next kSlots episodes of every env
+// are prepared BEFORE the loop by the three waves that would otherwise idle while the pipeline fills
+// (policy, agent, ball: one slot each), into LDS; a reset in the loop is a copy of 13 words by the
+// simulating wave and of the prepared first observation by the observing waves.  Only an env that ends
+// more than kSlots episodes within one launch prepares inline (and publishes through the slot it used
+// longest ago, which every reader has left at least two barriers earlier).
+// The arithmetic is the same functions in the same order as in the unified kernel: results are bit-identical.
 enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_FLAGS, WS_WORDS };
-enum { WP_DIST = S2D_OBS_DIM, WP_REL, WP_WORDS };             // post[] rows without noise
 enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_NPM, WA_NPS, WA_NPC, WA_NBM, WA_NBS, WA_NBC, WA_NTU, WA_WORDS };   // command + prepared noise
+enum { SL_FIRST = 13, SL_DIST = SL_FIRST + S2D_OBS_DIM, SL_REL, SL_WORDS };   // slot = NextEpisode (13 words) + FirstObs (12)
+static constexpr int kSlots = 3;
 // Issue priority of the four role waves of a group (s_setprio): a SIMD holds one wave of each role (of four
 // different groups, profiles/r01/wave_placement.txt), and the arbiter should prefer them by their slack --
-// simulate (none) first, the policy wave (half a cycle of slack) last.  Steady clocks, 65 536 envs, G env-steps/s
-// (simulate/agent/ball/policy): 0/0/0/0 71.3, 1/0/0/0 75.2, 1/1/1/0 76.5, 2/2/1/0 78.5, 2/1/2/0 79.8, 3/2/1/0 80.0,
-// 3/1/1/0 80.3, 2/1/1/0 80.2 (noise on: 54.4 for 1/1/1/0, 56.1 for 3/2/1/0, 56.9 for 2/1/1/0).  Overridable for experiments.
+// simulate (none) first, the policy wave (half a cycle of slack) last.  Overridable for experiments.
 #ifndef S2D_PRIO_S
 #define S2D_PRIO_S 2
 #endif
@@ -468,19 +468,39 @@ enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_NPM, WA_NPS, WA_NPC, WA_NBM, WA_NBS
 #endif
 static constexpr int kWsBlock = 4 * kWave;
 
+// one prepared episode of this lane's env -> LDS slot (struct-of-arrays over the lanes)
+template <bool NOISE>
+S2D_DEV void slot_fill(const S2DHot& p, const S2DRare* __restrict__ rp, float (*slot)[kWave], int lane, uint32_t gl,
+                       uint32_t gh, uint32_t episode) {
+  const S2DRare r = *rp;
+  const NextEpisode q = episode_prepare<NOISE>(p, rp, r, gl, gh, episode);
+  slot[0][lane] = q.px; slot[1][lane] = q.py; slot[2][lane] = q.vx; slot[3][lane] = q.vy; slot[4][lane] = q.body;
+  slot[5][lane] = q.stamina; slot[6][lane] = q.effort; slot[7][lane] = q.recovery; slot[8][lane] = q.capacity;
+  slot[9][lane] = q.bx; slot[10][lane] = q.by; slot[11][lane] = q.bvx; slot[12][lane] = q.bvy;
+  const FirstObs f = first_obs(p, q);
+#pragma unroll
+  for (int k = 0; k < S2D_OBS_DIM; ++k) slot[SL_FIRST + k][lane] = f.o[k];
+  slot[SL_DIST][lane] = f.dist; slot[SL_REL][lane] = f.rel;
+}
+S2D_DEV NextEpisode slot_take(const float (*slot)[kWave], int lane) {
+  return NextEpisode{slot[0][lane], slot[1][lane], slot[2][lane], slot[3][lane], slot[4][lane], slot[5][lane], slot[6][lane],
+                     slot[7][lane], slot[8][lane], slot[9][lane], slot[10][lane], slot[11][lane], slot[12][lane]};
+}
+
 template <int MODE, bool NOISE>
 __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
                                                                         float* __restrict__ S, int64_t stride,
                                                                         int64_t n, int n_steps,
                                                                         const void* __restrict__ actions, int kind,
                                                                         RolloutOut ro, StepOut o) {
-  __shared__ float act[2][WA_WORDS][kWave];                // decoded command of step t, double-buffered
+  constexpr int kActWords = NOISE ? (int)WA_WORDS : (int)WA_NPM;
+  __shared__ float act[2][kActWords][kWave];               // decoded command (+ prepared noise) of step t, double-buffered
   __shared__ float snap[2][WS_WORDS][kWave];               // post-cycle snapshot of step t, double-buffered
-  // envs that finished: the prepared first observation of the new episode and the carry it seeds
-  // (FirstObs: o[0..9], dist, rel)
-  __shared__ float post[2][WP_WORDS][kWave];
+  __shared__ float slots[kSlots][SL_WORDS][kWave];         // prepared episodes first_ep + k of every lane (see above)
   __shared__ __attribute__((aligned(16))) float tile[2][kObsTile];   // observation rows of step t, double-buffered
   __shared__ float4 act_lut[kWave];                        // decoded commands of a small discrete action space
+  __shared__ float ep_lds[S2D_TAB_MAX];                    // dash-only fast path: effort * power by step number
+  __shared__ float2 sc_lut[361];                           //   and (sin, cos) of the whole degrees -180 .. 180
   const int lane = threadIdx.x & (kWave - 1);
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 agent, 3 ball
   const int64_t wave_first = (int64_t)blockIdx.x * kWave;
@@ -489,6 +509,16 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   int64_t rows = n - wave_first; rows = rows > kWave ? kWave : rows;
   const int valid = (int)rows * S2D_OBS_DIM;
   const int n_iter = n_steps + 3;
+
+  // ---- before the loop: the three waves that idle while the pipeline fills prepare one future episode each
+  if (role != 1) {
+    if (active && p_sgpr.auto_reset) {
+      const uint64_t gid = (((uint64_t)p_sgpr.gid_hi << 32) | p_sgpr.gid_lo) + (uint64_t)i;
+      const uint32_t ep0 = reinterpret_cast<const uint32_t*>(S + F_EPISODE * stride)[i];
+      const int k = role == 0 ? 0 : role - 1;
+      slot_fill<NOISE>(p_sgpr, rp, slots[k], lane, (uint32_t)gid, (uint32_t)(gid >> 32), ep0 + 1u + (uint32_t)k);
+    }
+  }
 
   if (role == 0) {
     // ------------------------------------------------------------------ P-wave
@@ -514,7 +544,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       const CmdPrep c = cmd_prepare(p, c0, pw, d0);
       act_lut[lane] = make_float4(c.power, c.dir, c.dir_rate, d0);
     }
-    S2D_TICK_INIT(1);
+    __syncthreads();                                       // prepared episodes published
     for (int s = 0; s < n_iter; ++s) {
       if (s < n_steps && active) {
         const uint32_t k = k0 + (uint32_t)s;
@@ -532,7 +562,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         if (MODE == S2D_MODE_TURN4) act[b][WA_CMD][lane] = __int_as_float(cmd);
         act[b][WA_POWER][lane] = c.power;
         act[b][WA_DIR][lane] = c.dir; act[b][WA_RATE][lane] = c.dir_rate;
-        if (NOISE) {                                       // the state-independent half of this cycle's noise
+        if constexpr (NOISE) {                             // the state-independent half of this cycle's noise
           const NoiseIn nz = noise_prepare(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);
           act[b][WA_NPM][lane] = nz.pm; act[b][WA_NPS][lane] = nz.ps; act[b][WA_NPC][lane] = nz.pc;
           act[b][WA_NBM][lane] = nz.bm; act[b][WA_NBS][lane] = nz.bs; act[b][WA_NBC][lane] = nz.bc;
@@ -540,14 +570,8 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         }
         row += n;
       }
-#if S2D_PROFILE
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-      S2D_TICK(0);                                         // policy + command decode
       __syncthreads();
-      S2D_TICK(3);                                         // barrier
     }
-    S2D_TICK_FLUSH(o.stats, lane);
     if (active) {
       if (use_k) kplane[i] = k0 + (uint32_t)n_steps;
       o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
@@ -558,76 +582,90 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     const S2DHot p = hot_in_vgprs(p_sgpr);
     Env e;
     uint32_t gl = 0, gh = 0;
+    int nth = 0, j = 0;                                    // episodes this lane began in this launch; slot of the next one (nth mod kSlots)
     if (active) {
       env_load(e, S, stride, i);
       uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
       gl = (uint32_t)gid; gh = (uint32_t)(gid >> 32);
       asm volatile("" ::"v"(e.px), "v"(e.py), "v"(e.vx), "v"(e.vy), "v"(e.body), "v"(e.stamina), "v"(e.effort),
                    "v"(e.recovery), "v"(e.capacity), "v"(e.bx), "v"(e.by), "v"(e.bvx), "v"(e.bvy),
-                   "v"(e.step_number), "v"(e.cycle));
+                   "v"(e.step_number), "v"(e.cycle), "v"(e.episode));
     }
-    // the prepared next episode of this env (state + first observation, see episode_prepare) lives in registers
-    // here (VGPRs are plentiful in this wave), refilled for >= kRefillMin lanes at a time like the LDS tile of
-    // the unified kernel
-    bool have_prep = false;
-    NextEpisode nep{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    FirstObs fo{};
-    auto prepare = [&]() {
-      const S2DRare r = *rp;
-      nep = episode_prepare<NOISE>(p, rp, r, gl, gh, reset_key(e));
-      fo = first_obs(p, nep);
-    };
-    if (active && p.auto_reset) { prepare(); have_prep = true; }
-    int n_missing = 0;                                     // wave-uniform: active lanes without a prepared sample
-    S2D_TICK_INIT(2);
-    for (int s = 0; s < n_iter; ++s) {
-      if (s >= 1 && s <= n_steps) {                        // step s - 1
-        const int b = (s - 1) & 1;
-        if (n_missing >= kRefillMin) {                     // batched refill (scalar counter: no ballot in the hot path)
-          if (active && !have_prep) { prepare(); have_prep = true; }
-          n_missing = 0;
+    // Dash-only fast path (s2d_device.h, S2DTables): taken by a group whose envs all sit on the stamina table and have
+    // whole-degree body angles -- true for every state the engine itself produces in the dash-only modes; states loaded
+    // from elsewhere (or the turning mode) run the generic loop with the same results.
+    const S2DTables* const tb = tables_of(rp);
+    const int tab_len = MODE != S2D_MODE_TURN4 ? rp->tab_len : 0;
+    bool fast = false;
+    if (tab_len > 0) {
+      bool ok = true;
+      if (active) {
+        const int sn = e.step_number;
+        ok = sn >= 0 && sn < tab_len;
+        const int q = ok ? sn : 0;
+        ok = ok && e.stamina == tb->stamina[q] && e.effort == tb->effort[q] && e.recovery == tb->recovery[q] &&
+             e.capacity == tb->capacity[q] && e.body == rintf(e.body) && fabsf(e.body) <= 180.0f;
+      }
+      fast = __ballot(active && !ok) == 0ull;
+      if (fast) {
+        for (int k = lane; k < tab_len; k += kWave) ep_lds[k] = tb->ep[k];
+        for (int k = lane; k <= 360; k += kWave) {
+          float sn, cs;
+          sincos_deg((float)(k - 180), sn, cs);
+          sc_lut[k] = make_float2(sn, cs);
         }
-        if (active) {
-          S2D_TICK(0);                                     // refill check
+      }
+    }
+    __syncthreads();                                       // prepared episodes (and this wave's tables) published
+    auto loop = [&](auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
+      for (int s = 0; s < n_iter; ++s) {
+        if (s >= 1 && s <= n_steps && active) {            // step s - 1
+          const int b = (s - 1) & 1;
           int cmd = S2D_CMD_DASH;                          // only the turning mode has another command
           if (MODE == S2D_MODE_TURN4) cmd = __float_as_int(act[b][WA_CMD][lane]);
-          const CmdPrep c{act[b][WA_POWER][lane], act[b][WA_DIR][lane], act[b][WA_RATE][lane]};
           NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-          if (NOISE) {
+          if constexpr (NOISE) {
             nz = NoiseIn{act[b][WA_NPM][lane], act[b][WA_NPS][lane], act[b][WA_NPC][lane], act[b][WA_NBM][lane],
                          act[b][WA_NBS][lane], act[b][WA_NBC][lane], 0.0f};
             if (MODE == S2D_MODE_TURN4) nz.tu = act[b][WA_NTU][lane];
           }
-          e.step_number += 1;                              // reach_ball_env.py:55
-          const float d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);
-#if S2D_PROFILE
-          asm volatile("" ::"v"(e.px), "v"(e.py), "v"(e.bx), "v"(e.by), "v"(e.stamina), "v"(e.effort), "v"(e.vx), "v"(e.vy));
-          S2D_TICK(1);                                     // simulator cycle
-#endif
+          float d2;
+          if constexpr (FAST) {
+            const float ep = ep_lds[e.step_number];        // effort * power of the dash at this step number
+            const float2 sc = sc_lut[(int)norm_deg(e.body + act[b][WA_DIR][lane]) + 180];
+            e.step_number += 1;                            // reach_ball_env.py:55
+            d2 = sim_cycle_dash_fast<NOISE>(p, rp, e, ep, act[b][WA_RATE][lane], sc.x, sc.y, nz);
+          } else {
+            const CmdPrep c{act[b][WA_POWER][lane], act[b][WA_DIR][lane], act[b][WA_RATE][lane]};
+            e.step_number += 1;                            // reach_ball_env.py:55
+            d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);
+          }
           int flags = judge_sq(p, e.px, e.py, d2, e.step_number);
+          const bool took = flags && p.auto_reset;
           snap[b][WS_PX][lane] = e.px; snap[b][WS_PY][lane] = e.py; snap[b][WS_BODY][lane] = e.body;
           snap[b][WS_BX][lane] = e.bx; snap[b][WS_BY][lane] = e.by;
           snap[b][WS_BVX][lane] = e.bvx; snap[b][WS_BVY][lane] = e.bvy;
-          snap[b][WS_FLAGS][lane] = __int_as_float(flags);
-          if (flags && p.auto_reset) {                     // rare
-            if (!have_prep) prepare();                     // episode shorter than the refill cadence
-            episode_begin(e, nep);
-            have_prep = false;
-            n_missing += __popcll(__ballot(true));         // lanes of this wave that consumed their sample now
-#pragma unroll
-            for (int k = 0; k < S2D_OBS_DIM; ++k) post[b][k][lane] = fo.o[k];
-            post[b][WP_DIST][lane] = fo.dist; post[b][WP_REL][lane] = fo.rel;
+          snap[b][WS_FLAGS][lane] = __int_as_float(flags | (j << 8));   // bits 8..: the slot holding the next episode
+          if (took) {                                      // rare: the prepared episode is a copy
+            if (nth >= kSlots)                             // more than kSlots episodes ended in this launch: prepare inline
+              slot_fill<NOISE>(p, rp, slots[j], lane, gl, gh, (uint32_t)e.episode + 1u);
+            episode_begin(e, slot_take(slots[j], lane));
+            nth += 1; j = (j + 1 == kSlots) ? 0 : j + 1;
           }
         }
+        __syncthreads();
       }
-#if S2D_PROFILE
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-      S2D_TICK(2);                                         // done test + snapshot + reset
-      __syncthreads();
-      S2D_TICK(3);                                         // barrier
+    };
+    if (fast) {
+      loop(std::true_type{});
+      if (active) {                                        // the stamina words the fast loop did not carry
+        const int q = e.step_number;
+        e.stamina = tb->stamina[q]; e.effort = tb->effort[q]; e.recovery = tb->recovery[q]; e.capacity = tb->capacity[q];
+      }
+    } else {
+      loop(std::false_type{});
     }
-    S2D_TICK_FLUSH(o.stats, lane);
     if (active) {                                          // prev_dist / prev_angle belong to the A-wave
       S[F_PX * stride + i] = e.px; S[F_PY * stride + i] = e.py;
       S[F_VX * stride + i] = e.vx; S[F_VY * stride + i] = e.vy;
@@ -638,6 +676,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       S[F_BVX * stride + i] = e.bvx; S[F_BVY * stride + i] = e.bvy;
       S[F_STEP * stride + i] = __int_as_float(e.step_number);
       S[F_CYCLE * stride + i] = __int_as_float(e.cycle);
+      S[F_EPISODE * stride + i] = __int_as_float(e.episode);
     }
   } else if (role == 2) {
     __builtin_amdgcn_s_setprio(S2D_PRIO_A);
@@ -653,7 +692,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
     int64_t row = 0;
-    S2D_TICK_INIT(3);
+    __syncthreads();                                       // prepared episodes published
     for (int s = 0; s < n_iter; ++s) {
       if (s >= 2 && s < n_steps + 2) {                     // step s - 2
         const int b = s & 1;
@@ -661,22 +700,20 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         if (active) {
           float px = snap[b][WS_PX][lane], py = snap[b][WS_PY][lane], body = snap[b][WS_BODY][lane];
           float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
-          int flags = __float_as_int(snap[b][WS_FLAGS][lane]);
+          const int fw = __float_as_int(snap[b][WS_FLAGS][lane]);
+          const int flags = fw & 0xff;
           float dist = hypot2(bx - px, by - py);
           float rel = observe_player(p, px, py, body, bx, by, oa);
           reward = reward_of(prev_dist, prev_angle, dist, rel, flags, res);
           prev_dist = dist; prev_angle = rel;
           done = flags ? 1 : 0;
-#if S2D_PROFILE
-          asm volatile("" ::"v"(reward), "v"(oa[0]), "v"(res));
-          S2D_TICK(0);                                     // snapshot read + player half + reward
-#endif
           if (flags && p.auto_reset) {                     // rare: terminal row, then the new episode's first obs
+            const float (*sl)[kWave] = slots[fw >> 8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) term_row[k] = oa[k];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) oa[k] = post[b][k][lane];          // prepared with the episode by the simulate wave
-            prev_dist = post[b][WP_DIST][lane]; prev_angle = post[b][WP_REL][lane];   // reach_ball_env.py:166 carry seeded
+            for (int k = 0; k < 4; ++k) oa[k] = sl[SL_FIRST + k][lane];
+            prev_dist = sl[SL_DIST][lane]; prev_angle = sl[SL_REL][lane];   // reach_ball_env.py:166 carry seeded
           }
           if (ro.reward) ro.reward[row + i] = reward;
           if (ro.done) ro.done[row + i] = (uint8_t)done;
@@ -689,14 +726,8 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         }
         row += n;
       }
-#if S2D_PROFILE
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-      S2D_TICK(1);                                         // reset branch + stores + tile words
       __syncthreads();
-      S2D_TICK(3);                                         // barrier
     }
-    S2D_TICK_FLUSH(o.stats, lane);
     if (active) {
       S[F_PREV_DIST * stride + i] = prev_dist; S[F_PREV_ANGLE * stride + i] = prev_angle;
       o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
@@ -721,6 +752,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     const S2DHot& p = p_sgpr;
     float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
+    __syncthreads();                                       // prepared episodes published
     for (int s = 0; s < n_iter; ++s) {
       if (s >= 3 && ro.obs)                                // observation block of step s - 3, completed in iteration s - 1
         tile_flush(tile[(s - 1) & 1], lane, ro.obs + ((int64_t)(s - 3) * n + wave_first) * S2D_OBS_DIM, valid);
@@ -728,13 +760,14 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         const int b = s & 1;
         float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
         float bvx = snap[b][WS_BVX][lane], bvy = snap[b][WS_BVY][lane];
-        int flags = __float_as_int(snap[b][WS_FLAGS][lane]);
+        const int fw = __float_as_int(snap[b][WS_FLAGS][lane]);
         observe_ball(p, bx, by, bvx, bvy, ob6);
-        if (flags && p.auto_reset) {                       // rare: terminal row, then the new episode's first obs
+        if ((fw & 0xff) && p.auto_reset) {                 // rare: terminal row, then the new episode's first obs
+          const float (*sl)[kWave] = slots[fw >> 8];
 #pragma unroll
           for (int k = 4; k < S2D_OBS_DIM; ++k) term_row[k] = ob6[k];
 #pragma unroll
-          for (int k = 4; k < S2D_OBS_DIM; ++k) ob6[k] = post[b][k][lane];
+          for (int k = 4; k < S2D_OBS_DIM; ++k) ob6[k] = sl[SL_FIRST + k][lane];
         }
         if (ro.obs) {
           float* t = &tile[b][lane * S2D_OBS_DIM];
@@ -863,8 +896,9 @@ struct S2DEngine {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static int64_t stride_for(int64_t n) { return (int64_t)align_up((size_t)n, 256); }
 
+static_assert(sizeof(S2DRare) <= 256, "S2DTables sit 256 bytes behind S2DRare");
 struct ArenaLayout {
-  size_t state, obs, reward, done, result, terminal_obs, action_dir, action_cmd, stats, rare, total;
+  size_t state, obs, reward, done, result, terminal_obs, action_dir, action_cmd, stats, rare, tables, total;
 };
 static ArenaLayout layout_for(int64_t n) {
   ArenaLayout L;
@@ -879,11 +913,12 @@ static ArenaLayout layout_for(int64_t n) {
   L.action_cmd = off; off += align_up(s, 256);
   L.stats = off; off += (size_t)S2D_STATS_STRIPES * 8 * sizeof(unsigned long long);
   L.rare = off; off += align_up(sizeof(S2DRare), 256);
+  L.tables = off; off += align_up(sizeof(S2DTables), 256);   // directly behind S2DRare: kernels find them at rp + 256 bytes
   L.total = off;
   return L;
 }
 
-S2D_API const char* s2d_version(void) { return "s2d-hip 0.1 (gfx950, abi 1)"; }
+S2D_API const char* s2d_version(void) { return "s2d-hip 0.2 (gfx950, abi 2)"; }
 S2D_API const char* s2d_last_error(void) { return g_err.c_str(); }
 
 S2D_API void s2d_default_config(S2DConfig* c) {
@@ -911,7 +946,11 @@ S2D_API void s2d_default_config(S2DConfig* c) {
   t.min_distance_to_ball = 5.0; t.max_steps = 200;
   t.use_continuous_action = 1; t.action_space_size = 16; t.use_turning = 0;
   t.reset_ball_decay = 0.96;   // reach_ball_env.py:207
-  c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
+  c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1;
+  // The reference starts rcssserver with synch_mode / auto_mode / fullstate_l / coach only (soccer_2d_env.py:363-368), so the
+  // stock player_rand = 0.1 / ball_rand = 0.05 stay ON: noisy dynamics are the drop-in default.  noise = 0 is the explicit
+  // opt-in for deterministic runs (parity tests, the headline bench of SURVEY 8d).
+  c->noise = 1;
 }
 
 S2D_API int s2d_validate_config(const S2DConfig* c) {
@@ -984,6 +1023,14 @@ static void dev_params_from_config(const S2DConfig& c, S2DHot& h, S2DRare& r) {
   r.ball_speed = (float)t.ball_speed; r.ball_direction = (float)t.ball_direction;
   r.travel_factor = (float)((1.0 - std::pow(t.reset_ball_decay, (double)t.max_steps)) / (1.0 - t.reset_ball_decay));
   r.change_ball_position = t.change_ball_position; r.change_ball_velocity = t.change_ball_velocity;
+  // dash-only fast path (s2d_device.h, S2DTables): every command of the discrete / 1-D continuous modes is Dash(100, dir)
+  {
+    const float power = 100.0f < h.min_dash_power ? h.min_dash_power : (100.0f > h.max_dash_power ? h.max_dash_power : 100.0f);   // clampf
+    const bool whole_step = h.dash_angle_step >= 1.0f && h.dash_angle_step == std::rint(h.dash_angle_step);
+    const bool dash_only = !(t.use_continuous_action && t.use_turning);
+    r.tab_power = power;
+    r.tab_len = (dash_only && whole_step && power > 0.0f && c.auto_reset && t.max_steps + 1 <= S2D_TAB_MAX) ? t.max_steps + 1 : 0;
+  }
 }
 
 S2D_API size_t s2d_arena_bytes(const S2DConfig* cfg, int64_t n_envs) {
@@ -1044,6 +1091,7 @@ S2D_API int s2d_create(const S2DConfig* cfg, int64_t n_envs, int device, void* a
   b.step_number = reinterpret_cast<int32_t*>(S + (size_t)F_STEP * h->stride);
   b.cycle = reinterpret_cast<int32_t*>(S + (size_t)F_CYCLE * h->stride);
   b.policy_step = reinterpret_cast<int32_t*>(S + (size_t)F_POLICY * h->stride);
+  b.episode = reinterpret_cast<int32_t*>(S + (size_t)F_EPISODE * h->stride);
   b.obs = reinterpret_cast<float*>(h->arena + L.obs);
   b.reward = reinterpret_cast<float*>(h->arena + L.reward);
   b.done = reinterpret_cast<uint8_t*>(h->arena + L.done);
@@ -1061,6 +1109,8 @@ S2D_API int s2d_create(const S2DConfig* cfg, int64_t n_envs, int device, void* a
   if (e == hipSuccess) {
     hipLaunchKernelGGL(s2d_init_kernel, dim3(grid_for(n_envs)), dim3(kBlock), 0, st, h->hot, h->rare_dev, S,
                        h->stride, h->n);
+    hipLaunchKernelGGL(s2d_tables_kernel, dim3(1), dim3(64), 0, st, h->hot, h->rare_dev,
+                       reinterpret_cast<S2DTables*>(h->arena + L.tables));
     e = hipGetLastError();
   }
   if (e != hipSuccess) {
@@ -1093,10 +1143,10 @@ S2D_API int s2d_buffer_offsets(S2DHandle h, int64_t* offsets, int n_offsets) {
   const void* ptrs[] = {h->buf.player_x, h->buf.player_y, h->buf.player_vx, h->buf.player_vy, h->buf.player_body,
                         h->buf.stamina, h->buf.effort, h->buf.recovery, h->buf.stamina_capacity, h->buf.ball_x,
                         h->buf.ball_y, h->buf.ball_vx, h->buf.ball_vy, h->buf.prev_dist, h->buf.prev_angle,
-                        h->buf.step_number, h->buf.cycle, h->buf.policy_step, h->buf.obs, h->buf.reward, h->buf.done, h->buf.result,
+                        h->buf.step_number, h->buf.cycle, h->buf.policy_step, h->buf.episode, h->buf.obs, h->buf.reward, h->buf.done, h->buf.result,
                         h->buf.terminal_obs, h->buf.action_dir, h->buf.action_cmd, h->buf.stats};
   const int count = 1 + (int)(sizeof ptrs / sizeof ptrs[0]);
-  if (n_offsets < count) return fail(S2D_EINVAL, "offsets array too small (need 27)");
+  if (n_offsets < count) return fail(S2D_EINVAL, "offsets array too small (need 28)");
   offsets[0] = (int64_t)h->arena_bytes;
   for (int k = 1; k < count; ++k) offsets[k] = (int64_t)(static_cast<const char*>(ptrs[k - 1]) - h->arena);
   return S2D_OK;

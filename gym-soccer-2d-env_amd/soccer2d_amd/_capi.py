@@ -11,7 +11,7 @@ The product path has no CPU fallback: if the HIP library is missing or does not 
 import ctypes as C
 import os
 
-S2D_ABI_VERSION = 1
+S2D_ABI_VERSION = 2
 S2D_OBS_DIM = 10
 
 # error codes
@@ -78,14 +78,14 @@ BUFFER_FIELDS = (
     ('ball_vx', _F, 'float32', ()), ('ball_vy', _F, 'float32', ()),
     ('prev_dist', _F, 'float32', ()), ('prev_angle', _F, 'float32', ()),
     ('step_number', _I32, 'int32', ()), ('cycle', _I32, 'int32', ()),
-    ('policy_step', _I32, 'int32', ()),
+    ('policy_step', _I32, 'int32', ()), ('episode', _I32, 'int32', ()),
     ('obs', _F, 'float32', (S2D_OBS_DIM,)), ('reward', _F, 'float32', ()),
     ('done', _U8, 'uint8', ()), ('result', _U8, 'uint8', ()),
     ('terminal_obs', _F, 'float32', (S2D_OBS_DIM,)),
     ('action_dir', _F, 'float32', ()), ('action_cmd', _U8, 'uint8', ()),
     ('stats', C.POINTER(C.c_ulonglong), 'int64', None),   # [8], not per-env
 )
-STATE_FIELDS = tuple(f[0] for f in BUFFER_FIELDS[:18])
+STATE_FIELDS = tuple(f[0] for f in BUFFER_FIELDS[:19])
 
 
 class S2DBuffers(C.Structure):

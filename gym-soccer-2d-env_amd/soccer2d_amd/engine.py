@@ -21,9 +21,11 @@ TASK_KWARGS = dict(change_ball_position=True, change_ball_velocity=False, ball_p
                    use_continuous_action=True, action_space_size=16, use_turning=False)
 
 
-def make_config(seed=0x5EED, env_id_offset=0, auto_reset=True, noise=False, server_params=None, **kwargs):
+def make_config(seed=0x5EED, env_id_offset=0, auto_reset=True, noise=True, server_params=None, **kwargs):
     """S2DConfig from ReachBallEnv-style kwargs (+ optional ServerParam overrides by
-    idl/service.proto field name).  Unknown names raise ValueError."""
+    idl/service.proto field name).  Unknown names raise ValueError.  noise=True (player_rand / ball_rand on) is the
+    default because the reference's rcssserver runs with its stock noise (soccer_2d_env.py:363-368); noise=False is the
+    explicit opt-in for deterministic dynamics."""
     lib = _capi.load_library()
     cfg = _capi.S2DConfig()
     lib.s2d_default_config(C.byref(cfg))
@@ -82,8 +84,8 @@ class Engine:
 
     def _make_views(self, nbytes):
         n = self.num_envs
-        off = (C.c_int64 * 27)()
-        _capi.check(self.lib, self.lib.s2d_buffer_offsets(self._h, off, 27), 's2d_buffer_offsets')
+        off = (C.c_int64 * 28)()
+        _capi.check(self.lib, self.lib.s2d_buffer_offsets(self._h, off, 28), 's2d_buffer_offsets')
         assert off[0] == nbytes
         self.buffers = {}
         for k, (name, _ct, dt, trail) in enumerate(BUFFER_FIELDS):

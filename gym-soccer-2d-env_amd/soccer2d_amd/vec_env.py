@@ -23,7 +23,7 @@ RESULT_NAMES = _capi.RESULT_NAMES
 class Soccer2DVecEnv:
     metadata = {'render.modes': ['human']}
 
-    def __init__(self, num_envs, device='cuda:0', seed=0x5EED, env_id_offset=0, auto_reset=True, noise=False,
+    def __init__(self, num_envs, device='cuda:0', seed=0x5EED, env_id_offset=0, auto_reset=True, noise=True,
                  server_params=None, clone_outputs=False, **kwargs):
         cfg = make_config(seed=seed, env_id_offset=env_id_offset, auto_reset=auto_reset, noise=noise,
                           server_params=server_params, **kwargs)

@@ -35,7 +35,7 @@ class Soccer2DEnv(_Base):
     task_kwargs = {}
 
     def __init__(self, render_mode=None, run_grpc_server=True, run_rcssserver=True, run_trainer_player=True,
-                 logger=None, log_dir=None, device='cuda:0', seed=0x5EED, noise=False, server_params=None,
+                 logger=None, log_dir=None, device='cuda:0', seed=0x5EED, noise=True, server_params=None,
                  **kwargs):
         # run_* switches are accepted for signature compatibility; there is nothing to spawn.
         self.render_mode = render_mode

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define S2D_ABI_VERSION 1
+#define S2D_ABI_VERSION 2
 
 /* ---- error codes (0 = ok, negative = failure; text via s2d_last_error()) ------------ */
 enum {
@@ -132,6 +132,9 @@ typedef struct S2DBuffers {
   int32_t *cycle;                 /* WorldModel.cycle, idl/service.proto:326 */
   int32_t *policy_step;           /* steps that consumed an in-engine policy / select draw (S2D_ACT_RANDOM,
                                    * or any step of a use_turning env): the Philox counter of those draws */
+  int32_t *episode;               /* resets so far = index of the current episode (0 before the first reset): the
+                                   * Philox counter of the reset sampler, so that episode j of env g is a function of
+                                   * (g, j) alone and can be prepared ahead of the simulation */
   /* per-step outputs */
   float *obs;            /* [N][10]  reach_ball_env.py:98-107 */
   float *reward;         /* [N] */

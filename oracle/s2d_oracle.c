@@ -300,6 +300,7 @@ typedef struct Env {
   REAL bx, by, bvx, bvy, prev_dist, prev_angle;
   int32_t step_number, cycle;
   uint32_t policy_step;   /* steps that consumed an in-engine POLICY / SELECT draw */
+  uint32_t episode;       /* number of resets so far = index of the current episode (0 before the first reset) */
 } Env;
 
 static REAL clampr(REAL v, REAL lo, REAL hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -429,10 +430,11 @@ static void sim_cycle(const P *p, Env *e, uint64_t gid, int cmd, REAL power, REA
  * no body command (soccer_2d_env.py:186-197); carry is seeded (reach_ball_env.py:166). */
 static void env_reset(const P *p, Env *e, uint64_t gid, REAL *obs) {
   DrawSrc s; memset(&s, 0, sizeof s);
-  /* RESET stream counter word: the cycle at which the CURRENT episode began
-   * (= cycle - step_number - 1, constant during an episode, unique per episode), so the next
-   * episode's initial state is a function of data known from the episode's first cycle on. */
-  s.seed = p->seed; s.gid = gid; s.cycle = (uint32_t)e->cycle - (uint32_t)e->step_number - 1u;
+  /* RESET stream counter word: the index of the episode the reset starts (1, 2, ...).  The state a reset leaves
+   * behind is therefore a function of (env id, episode index) alone -- independent of how long earlier episodes
+   * lasted -- so an engine may prepare any number of future episodes ahead of the simulation. */
+  e->episode += 1u;
+  s.seed = p->seed; s.gid = gid; s.cycle = e->episode;
   ResetDraw o;
   reset_sample(p, &s, &o);
   e->step_number = 0;                                    /* :172 */
@@ -611,13 +613,14 @@ API int s2do_get_state(const S2DOEngine *h, int field, double *out) {
       case 10: v = e->by; break; case 11: v = e->bvx; break; case 12: v = e->bvy; break;
       case 13: v = e->prev_dist; break; case 14: v = e->prev_angle; break;
       case 15: v = e->step_number; break; case 16: v = e->cycle; break; case 17: v = e->policy_step; break;
+      case 18: v = e->episode; break;
       default: return -1;
     }
     out[i] = v;
   }
   return 0;
 }
-/* overwrite one env's state (tests: hand-placed scenarios) -- 18 values in field order */
+/* overwrite one env's state (tests: hand-placed scenarios) -- 19 values in field order */
 API int s2do_set_env(S2DOEngine *h, int64_t i, const double *v17) {
   if (i < 0 || i >= h->n) return -1;
   Env *e = &h->env[i];
@@ -626,6 +629,7 @@ API int s2do_set_env(S2DOEngine *h, int64_t i, const double *v17) {
   e->bx = (REAL)v17[9]; e->by = (REAL)v17[10]; e->bvx = (REAL)v17[11]; e->bvy = (REAL)v17[12];
   e->prev_dist = (REAL)v17[13]; e->prev_angle = (REAL)v17[14];
   e->step_number = (int32_t)v17[15]; e->cycle = (int32_t)v17[16]; e->policy_step = (uint32_t)v17[17];
+  e->episode = (uint32_t)v17[18];
   return 0;
 }
 API const REAL *s2do_obs(const S2DOEngine *h) { return h->obs; }

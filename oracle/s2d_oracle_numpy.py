@@ -78,6 +78,7 @@ class NumpyReachBall:
         self.step_number = np.zeros(n, dtype=np.int64)
         self.cycle = np.zeros(n, dtype=np.int64)
         self.policy_step = np.zeros(n, dtype=np.uint64)
+        self.episode = np.zeros(n, dtype=np.int64)
         self.obs = np.zeros((n, 10))
         self.terminal_obs = np.zeros((n, 10))
         self.reward, self.done, self.result = z(), np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
@@ -94,7 +95,8 @@ class NumpyReachBall:
     # ------------------------------------------------------------------ A5: reset sample
     def _reset_sample(self, idx):
         tk, sp = self.tk, self.sp
-        c0 = self.cycle[idx] - self.step_number[idx] - 1          # cycle at which the episode began
+        self.episode[idx] += 1
+        c0 = self.episode[idx]                                    # index of the episode the reset starts
         w = self._draw(idx, c0, ST_RESET, 0)
         w1 = self._draw(idx, c0, ST_RESET, 1)
         px = (-50 + rnd_below(w[0], 101)).astype(np.float64)

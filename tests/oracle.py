@@ -42,7 +42,7 @@ DQN_KWARGS = dict(change_ball_position=True, change_ball_velocity=True, min_dist
                   max_steps=200, use_continuous_action=False, action_space_size=16, use_turning=False)
 
 
-def make_config(seed=0x5EED, env_id_offset=0, auto_reset=1, noise=0, server=None, **task):
+def make_config(seed=0x5EED, env_id_offset=0, auto_reset=1, noise=1, server=None, **task):
     cfg = _capi.S2DConfig()
     cfg.abi_version = _capi.S2D_ABI_VERSION
     cfg.struct_bytes = C.sizeof(_capi.S2DConfig)

@@ -16,6 +16,7 @@ torch = pytest.importorskip('torch')
 def _engine(n, **kw):
     from soccer2d_amd.engine import Engine, make_config
     server = kw.pop('server', None)
+    kw.setdefault('noise', False)           # the product default is noise ON; these parity cases name it explicitly
     cfg = make_config(server_params=server, **kw)
     return Engine(n, 'cuda:0', cfg=cfg)
 
@@ -42,6 +43,12 @@ def assert_same(gpu_t, cpu_a, what):
         bad = np.argwhere(bits(g) != bits(cpu_a))
         i = tuple(bad[0])
         raise AssertionError(f"{what}: {len(bad)} of {g.size} words differ; first at {i}: gpu={g[i]!r} cpu={cpu_a[i]!r}")
+
+
+def _compare_rollout(out, ref, tag):
+    torch.cuda.synchronize()
+    for k in ('obs', 'action', 'reward', 'done', 'result'):
+        assert_same(out[k], ref[k], f'{tag} rollout.{k}')
 
 
 def assert_state_same(eng, orc, tag=''):
@@ -354,6 +361,33 @@ def test_short_rollouts_pipeline_fill_and_drain(name, ws, monkeypatch):
         eng.step(None); orc.step(None)
         assert_state_same(eng, orc, f'{name} step after T={T}')
     assert int(eng.policy_step.min()) == int(eng.policy_step.max()) > 0
+
+
+@pytest.mark.parametrize('noise', [False, True])
+def test_dash_fast_path_and_its_fallback(noise, monkeypatch):
+    """The four-wave pipeline's dash-only fast path (stamina table + whole-degree sine table) is taken by groups whose envs
+    sit on the table; a group holding a foreign state (another stamina word, a fractional body angle, a step number beyond
+    the table) must run the generic loop -- both bit-equal to the oracle, in the same launch.  Also: more than kSlots = 3
+    episodes ending inside one launch (the inline-prepare path), forced by max_steps = 4."""
+    monkeypatch.setenv('S2D_ROLLOUT_WS', '1')
+    kw = dict(use_continuous_action=False, action_space_size=16, change_ball_velocity=True, max_steps=4, noise=noise)
+    n = 64 * 6 + 17
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    _compare_rollout(eng.rollout(24), orc.rollout(24), 'many episodes per launch')
+    assert_state_same(eng, orc, 'after the short-episode launch')
+    # foreign states in groups 1, 3 and 5 (groups 0, 2, 4 and the ragged last one stay on the table)
+    torch.cuda.synchronize()
+    edits = {70: dict(stamina=7777.0), 64 * 3 + 5: dict(player_body=33.5), 64 * 5 + 63: dict(effort=0.75, recovery=0.9)}
+    for i, kv in edits.items():
+        for k, v in kv.items():
+            getattr(eng, k)[i] = v
+        orc.set_env(i, **kv)
+    for T in (7, 64):
+        _compare_rollout(eng.rollout(T), orc.rollout(T), f'foreign states T={T}')
+        assert_state_same(eng, orc, f'foreign states T={T}')
+    o1, r1, d1, s1 = eng.step(None); o2, r2, d2, s2 = orc.step(None)
+    assert_same(o1, o2, 'step after'); assert_same(r1, r2, 'step after reward')
 
 
 def test_cycle_counter_wraps_past_int32():

@@ -25,7 +25,7 @@ CASES = {
 
 
 def _pair(n, kw, **extra):
-    cfg = O.make_config(**extra, **kw)
+    cfg = O.make_config(noise=0, **extra, **kw)        # the NumPy restatement has no noise model
     task = dict(O.TASK_DEFAULTS); task.update(kw)
     nb = NumpyReachBall(n, O.SERVER_DEFAULTS, task, seed=cfg.seed, env_id_offset=cfg.env_id_offset,
                         auto_reset=bool(cfg.auto_reset))
