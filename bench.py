@@ -57,6 +57,12 @@ def parse():
     ap.add_argument('--settle-ms', type=float, default=200.0,
                     help='untimed load before the W warm-up steps so that the chip\'s clock has settled (it takes tens of ms '
                          'of sustained load; a 4 ms run measures the ramp: 66 G instead of 80 G env-steps/s); 0 = off')
+    ap.add_argument('--rotate-buffers', type=int, default=1,
+                    help='rollout mode: cycle through this many record buffers (K x 218.6 MB > 512 MiB makes every launch write cold '
+                         'lines: no hit in the 256 MiB Infinity Cache); the default line re-writes one buffer and carries the rotating '
+                         'figure in `secondary`')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary measurements (per-step API, cold, rotating, noise)')
+    ap.add_argument('--eager', action='store_true', help='issue the timed launches eagerly from Python instead of replaying one hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-steps', type=int, default=0, help='0 = auto (about 10-20 s of CPU work)')
     args = ap.parse_args()
@@ -67,12 +73,14 @@ def parse():
         args.warmup = 256 if per_cycle else 4
     if args.steps < 1 or args.warmup < 0 or args.fuse < 1:
         ap.error('--steps must be >= 1, --warmup >= 0, --fuse >= 1')
+    if args.mode == 'graph':
+        args.eager = True          # that mode replays its own graph of single-cycle launches
     # cycles per bench step: a whole launch (or graph replay) of `fuse` cycles, or one cycle in step mode
     args.cycles_per_step = 1 if per_cycle else args.fuse
     return args
 
 
-def cpu_baseline(n_envs, sample_steps):
+def cpu_baseline(n_envs, sample_steps, noise=False):
     """Time the CPU oracle (plain-C scalar port of the same algorithm, fp32 build) on the
     host cores of this box, on a bounded sample of the same workload.  kind = "port"."""
     import ctypes as C
@@ -84,7 +92,7 @@ def cpu_baseline(n_envs, sample_steps):
         gomp = C.CDLL('libgomp.so.1')
     except OSError:
         gomp, threads = None, 1
-    cfg = O.make_config(**DQN_KWARGS)
+    cfg = O.make_config(noise=int(noise), **DQN_KWARGS)
     eng = O.OracleEngine(cfg, n_envs, 'f32')
 
     def run(nthreads, steps):
@@ -288,6 +296,98 @@ def load_traffic(mode, fuse, n_envs):
     return best
 
 
+def graph_of(issue):
+    """Capture what `issue()` launches into a hipGraph (setup, outside every timed region).  A launch of 64 fused cycles
+    takes ~48 us on the device; issued eagerly from Python (ctypes call + stream lookup + hipLaunchKernel, 30-70 us per call
+    depending on the host) the HOST would be the slower side and the figure would measure it.  Replaying a graph hands
+    the whole sequence to the device at once."""
+    import torch
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        issue()
+    torch.cuda.synchronize()
+    return g
+
+
+def time_graph(g, stream):
+    """seconds of one replay, from one HIP event pair on the launch stream (a pair around every launch would cost ~4 us per
+    launch in marker packets)"""
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    g.replay()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3
+
+
+def time_rollout(eng, T, launches, bufs, stream):
+    """`launches` rollout launches of T cycles, cycling through the buffers in `bufs`.  Returns seconds (device time)."""
+    nb = len(bufs)
+    g = graph_of(lambda: [eng.rollout(T, out=bufs[i % nb]) for i in range(launches)])
+    return time_graph(g, stream)
+
+
+def time_steps(eng, k, stream):
+    g = graph_of(lambda: [eng.step(None) for _ in range(k)])
+    return time_graph(g, stream)
+
+
+def roofline_of(alg_bytes_launch, launch_s, kernel, traffic, n, steps_per_launch):
+    achieved = alg_bytes_launch / launch_s / 1e9
+    return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'traffic': traffic, 'kernel': kernel, 'launch_us': launch_s * 1e6,
+            'algorithmic_bytes_per_launch': alg_bytes_launch,
+            'algorithmic_bytes_per_env_step': alg_bytes_launch / (n * steps_per_launch),
+            # what the PMC profiles say limits the kernel (profiles/r02/pmc_rollout_instmix.txt): HBM traffic equals the
+            # algorithmic bytes; the SIMDs' instruction issue is what is saturated
+            'limiter': 'valu-issue' if steps_per_launch > 1 else 'launch-latency'}
+
+
+def secondary_measurements(args, dev, stream, rank, n, T):
+    """More figures for the same workload, carried in the same JSON line (`secondary`): the per-step API, the rollout into
+    rotating buffers (> 512 MiB in flight, so that no line of the record can be served by the 256 MiB Infinity Cache) and
+    the noise-on rollout (the drop-in default).  Fresh engines, a few seconds in all.  (`rollout_cold`, the figure without the
+    settle phase, is measured by main() as the first GPU work of the process.)"""
+    import torch
+    from soccer2d_amd.engine import Engine, make_config
+    out = {}
+
+    def fresh(noise=False):
+        e = Engine(n, dev, cfg=make_config(seed=0x5EED, env_id_offset=rank * n, auto_reset=True, noise=noise, **DQN_KWARGS))
+        e.reset()
+        return e
+    alg_roll = n * (2 * STATE_BYTES + T * RECORD_BYTES)
+    eng = fresh()
+    ro = eng.alloc_rollout(T)
+    # (b) rotating buffers, steady clocks
+    per_buf = T * n * RECORD_BYTES
+    nb = max(2, -(-(600 << 20) // per_buf))
+    bufs = [ro] + [eng.alloc_rollout(T) for _ in range(nb - 1)]
+    settle(lambda k: [eng.rollout(T, out=bufs[j % nb]) for j in range(k // T)], 16 * T, args.settle_ms)
+    dt = time_rollout(eng, T, 8 * nb, bufs, stream)
+    out['rollout_rotating_buffers'] = {'value': n * T * 8 * nb / dt, 'unit': 'env-steps/s', 'buffers': nb,
+                                       'bytes_in_flight': nb * per_buf, 'launches': 8 * nb,
+                                       'roofline': roofline_of(alg_roll, dt / (8 * nb), eng.kernel_name(),
+                                                               load_traffic('rollout-rotate', T, n), n, T)}
+    del bufs
+    # (c) per-step API (what an SB3-style learner drives), steady clocks, 2 048 launches
+    settle(lambda k: [eng.step(None) for _ in range(k)], 2048, args.settle_ms)
+    dt = time_steps(eng, 2048, stream)
+    alg_step = n * (2 * STATE_BYTES + 4 + RECORD_BYTES - 4)
+    out['step_api'] = {'value': n * 2048 / dt, 'unit': 'env-steps/s', 'launches': 2048,
+                       'roofline': roofline_of(alg_step, dt / 2048, eng.kernel_name(), load_traffic('step', T, n), n, 1)}
+    del eng
+    # (d) noise on (the drop-in default: rcssserver's stock player_rand / ball_rand)
+    eng = fresh(noise=True)
+    ro = eng.alloc_rollout(T)
+    settle(lambda k: [eng.rollout(T, out=ro) for _ in range(k // T)], 16 * T, args.settle_ms)
+    dt = time_rollout(eng, T, 64, [ro], stream)
+    out['rollout_noise_on'] = {'value': n * T * 64 / dt, 'unit': 'env-steps/s', 'launches': 64,
+                               'roofline': roofline_of(alg_roll, dt / 64, eng.kernel_name(), None, n, T)}
+    return out
+
+
 def main():
     args = parse()
     if args.task == 'match':
@@ -316,8 +416,19 @@ def main():
     eng.reset()
     T = max(1, args.fuse)
     K, W = args.steps * args.cycles_per_step, args.warmup * args.cycles_per_step     # in cycles
-    ro = eng.alloc_rollout(T) if args.mode == 'rollout' else None
+    nbuf = max(1, args.rotate_buffers)
+    bufs = [eng.alloc_rollout(T) for _ in range(nbuf)] if args.mode == 'rollout' else None
     stream = torch.cuda.current_stream(dev)
+    issued = [0]
+    cold = None
+    if world == 1 and not args.no_secondary and args.mode == 'rollout' and args.variant == 'dqn':
+        # the cold figure: the first GPU work of this process -- 4 warm-up launches, 20 timed, no settle phase (the chip's
+        # clock has not settled: profiles/r01/duration_sweep.txt)
+        for _ in range(4):
+            eng.rollout(T, out=bufs[0])
+        dt = time_rollout(eng, T, 20, bufs[:1], stream)
+        cold = {'value': n * T * 20 / dt, 'unit': 'env-steps/s', 'launches': 20, 'settle_ms': 0,
+                'roofline': roofline_of(n * (2 * STATE_BYTES + T * RECORD_BYTES), dt / 20, eng.kernel_name(), None, n, T)}
 
     graph = None
     if args.mode == 'graph':
@@ -336,9 +447,9 @@ def main():
         if args.mode == 'rollout':
             full, rem = divmod(k, T)
             for _ in range(full):
-                eng.rollout(T, out=ro)
+                eng.rollout(T, out=bufs[issued[0] % nbuf]); issued[0] += 1
             if rem:
-                eng.rollout(rem, out=ro)
+                eng.rollout(rem, out=bufs[issued[0] % nbuf]); issued[0] += 1
             return full + (1 if rem else 0)
         if args.mode == 'graph':
             full, rem = divmod(k, T)
@@ -354,55 +465,47 @@ def main():
     settle(launch, 16 * T if args.mode != 'step' else 2048, args.settle_ms)
     launch(W)
     torch.cuda.synchronize()
+    # the K timed cycles as ONE hipGraph (captured here, outside the timed region; see graph_of) unless --eager
+    timed = None
+    n_launches = [0]
+    if not args.eager:
+        timed = graph_of(lambda: n_launches.__setitem__(0, launch(K)))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
 
     # ---- timed region: EXACTLY K cycles ----
-    per_launch_events = []
     t0 = time.perf_counter()
-    if args.mode == 'rollout':
-        full, rem = divmod(K, T)
-        # ONE event pair over the timed region: a timed event pair around every launch costs ~4 us per launch
-        # (6 % of a 65 us kernel) in marker packets between dependent kernels
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for i in range(full + (1 if rem else 0)):
-            eng.rollout(T if i < full else rem, out=ro)
-        e1.record(stream)
-        per_launch_events.append((e0, e1))
-        n_launches = full + (1 if rem else 0)
+    # ONE event pair over the timed region, recorded on the launch stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    if timed is not None:
+        timed.replay()
     else:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        n_launches = launch(K)
-        e1.record(stream)
-        per_launch_events.append((e0, e1))
+        n_launches[0] = launch(K)
+    e1.record(stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    n_launches = n_launches[0]
 
     elapsed = max_over_ranks(dist, dev, elapsed)
 
     # dominant-kernel launch duration from HIP events on the launch stream
     if args.mode == 'rollout':
-        a, b = per_launch_events[0]
         steps_per_launch = T if K >= T else K
         # average duration of a full launch; a trailing short launch (K not a multiple of T) counts by its share of cycles
-        launch_s = a.elapsed_time(b) * 1e-3 * steps_per_launch / K
-    else:
-        a, b = per_launch_events[0]
-        launch_s = a.elapsed_time(b) * 1e-3 / K
-        steps_per_launch = 1
-    if args.mode == 'rollout':
+        launch_s = e0.elapsed_time(e1) * 1e-3 * steps_per_launch / K
         alg_bytes_launch = n * (2 * STATE_BYTES + steps_per_launch * RECORD_BYTES)
         kernel = eng.kernel_name() or 's2d_reach_rollout_kernel'
     else:
+        launch_s = e0.elapsed_time(e1) * 1e-3 / K
+        steps_per_launch = 1
         alg_bytes_launch = n * (2 * STATE_BYTES + 4 + RECORD_BYTES - 4)      # 186 B per env-step
         kernel = eng.kernel_name() or 's2d_reach_step_kernel'
-    achieved = alg_bytes_launch / launch_s / 1e9
+    traffic_key = args.mode if nbuf == 1 else args.mode + '-rotate'
 
     total_steps = world * n * K
     stats = eng.stats.cpu().tolist()
@@ -422,19 +525,22 @@ def main():
                                    f'(BASELINE.json configs[2]; kwargs of dqn_stable_baselines3.py:18-31)',
                        'envs_per_gpu': n, 'global_envs': world * n, 'mode': args.mode, 'variant': args.variant,
                        'cycles_per_launch': steps_per_launch if args.mode != 'graph' else f'1 ({T} per graph replay)',
-                       'settle_ms': args.settle_ms,
+                       'settle_ms': args.settle_ms, 'rollout_buffers': nbuf, 'issue': 'eager' if args.eager else 'one hipGraph replay',
                        'noise': bool(args.noise), 'parallelism': f'env-shard x{world} (no collective)',
                        'launches': n_launches},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(args.mode, T, n),
-                         'kernel': kernel, 'launch_us': launch_s * 1e6,
-                         'algorithmic_bytes_per_launch': alg_bytes_launch,
-                         'algorithmic_bytes_per_env_step': alg_bytes_launch / (n * steps_per_launch)},
+            'roofline': roofline_of(alg_bytes_launch, launch_s, kernel, load_traffic(traffic_key, T, n), n, steps_per_launch),
             'episodes': {'goal': stats[1], 'out': stats[2], 'timeout': stats[3]},
         }
+        if world == 1 and not args.no_secondary and args.mode == 'rollout' and args.variant == 'dqn':
+            del eng, bufs
+            try:
+                line['secondary'] = secondary_measurements(args, dev, stream, rank, n, T)
+                line['secondary']['rollout_cold'] = cold
+            except Exception as ex:
+                line['secondary'] = {'error': repr(ex), 'rollout_cold': cold}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line['cpu_baseline'] = cpu_baseline(n, args.cpu_sample_steps)
+                line['cpu_baseline'] = cpu_baseline(n, args.cpu_sample_steps, bool(args.noise))
             except Exception as ex:     # the baseline is a report, never the product
                 line['cpu_baseline'] = {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port',
                                         'sample': f'failed: {ex!r}'}

@@ -77,6 +77,7 @@ class Engine:
         self._h = h
         self._make_views(nbytes)
         self._wm = None
+        self._ro_cache = {}
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -165,19 +166,30 @@ class Engine:
 
     def rollout(self, n_steps, actions=None, out=None, with_obs=True):
         """n_steps fused cycles in one launch.  Returns dict of time-major tensors
-        obs [T,N,10], action [T,N]/[T,N,1]/[T,N,4], reward [T,N], done [T,N], result [T,N]."""
-        T, n, t = int(n_steps), self.num_envs, self.cfg.task
+        obs [T,N,10], action [T,N]/[T,N,1]/[T,N,4], reward [T,N], done [T,N], result [T,N].
+        A caller-owned `out` dict is validated once and its pointer block cached (keyed by the dict's identity and the
+        tensors' addresses), so that re-launching into the same buffers costs one ctypes call: at 65 536 envs a launch of
+        64 cycles takes ~48 us on the device, and the host must not be the slower side."""
+        T, n = int(n_steps), self.num_envs
         keep, ptr, kind = self._action_arg(actions, leading=T)
         if out is None:
             out = self.alloc_rollout(T, with_obs=with_obs)
-        ro = _capi.S2DRollout()
-        for name in ('obs', 'action', 'reward', 'done', 'result'):
-            v = out.get(name)
-            if v is not None:
-                if not v.is_contiguous() or v.device != self.device or v.shape[0] < T or v.shape[1] != n:
-                    raise ValueError(f"rollout buffer {name!r} must be a contiguous [T>={T},{n},...] tensor on {self.device}")
-                setattr(ro, name, v.data_ptr())
-        _capi.check(self.lib, self.lib.s2d_rollout(self._h, T, ptr, kind, C.byref(ro), self._stream()), 's2d_rollout')
+        cached = self._ro_cache.get(id(out))
+        key = tuple(None if out.get(k) is None else out[k].data_ptr() for k in ('obs', 'action', 'reward', 'done', 'result'))
+        if cached is None or cached[0] != key or cached[1] < T:
+            ro = _capi.S2DRollout()
+            t_min = None
+            for name in ('obs', 'action', 'reward', 'done', 'result'):
+                v = out.get(name)
+                if v is not None:
+                    if not v.is_contiguous() or v.device != self.device or v.shape[0] < T or v.shape[1] != n:
+                        raise ValueError(f"rollout buffer {name!r} must be a contiguous [T>={T},{n},...] tensor on {self.device}")
+                    setattr(ro, name, v.data_ptr())
+                    t_min = v.shape[0] if t_min is None else min(t_min, v.shape[0])
+            if len(self._ro_cache) > 64:
+                self._ro_cache.clear()
+            cached = self._ro_cache[id(out)] = (key, T if t_min is None else t_min, ro, out)
+        _capi.check(self.lib, self.lib.s2d_rollout(self._h, T, ptr, kind, C.byref(cached[2]), self._stream()), 's2d_rollout')
         self._keep = (keep, out)
         return out
 

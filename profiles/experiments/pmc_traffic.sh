@@ -12,10 +12,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 run() { # name, bench args...
   NAME=$1; shift
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${NAME}_fetch -- python3 bench.py --no-cpu-baseline "$@" > $OUT/${NAME}_fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${NAME}_write -- python3 bench.py --no-cpu-baseline "$@" > $OUT/${NAME}_write.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${NAME}_fetch -- python3 bench.py --no-cpu-baseline --no-secondary "$@" > $OUT/${NAME}_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${NAME}_write -- python3 bench.py --no-cpu-baseline --no-secondary "$@" > $OUT/${NAME}_write.log 2>&1
 }
 run rollout64k --steps 16 --warmup 1
+run rollout64k_rot --steps 18 --warmup 3 --rotate-buffers 3
 run rollout1m --steps 16 --warmup 1 --envs 1048576
 run step64k --steps 1024 --warmup 64 --mode step
 run match8k --task match --steps 8 --warmup 1
@@ -30,6 +31,7 @@ def avg(tag, counter, kern):
     return (tot / n if n else None), n
 rows = []
 for name, mode, fuse, envs, kern in (('rollout64k', 'rollout', 64, 65536, 'rollout_'),
+                                     ('rollout64k_rot', 'rollout-rotate', 64, 65536, 'rollout_'),
                                      ('rollout1m', 'rollout', 64, 1048576, 'rollout_'),
                                      ('step64k', 'step', 64, 65536, 'step_kernel'),
                                      ('match8k', 'match-rollout', 64, 8192, 'match_rollout')):
