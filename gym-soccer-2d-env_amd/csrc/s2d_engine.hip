@@ -809,6 +809,31 @@ __global__ __launch_bounds__(kBlock) void s2d_world_model_kernel(const float* __
   if (w.self_angle_from_ball) w.self_angle_from_ball[i] = atan2_deg(-dy, -dx);
 }
 
+// diagnostic ("validate state" guard): count the envs whose state words left their domain
+enum { SV_NONFINITE, SV_BODY, SV_STAMINA, SV_EFFORT_RECOVERY, SV_COUNTERS, SV_OBS, SV_WORDS = 8 };
+__global__ __launch_bounds__(kBlock) void s2d_validate_kernel(S2DHot p, const float* __restrict__ S, int64_t stride, int64_t n,
+                                                              const float* __restrict__ obs, unsigned int* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  Env e;
+  env_load(e, S, stride, i);
+  const float w[15] = {e.px, e.py, e.vx, e.vy, e.body, e.stamina, e.effort, e.recovery, e.capacity, e.bx, e.by, e.bvx, e.bvy,
+                       e.prev_dist, e.prev_angle};
+  bool finite = true;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) finite = finite && isfinite(w[k]);
+  bool obs_ok = true;
+#pragma unroll
+  for (int k = 0; k < S2D_OBS_DIM; ++k) obs_ok = obs_ok && isfinite(obs[i * S2D_OBS_DIM + k]);
+  if (!finite) atomicAdd(&out[SV_NONFINITE], 1u);
+  if (!(fabsf(e.body) <= 180.0f) || !(fabsf(e.prev_angle) <= 180.0f)) atomicAdd(&out[SV_BODY], 1u);
+  if (!(e.stamina >= 0.0f && e.stamina <= p.stamina_max) || !(e.capacity >= 0.0f || p.stamina_capacity < 0.0f)) atomicAdd(&out[SV_STAMINA], 1u);
+  if (!(e.effort >= p.effort_min && e.effort <= p.effort_init) || !(e.recovery >= p.recover_min && e.recovery <= p.recover_init))
+    atomicAdd(&out[SV_EFFORT_RECOVERY], 1u);
+  if (e.step_number < 0 || e.episode < 0 || !(e.prev_dist >= 0.0f)) atomicAdd(&out[SV_COUNTERS], 1u);
+  if (!obs_ok) atomicAdd(&out[SV_OBS], 1u);
+}
+
 // diagnostic: evaluate the math spec / Philox on the device (tests compare with the oracle)
 __global__ void s2d_debug_eval_kernel(int op, const float* __restrict__ in, float* __restrict__ out, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1266,6 +1291,24 @@ S2D_API int s2d_stats_reset(S2DHandle h, void* stream) {
 }
 
 S2D_API const char* s2d_kernel_name(S2DHandle h) { return h ? h->last_kernel : ""; }
+
+S2D_API int s2d_validate_state(S2DHandle h, uint32_t* counts_dev, void* stream) {
+  if (!h || !counts_dev) return fail(S2D_EINVAL, "NULL argument");
+  DeviceGuard guard(h->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemsetAsync(counts_dev, 0, SV_WORDS * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(s2d_validate_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, st, h->hot,
+                     reinterpret_cast<const float*>(h->buf.player_x), h->stride, h->n, h->buf.obs, counts_dev);
+  HIP_TRY(hipGetLastError());
+  return S2D_OK;
+}
+
+S2D_API int s2d_set_seed(S2DHandle h, uint64_t seed) {
+  if (!h) return fail(S2D_EINVAL, "NULL handle");
+  h->cfg.seed = seed;
+  h->hot.seed_lo = (uint32_t)seed; h->hot.seed_hi = (uint32_t)(seed >> 32);
+  return S2D_OK;
+}
 
 S2D_API int s2d_debug_eval(int op, const void* in_dev, void* out_dev, int64_t n, void* stream) {
   if (!in_dev || !out_dev || n <= 0 || op < 0 || op > 8) return fail(S2D_EINVAL, "bad s2d_debug_eval argument");

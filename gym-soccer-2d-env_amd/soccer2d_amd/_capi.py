@@ -126,6 +126,8 @@ PROTOTYPES = (
     ('s2d_world_model', C.c_int, (C.c_void_p, C.POINTER(S2DWorldModel), C.c_void_p)),
     ('s2d_stats_reset', C.c_int, (C.c_void_p, C.c_void_p)),
     ('s2d_kernel_name', C.c_char_p, (C.c_void_p,)),
+    ('s2d_validate_state', C.c_int, (C.c_void_p, C.c_void_p, C.c_void_p)),
+    ('s2d_set_seed', C.c_int, (C.c_void_p, C.c_uint64)),
     ('s2d_debug_eval', C.c_int, (C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)),
 )
 

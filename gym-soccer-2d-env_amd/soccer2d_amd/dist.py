@@ -29,31 +29,66 @@ def make_sharded_vec_env(n_global, rank, world, device=None, **kwargs):
     return Soccer2DVecEnv(count, device=device, env_id_offset=offset, **kwargs)
 
 
-def all_gather_rollout(rollout, group=None, time_major=True):
-    """All-gather a local rollout dict {name: tensor[T, N_local, ...]} over the env axis.
+FIELDS = ('obs', 'action', 'reward', 'done', 'result')
 
-    Every rank must hold the same N_local (use equal shards for league play).  Returns
-    {name: tensor[T, world*N_local, ...]} if time_major (one permute copy) else the raw
-    gathered slabs {name: tensor[world, T, N_local, ...]} (no copy after the collective).
-    One collective per field; fields are small in number and large in bytes, which is the
-    shape direct xGMI all-gathers want (7 links x ~153 GB/s per GPU)."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):      # single process: the local shard is the whole batch
-        # (copies, like the collective: the caller may reuse its rollout buffers)
-        return {k: (v.clone() if time_major else v.clone().unsqueeze(0)) for k, v in rollout.items() if v is not None}
-    world = dist.get_world_size(group)
-    out = {}
-    for name, t in rollout.items():
+
+def _pack(rollout):
+    """One contiguous uint8 slab holding every field of a rollout dict (+ its layout).  Slab-backed rollouts
+    (Engine.alloc_rollout(slab=True)) are used as they are; others are packed with one copy."""
+    if rollout.get('_slab') is not None:
+        return rollout['_slab'], rollout['_layout']
+    layout, off = [], 0
+    for name in FIELDS:
+        t = rollout.get(name)
         if t is None:
             continue
-        t = t.contiguous()
-        slab = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(slab.view(-1), t.view(-1), group=group)
+        nb = t.numel() * t.element_size()
+        layout.append((name, t.dtype, tuple(t.shape), off, nb))
+        off += (nb + 255) // 256 * 256
+    some = next(v for k, v in rollout.items() if k in FIELDS and v is not None)
+    slab = torch.empty(off, dtype=torch.uint8, device=some.device)
+    for name, dt, shape, o, nb in layout:
+        slab[o:o + nb].copy_(rollout[name].contiguous().view(-1).view(torch.uint8))
+    return slab, tuple(layout)
+
+
+def _views(gathered, layout, world, time_major):
+    """{name: tensor} views of a gathered slab [world, slab_bytes]."""
+    out = {}
+    for name, dt, shape, o, nb in layout:
+        v = gathered[:, o:o + nb].view(dt).view((world,) + tuple(shape))       # [world, T, N_local, ...]
         if time_major:
-            T, n = t.shape[0], t.shape[1]
-            slab = slab.movedim(0, 1).reshape((T, world * n) + tuple(t.shape[2:]))
-        out[name] = slab
+            T, n = shape[0], shape[1]
+            v = v.movedim(0, 1).reshape((T, world * n) + tuple(shape[2:]))     # one permute copy
+        out[name] = v
     return out
+
+
+def all_gather_rollout(rollout, group=None, time_major=True, out=None):
+    """All-gather a local rollout dict {name: tensor[T, N_local, ...]} over the env axis with ONE collective.
+
+    The five fields of a rollout record (obs f32, action i32 / f32, reward f32, done u8, result u8) are carved out of one
+    contiguous uint8 slab (Engine.alloc_rollout(slab=True): the rollout kernel writes into it directly, no packing copy)
+    and the slab travels in a single `all_gather_into_tensor` -- on the GPUs RCCL over xGMI; every rank holds the same
+    N_local (equal shards for league play).  Per exchange and rank: T * N_local * 50 bytes sent (+ < 1.3 KB of alignment
+    padding), world times that received: 209.7 MB out / 1.68 GB in at T = 64, N_local = 65 536, world = 8 -- one large
+    message per peer, the shape direct xGMI all-gathers want (7 links x ~153 GB/s per GPU); round 1 issued five
+    collectives per exchange, two of them 4 MB slabs where launch latency dominates.
+    Returns {name: tensor[T, world*N_local, ...]} if time_major (one permute copy per field) else the raw gathered views
+    {name: tensor[world, T, N_local, ...]} (no copy after the collective).  `out`: optional preallocated uint8 tensor
+    [world, slab_bytes] to gather into (LeagueRolloutExchange double-buffers it)."""
+    import torch.distributed as dist
+    slab, layout = _pack(rollout)
+    if not (dist.is_available() and dist.is_initialized()):      # single process: the local shard is the whole batch
+        g = slab.clone().unsqueeze(0) if out is None else out    # (copies, like the collective: the caller may reuse its buffers)
+        if out is not None:
+            out[0].copy_(slab)
+        return _views(g, layout, 1, time_major)
+    world = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty((world, slab.numel()), dtype=torch.uint8, device=slab.device)
+    dist.all_gather_into_tensor(out.view(-1), slab, group=group)
+    return _views(out, layout, world, time_major)
 
 
 def all_reduce_stats(stats, group=None):
@@ -65,41 +100,55 @@ def all_reduce_stats(stats, group=None):
 
 
 class LeagueRolloutExchange:
-    """Double-buffered rollout exchange for league self-play: while rollout k+1 is being
-    simulated on the compute stream, rollout k is all-gathered on a side stream."""
+    """Double-buffered rollout exchange for league self-play: while rollout k+1 is being simulated on the compute stream,
+    rollout k is all-gathered (one collective) on a side stream.  Local rollout slabs AND gathered slabs are allocated
+    once, up front, two of each: nothing is allocated on the side stream, so the caching allocator never hands a block that
+    compute-stream kernels still read to the next gather."""
 
     def __init__(self, env, n_steps, group=None):
+        import torch.distributed as dist
         self.env, self.T, self.group = env, int(n_steps), group
-        self.bufs = [env.engine.alloc_rollout(self.T), env.engine.alloc_rollout(self.T)]
+        self.bufs = [env.engine.alloc_rollout(self.T, slab=True), env.engine.alloc_rollout(self.T, slab=True)]
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        nbytes = self.bufs[0]['_slab'].numel()
+        self.gathered = [torch.empty((self.world, nbytes), dtype=torch.uint8, device=env.device) for _ in range(2)]
+        self.bytes_per_exchange = {'sent': nbytes, 'received': self.world * nbytes, 'collectives': 1}
         self.side = torch.cuda.Stream(env.device)
         self.k = 0
         self._pending = None
 
     def step(self, actions=None):
-        """Simulate T cycles into buffer k, start gathering it, return the PREVIOUS gathered
-        rollout (None on the first call)."""
-        buf = self.bufs[self.k & 1]
+        """Simulate T cycles into buffer k, start gathering it, return the PREVIOUS gathered rollout (None on the first
+        call): {name: tensor[world, T, N_local, ...]} views of a gathered slab that stays valid until the call after next."""
+        b = self.k & 1
+        buf = self.bufs[b]
         cur = torch.cuda.current_stream(self.env.device)
         self.env.engine.rollout(self.T, actions=actions, out=buf)
         ready = torch.cuda.Event()
         ready.record(cur)
         prev = self._pending
         with torch.cuda.stream(self.side):
+            # `ready` also orders this gather behind every read the caller queued on the compute stream from gathered[b],
+            # which was handed out two calls ago
             self.side.wait_event(ready)
-            gathered = all_gather_rollout(buf, group=self.group, time_major=False)
+            gathered = all_gather_rollout(buf, group=self.group, time_major=False, out=self.gathered[b])
             done = torch.cuda.Event()
             done.record(self.side)
-        self._pending = (gathered, done)
+        self._pending = (gathered, done, b)
         self.k += 1
         if prev is None:
             return None
-        prev[1].synchronize()
-        return prev[0]
+        return self._hand_out(prev, cur)
+
+    def _hand_out(self, pending, cur):
+        g, ev, b = pending
+        cur.wait_event(ev)                                    # consumers on the compute stream see the finished gather
+        return g
 
     def flush(self):
         if self._pending is None:
             return None
-        g, ev = self._pending
-        ev.synchronize()
+        cur = torch.cuda.current_stream(self.env.device)
+        g = self._hand_out(self._pending, cur)
         self._pending = None
         return g

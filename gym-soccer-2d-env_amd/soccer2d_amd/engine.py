@@ -193,17 +193,33 @@ class Engine:
         self._keep = (keep, out)
         return out
 
-    def alloc_rollout(self, T, with_obs=True):
+    def alloc_rollout(self, T, with_obs=True, slab=False):
+        """Caller-owned rollout buffers for `rollout(..., out=)`.  slab=True carves all five fields out of ONE contiguous
+        uint8 tensor (256-byte aligned fields; returned under the key '_slab'), so that a whole rollout record travels in a
+        single collective (dist.all_gather_rollout) without a packing copy: the kernel writes straight into the slab."""
         n, t, dev = self.num_envs, self.cfg.task, self.device
-        if not t.use_continuous_action:
-            act = torch.empty((T, n), dtype=torch.int32, device=dev)
-        else:
-            act = torch.empty((T, n, 4 if t.use_turning else 1), dtype=torch.float32, device=dev)
-        return dict(obs=torch.empty((T, n, S2D_OBS_DIM), dtype=torch.float32, device=dev) if with_obs else None,
-                    action=act,
-                    reward=torch.empty((T, n), dtype=torch.float32, device=dev),
-                    done=torch.empty((T, n), dtype=torch.uint8, device=dev),
-                    result=torch.empty((T, n), dtype=torch.uint8, device=dev))
+        act_dt, act_trail = (torch.int32, ()) if not t.use_continuous_action else (torch.float32, (4 if t.use_turning else 1,))
+        fields = [('obs', torch.float32, (S2D_OBS_DIM,))] if with_obs else []
+        fields += [('action', act_dt, act_trail), ('reward', torch.float32, ()), ('done', torch.uint8, ()), ('result', torch.uint8, ())]
+        if not slab:
+            out = {name: torch.empty((T, n) + trail, dtype=dt, device=dev) for name, dt, trail in fields}
+            out.setdefault('obs', None)
+            return out
+        layout, off = [], 0
+        for name, dt, trail in fields:
+            cnt = T * n
+            for d in trail:
+                cnt *= d
+            nbytes = cnt * torch.empty((), dtype=dt).element_size()
+            layout.append((name, dt, (T, n) + trail, off, nbytes))
+            off += (nbytes + 255) // 256 * 256
+        raw = torch.empty(off + 256, dtype=torch.uint8, device=dev)
+        shift = (-raw.data_ptr()) % 256
+        slab_t = raw[shift:shift + off]
+        out = {name: slab_t[o:o + nb].view(dt).view(shape) for name, dt, shape, o, nb in layout}
+        out.setdefault('obs', None)
+        out['_slab'], out['_layout'] = slab_t, tuple(layout)
+        return out
 
     # ------------------------------------------------------------------ state access
     def world_model_derived(self):
@@ -216,6 +232,20 @@ class Engine:
             setattr(wm, k, v.data_ptr())
         _capi.check(self.lib, self.lib.s2d_world_model(self._h, C.byref(wm), self._stream()), 's2d_world_model')
         return self._wm
+
+    VALIDATE_NAMES = ('non_finite', 'angle_range', 'stamina_range', 'effort_recovery_range', 'counters', 'obs_non_finite')
+
+    def validate_state(self):
+        """Debug guard (s2d_validate_state): dict of violation counts; all zero for every state the engine produces."""
+        counts = torch.zeros(8, dtype=torch.int32, device=self.device)
+        _capi.check(self.lib, self.lib.s2d_validate_state(self._h, C.c_void_p(counts.data_ptr()), self._stream()), 's2d_validate_state')
+        c = counts.cpu().tolist()
+        return dict(zip(self.VALIDATE_NAMES, c))
+
+    def set_seed(self, seed):
+        """New Philox key for all later draws (takes effect at the next launch)."""
+        _capi.check(self.lib, self.lib.s2d_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF), 's2d_set_seed')
+        self.cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
 
     @property
     def stats(self):

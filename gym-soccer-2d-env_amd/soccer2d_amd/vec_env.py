@@ -66,7 +66,14 @@ class Soccer2DVecEnv:
             self._closed = True
 
     def seed(self, seed=None):
-        raise NotImplementedError('the Philox key is fixed at construction (seed=...); build a new env')
+        """gym's env.seed(): a new Philox key for every later draw (resets, in-engine policy, noise), followed by a reset of
+        all envs so that the next episodes start from the new stream.  The reference never seeds its `random` / `np.random`
+        (reach_ball_env.py:71, 173-205); here the same seed gives the same trajectories on any shard layout."""
+        if seed is None:
+            seed = int(torch.seed()) & 0xFFFFFFFFFFFFFFFF
+        self.engine.set_seed(seed)
+        self.reset()
+        return [int(seed)]
 
     # -- reference-style views -------------------------------------------------------------
     def infos(self, result=None):

@@ -212,6 +212,15 @@ int s2d_world_model(S2DHandle h, const S2DWorldModel *out, void *stream);
 int s2d_stats_reset(S2DHandle h, void *stream);
 /* name of the most recently launched kernel variant (for profiling reports) */
 const char *s2d_kernel_name(S2DHandle h);
+/* debug guard (the reference's desync recovery, soccer_2d_env.py:154-159, 257-260, has no counterpart in a
+ * lockstep engine; what remains to watch is a state word leaving its domain).  counts_dev[8] (device memory) receives the
+ * number of envs with: [0] a non-finite state word, [1] |body| or |prev_angle| > 180, [2] stamina outside [0, stamina_max] or a
+ * negative capacity, [3] effort / recovery outside their ServerParam ranges, [4] a negative step / episode counter or
+ * distance carry, [5] a non-finite observation; [6..7] reserved.  All zero for every state the engine produces. */
+int s2d_validate_state(S2DHandle h, uint32_t *counts_dev, void *stream);
+/* new Philox key for all later draws (gym's env.seed(); the reference's `random` / `np.random` are unseeded).  Takes
+ * effect at the next launch; callers normally follow it with s2d_reset. */
+int s2d_set_seed(S2DHandle h, uint64_t seed);
 /* diagnostic: evaluate one primitive of the fp32 math spec / Philox on the device so that
  * tests can compare it bit for bit with the CPU oracle.  op: 0 sincos_deg (in[n] -> out[n][2]),
  * 1 atan2_deg (in[n][2]=y,x -> out[n]), 2 exp, 3 norm_deg, 4 philox4x32-10 (in = uint32[n][6]

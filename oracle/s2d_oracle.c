@@ -301,6 +301,7 @@ typedef struct Env {
   int32_t step_number, cycle;
   uint32_t policy_step;   /* steps that consumed an in-engine POLICY / SELECT draw */
   uint32_t episode;       /* number of resets so far = index of the current episode (0 before the first reset) */
+  int32_t last_tries;     /* velocity candidates the last reset drew (diagnostic for the distribution tests) */
 } Env;
 
 static REAL clampr(REAL v, REAL lo, REAL hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -437,6 +438,7 @@ static void env_reset(const P *p, Env *e, uint64_t gid, REAL *obs) {
   s.seed = p->seed; s.gid = gid; s.cycle = e->episode;
   ResetDraw o;
   reset_sample(p, &s, &o);
+  e->last_tries = o.tries;
   e->step_number = 0;                                    /* :172 */
   e->bx = o.bx; e->by = o.by; e->bvx = o.bvx; e->bvy = o.bvy;      /* (move (ball) x y 0 vx vy) */
   e->px = o.px; e->py = o.py; e->body = norm_deg(o.body); e->vx = R(0.0); e->vy = R(0.0); /* (move (player..)) */
@@ -632,6 +634,7 @@ API int s2do_set_env(S2DOEngine *h, int64_t i, const double *v17) {
   e->episode = (uint32_t)v17[18];
   return 0;
 }
+API void s2do_last_tries(const S2DOEngine *h, int32_t *out) { for (int64_t i = 0; i < h->n; ++i) out[i] = h->env[i].last_tries; }
 API const REAL *s2do_obs(const S2DOEngine *h) { return h->obs; }
 API const REAL *s2do_terminal_obs(const S2DOEngine *h) { return h->terminal_obs; }
 API const REAL *s2do_reward(const S2DOEngine *h) { return h->reward; }

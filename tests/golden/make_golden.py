@@ -587,12 +587,14 @@ def gen_reset_dist(n_runs=120000):
             vx, vy = float(mb.velocity.x), float(mb.velocity.y)
             sp = math.hypot(vx, vy)
             h['speed'][min(29, int(sp / 0.1))] += 1
-            h['dir'][int(((math.degrees(math.atan2(vy, vx)) + 360.0 + 5.0) % 360.0) // 10.0)] += 1   # bins centred on multiples of 10
+            if sp > 0.0:
+                deg = int(round(math.degrees(math.atan2(vy, vx)))) % 360          # the draw was a whole degree (:205)
+                h['dir'][((deg + 5) % 360) // 10] += 1                            # bins centred on multiples of 10
             h['tries'][min(15, rec.tries - 1)] += 1
     finally:
         mod.random = real
     return {'runs': n_runs, 'seed': 20261004, 'kwargs': {'change_ball_position': True, 'change_ball_velocity': True, 'max_steps': 200},
-            'bins': {'speed': '30 bins of 0.1 over [0, 3)', 'dir': '36 bins of 10 deg centred on 0, 10, ..., 350 (direction of the accepted velocity)',
+            'bins': {'speed': '30 bins of 0.1 over [0, 3)', 'dir': '36 bins of 10 deg centred on 0, 10, ..., 350: whole degrees d with (d + 5) % 360 // 10 == bin (direction of the accepted velocity, rounded to the whole degree it was drawn as)',
                      'tries': 'number of candidates drawn, 1..15, last bin = 16 and more', 'body': 'randint(0, 360) as sent'},
             'hist': {k: v.tolist() for k, v in h.items()}}
 

@@ -301,6 +301,14 @@ class OracleEngine:
             return out.astype(np.int32)
         return out.astype(self.L._np_real)
 
+    def reset_tries(self):
+        """reset every env; the number of ball-velocity candidates each reset drew (reach_ball_env.py:202-212)"""
+        self.reset()
+        out = np.zeros(self.n, dtype=np.int32)
+        self.L.s2do_last_tries.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.s2do_last_tries(self.h, out.ctypes.data)
+        return out
+
     def set_env(self, i, **kw):
         cur = [float(self.state(f)[i]) for f in STATE_FIELDS]
         for k, v in kw.items():

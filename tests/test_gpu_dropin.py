@@ -1,5 +1,7 @@
 """Drop-in boundary on the GPU: the reference's own call patterns (dqn_stable_baselines3.py:
 36-56, reach_ball_env.py) against the HIP engine, checked with the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -241,3 +243,76 @@ def test_factory_single_env_flow_like_the_ddpg_script():
             assert np.array_equal(obs.astype(np.float32), orc.reset()[0])
     assert results['Goal'] >= 3 and results['Goal'] > results['Out'] + results['Timeout']   # steering at the ball reaches it
     env.close()
+
+
+def test_rccl_single_rank_exchange_on_device():
+    """The RCCL code path itself (backend 'nccl' IS RCCL on ROCm) with a real process group of world size 1 on cuda:0:
+    slab-backed rollout buffers, ONE all_gather_into_tensor per exchange on the side stream, the timing all-reduce of
+    bench.py.  (A scaling curve needs the driver's 8-GPU node; this pins that the device-tensor / stream plumbing works.)"""
+    import torch.distributed as dist
+    import bench
+    from soccer2d_amd.dist import LeagueRolloutExchange, all_reduce_stats, make_sharded_vec_env
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29650 + os.getpid() % 300))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == 'nccl'
+        n, T = 4096, 16
+        env = make_sharded_vec_env(n, 0, 1, device='cuda:0', **KW)
+        ref = make_sharded_vec_env(n, 0, 1, device='cuda:0', **KW)
+        env.reset(); ref.reset()
+        ex = LeagueRolloutExchange(env, T)
+        assert ex.world == 1 and ex.bytes_per_exchange['collectives'] == 1
+        assert ex.bytes_per_exchange['sent'] >= T * n * 50
+        calls, real = [], dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda *a, **k: (calls.append(a[0].device), real(*a, **k))[1]
+        try:
+            got = [ex.step(), ex.step(), ex.step(), ex.flush()]
+        finally:
+            dist.all_gather_into_tensor = real
+        assert got[0] is None and len(calls) == 3 and all(d.type == 'cuda' for d in calls)
+        for k in range(3):
+            want = ref.rollout(T)
+            torch.cuda.synchronize()
+            for name in ('obs', 'action', 'reward', 'done', 'result'):
+                assert got[k + 1][name].shape == (1,) + tuple(want[name].shape)
+                assert torch.equal(got[k + 1][name][0], want[name]), (k, name)
+        assert bench.max_over_ranks(dist, dev, 1.25) == 1.25                      # the timing all-reduce of bench.py, on RCCL
+        s = all_reduce_stats(env.engine.stats)
+        assert torch.equal(s, env.engine.stats)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_validate_state_guard():
+    """s2d_validate_state: zero violations for everything the engine produces (noise on, 4 096 envs x 200 cycles); hand-made
+    violations are counted by category."""
+    from soccer2d_amd.vec_env import Soccer2DVecEnv
+    env = Soccer2DVecEnv(4096, noise=True, **KW)
+    env.reset()
+    for _ in range(3):
+        env.rollout(64, with_obs=False)
+    env.step(None)
+    assert set(env.engine.validate_state().values()) == {0}
+    e = env.engine
+    e.player_x[5] = float('nan'); e.ball_vy[6] = float('inf'); e.player_body[9] = 270.0; e.stamina[7] = -1.0
+    e.effort[11] = 0.1; e.step_number[12] = -3; e.obs[13, 4] = float('nan')
+    v = e.validate_state()
+    assert v == dict(non_finite=2, angle_range=1, stamina_range=1, effort_recovery_range=1, counters=1, obs_non_finite=1), v
+
+
+def test_seed_gives_a_new_reproducible_stream():
+    """gym's env.seed(): new Philox key + reset (the reference never seeds its RNGs)."""
+    from soccer2d_amd.vec_env import Soccer2DVecEnv
+    a, b = Soccer2DVecEnv(1000, **KW), Soccer2DVecEnv(1000, seed=99, **KW)
+    a.reset(); b.reset()
+    before = a.rollout(8)['obs'].clone()
+    assert a.seed(1234) == [1234] and b.seed(1234) == [1234]
+    assert torch.equal(a.engine.obs, b.engine.obs)                       # the reset seed() performs
+    ra, rb = a.rollout(40), b.rollout(40)
+    for k in ('obs', 'action', 'reward', 'done', 'result'):
+        assert torch.equal(ra[k], rb[k]), k
+    a.seed(1235)
+    assert not torch.equal(a.rollout(40)['action'], rb['action']) and not torch.equal(before, ra['obs'][:8])

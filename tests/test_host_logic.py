@@ -84,8 +84,12 @@ def _worker(rank, world, port, n_global, T, q):
     eng.reset()
     ro = eng.rollout(T)
     local = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ro.items()}
+    calls, real = [], dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     full = all_gather_rollout(local, time_major=True)
+    assert len(calls) == 1, 'one collective per exchange (all five fields travel in one slab)'
     raw = all_gather_rollout(local, time_major=False)
+    dist.all_gather_into_tensor = real
     stats = all_reduce_stats(torch.from_numpy(eng.stats().astype(np.int64)))
     if rank == 0:
         q.put(({k: v.numpy() for k, v in full.items()}, {k: tuple(v.shape) for k, v in raw.items()}, stats.numpy()))
