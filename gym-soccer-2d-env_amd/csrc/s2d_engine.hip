@@ -43,7 +43,22 @@ struct StepOut {
   float* action_dir;     // [N]
   uint8_t* action_cmd;   // [N]
   unsigned long long* stats;
+  float* prep;           // persistent prepared episodes of the per-step API: [2][PS_WORDS][stride] words + [2][stride] tags
 };
+
+// ---- persistent prepared episodes (per-step API) ------------------------------------------------------------------------
+// s2d_step runs one wave per 64 envs, and a launch lasts as long as its slowest wave.  Drawing a reset inline (Philox blocks,
+// the rejection loop, a simulator cycle, the first observation: ~2.8 us with one or two active lanes) therefore cost EVERY
+// launch those 2.8 us, because some wave always has an episode ending (profiles/r02/ab_step.txt: 7.3 us per launch against
+// 4.5 us for a workload whose episodes never end).  Episode j of env g is a function of (g, j) alone, so every env keeps its
+// next two episodes prepared in the arena: slot j & 1 holds episode j, tagged with j.  A step prefetches slot
+// (episode + 1) & 1 together with the state; a reset is a register copy.  Slots are refilled off the critical path by extra
+// workgroups appended to the same launch's grid: each looks at its envs' `episode` e and prepares episode e + 2 if slot
+// e & 1 does not hold it yet -- never the slot a main wave may be reading in the same launch -- and finishes well inside
+// the launch.  s2d_reset prepares both slots of the envs it resets; a slot whose tag does not match (first use after the
+// rollout kernels advanced the episode counter) is ignored and the reset is drawn inline, once.
+enum { PS_FIRST = 13, PS_DIST = PS_FIRST + S2D_OBS_DIM, PS_REL, PS_WORDS };   // NextEpisode (13 words) + FirstObs (12)
+S2D_DEV uint32_t* prep_tags(float* prep, int64_t stride) { return reinterpret_cast<uint32_t*>(prep + 2 * PS_WORDS * stride); }
 
 // LDS ops of one wave execute in order, so a wave-private tile needs no s_barrier; the
 // wavefront-scope fences only stop the compiler from reordering the cross-lane accesses.
@@ -222,6 +237,21 @@ S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, u
   }
 }
 
+// prepare episode `episode` of the env and store it in its persistent slot (episode & 1), tag last
+template <bool NOISE>
+S2D_DEV void prep_store(const S2DHot& p, const S2DRare* __restrict__ rp, float* __restrict__ prep, int64_t stride, int64_t i,
+                        uint32_t gl, uint32_t gh, uint32_t episode) {
+  const S2DRare r = *rp;
+  const NextEpisode q = episode_prepare<NOISE>(p, rp, r, gl, gh, episode);
+  const FirstObs f = first_obs(p, q);
+  float* d = prep + (int64_t)(episode & 1u) * PS_WORDS * stride + i;
+  const float w[PS_WORDS] = {q.px, q.py, q.vx, q.vy, q.body, q.stamina, q.effort, q.recovery, q.capacity, q.bx, q.by, q.bvx, q.bvy,
+                             f.o[0], f.o[1], f.o[2], f.o[3], f.o[4], f.o[5], f.o[6], f.o[7], f.o[8], f.o[9], f.dist, f.rel};
+#pragma unroll
+  for (int k = 0; k < PS_WORDS; ++k) d[k * stride] = w[k];
+  prep_tags(prep, stride)[(int64_t)(episode & 1u) * stride + i] = episode;
+}
+
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
@@ -264,6 +294,10 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_reset_kernel(S2DHot p, const
       observe_and_check(p, e, d2, ob, d, w, r);
       env_store(e, S, stride, i);
       o.reward[i] = 0.0f; o.done[i] = 0; o.result[i] = 0;
+      if (p.auto_reset) {                                // the per-step API's prepared episodes (see StepOut::prep)
+        prep_store<NOISE>(p, rp, o.prep, stride, i, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)e.episode + 1u);
+        prep_store<NOISE>(p, rp, o.prep, stride, i, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)e.episode + 2u);
+      }
     } else {                                             // keep the row this env already has
 #pragma unroll
       for (int k = 0; k < S2D_OBS_DIM; ++k) ob.o[k] = o.obs[i * S2D_OBS_DIM + k];
@@ -277,10 +311,24 @@ template <int MODE, bool NOISE>
 __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const S2DRare* __restrict__ rp,
                                                                 float* __restrict__ S, int64_t stride, int64_t n,
                                                                 const void* __restrict__ actions, int kind,
-                                                                StepOut o) {
+                                                                StepOut o, int refill_blocks) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if ((int)blockIdx.x < refill_blocks) {
+    // ---- refill workgroups (see StepOut::prep), the FIRST blocks of the grid so that they start first: episode e + 2 into
+    // slot e & 1 where it is missing
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* const tags = prep_tags(o.prep, stride);
+    const uint32_t t0 = tags[i], t1 = tags[stride + i];  // both tags: no load whose address waits for another load
+    const uint32_t e2 = reinterpret_cast<const uint32_t*>(S + F_EPISODE * stride)[i] + 2u;
+    if (((e2 & 1u) ? t1 : t0) == e2) return;
+    const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
+    prep_store<NOISE>(p, rp, o.prep, stride, i, (uint32_t)gid, (uint32_t)(gid >> 32), e2);
+    return;
+  }
+  const int main_block = (int)blockIdx.x - refill_blocks;
+  const int64_t i = (int64_t)main_block * kBlock + threadIdx.x;
   const int64_t wave_first = i - lane;
   if (wave_first >= n) return;                           // wave-uniform
   const bool active = i < n;
@@ -295,12 +343,52 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
     uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
     uint32_t k = 0;
     if (use_k) k = kplane[i];
+    // the prepared next episode travels with the state (loaded always, used when the episode ends in this step)
+    // (BOTH slots: which one holds episode + 1 depends on the episode word, and a load whose address waits for another load
+    // would put a second memory latency on every step)
+    float pw0[PS_WORDS], pw1[PS_WORDS];
+    uint32_t ptag0 = 0u, ptag1 = 0u;
+    if (p.auto_reset) {
+      const float* src = o.prep + i;
+#pragma unroll
+      for (int w = 0; w < PS_WORDS; ++w) { pw0[w] = src[w * stride]; pw1[w] = src[(PS_WORDS + w) * stride]; }
+      ptag0 = prep_tags(o.prep, stride)[i]; ptag1 = prep_tags(o.prep, stride)[stride + i];
+    }
     U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
     float reward, dir; int done, cmd;
+#if S2D_XSKIP & 16
+    cmd = 1; dir = e.vx; reward = e.vy; done = 0;
+    ob.o[0] = e.px; ob.o[1] = e.py; ob.o[2] = e.body; ob.o[3] = e.stamina; ob.o[4] = e.effort; ob.o[5] = e.bx; ob.o[6] = e.by;
+    ob.o[7] = e.bvx; ob.o[8] = e.bvy; ob.o[9] = e.prev_dist; e.cycle += 1;
+#else
     CmdPrep c = decide<MODE>(p, actions, kind, i, gl, gh, k, true, quad, squad, nullptr, cmd, dir);
-    bool no_prep = false;
-    step_env<NOISE>(p, rp, e, gl, gh, k, cmd, c, ob, reward, done, res, o.terminal_obs + i * S2D_OBS_DIM, nullptr,
-                    lane, no_prep);
+    // A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269), as step_env(), with the reset served from the prefetched slot
+    e.step_number += 1;                                  // reach_ball_env.py:55
+    NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (NOISE) nz = noise_prepare(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);
+    float d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);   // trainer forces PlayOn each cycle (:242)
+    observe_and_check(p, e, d2, ob, done, reward, res);
+    if (done && p.auto_reset) {                          // SB3 VecEnv convention
+      float* const terminal_row = o.terminal_obs + i * S2D_OBS_DIM;
+#pragma unroll
+      for (int w = 0; w < S2D_OBS_DIM; ++w) terminal_row[w] = ob.o[w];
+      const bool odd = (((uint32_t)e.episode + 1u) & 1u) != 0u;
+      const uint32_t ptag = odd ? ptag1 : ptag0;
+      float pw[PS_WORDS];
+#pragma unroll
+      for (int w = 0; w < PS_WORDS; ++w) pw[w] = odd ? pw1[w] : pw0[w];
+      if (ptag == (uint32_t)e.episode + 1u) {            // prepared: a copy
+        episode_begin(e, NextEpisode{pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7], pw[8], pw[9], pw[10], pw[11], pw[12]});
+#pragma unroll
+        for (int w = 0; w < S2D_OBS_DIM; ++w) ob.o[w] = pw[PS_FIRST + w];
+        e.prev_dist = pw[PS_DIST]; e.prev_angle = pw[PS_REL];   // reach_ball_env.py:166: carry seeded
+      } else {                                           // slot not (yet) valid: draw it here
+        d2 = env_reset<NOISE>(p, rp, e, gl, gh);
+        int dn2, r2; float w2;
+        observe_and_check(p, e, d2, ob, dn2, w2, r2);    // reach_ball_env.py:166: carry seeded, outputs dropped
+      }
+    }
+#endif
     env_store(e, S, stride, i);
     if (use_k) kplane[i] = k + 1u;
     o.reward[i] = reward;
@@ -312,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
   int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
   store_obs_tile(lds[wv], ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, (int)rows * S2D_OBS_DIM);
   wave_count_results(res, active, lane, o.stats);
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n);
+  if (main_block == 0 && threadIdx.x == 0) atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n);
 }
 
 // T fused cycles per launch: the 17 state words stay in registers, only the rollout record
@@ -923,7 +1011,7 @@ static int64_t stride_for(int64_t n) { return (int64_t)align_up((size_t)n, 256);
 
 static_assert(sizeof(S2DRare) <= 256, "S2DTables sit 256 bytes behind S2DRare");
 struct ArenaLayout {
-  size_t state, obs, reward, done, result, terminal_obs, action_dir, action_cmd, stats, rare, tables, total;
+  size_t state, obs, reward, done, result, terminal_obs, action_dir, action_cmd, stats, prep, rare, tables, total;
 };
 static ArenaLayout layout_for(int64_t n) {
   ArenaLayout L;
@@ -937,6 +1025,7 @@ static ArenaLayout layout_for(int64_t n) {
   L.action_dir = off; off += align_up(s * 4, 256);
   L.action_cmd = off; off += align_up(s, 256);
   L.stats = off; off += (size_t)S2D_STATS_STRIPES * 8 * sizeof(unsigned long long);
+  L.prep = off; off += align_up((size_t)(2 * PS_WORDS + 2) * s * 4, 256);
   L.rare = off; off += align_up(sizeof(S2DRare), 256);
   L.tables = off; off += align_up(sizeof(S2DTables), 256);   // directly behind S2DRare: kernels find them at rp + 256 bytes
   L.total = off;
@@ -1125,7 +1214,8 @@ S2D_API int s2d_create(const S2DConfig* cfg, int64_t n_envs, int device, void* a
   b.action_dir = reinterpret_cast<float*>(h->arena + L.action_dir);
   b.action_cmd = reinterpret_cast<uint8_t*>(h->arena + L.action_cmd);
   b.stats = reinterpret_cast<unsigned long long*>(h->arena + L.stats);
-  h->out = StepOut{b.obs, b.reward, b.done, b.result, b.terminal_obs, b.action_dir, b.action_cmd, b.stats};
+  h->out = StepOut{b.obs, b.reward, b.done, b.result, b.terminal_obs, b.action_dir, b.action_cmd, b.stats,
+                   reinterpret_cast<float*>(h->arena + L.prep)};
   h->rare_dev = reinterpret_cast<const S2DRare*>(h->arena + L.rare);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipError_t e = hipMemsetAsync(h->arena, 0, L.total, st);
@@ -1216,14 +1306,17 @@ S2D_API int s2d_step(S2DHandle h, const void* actions_dev, int action_kind, void
   int rc = check_action_kind(h, actions_dev, action_kind);
   if (rc != S2D_OK) return rc;
   DeviceGuard guard(h->device);
-  using StepK = void (*)(S2DHot, const S2DRare*, float*, int64_t, int64_t, const void*, int, StepOut);
+  using StepK = void (*)(S2DHot, const S2DRare*, float*, int64_t, int64_t, const void*, int, StepOut, int);
   static const StepK table[3][2] = {
       {s2d_reach_step_kernel<S2D_MODE_DISCRETE, false>, s2d_reach_step_kernel<S2D_MODE_DISCRETE, true>},
       {s2d_reach_step_kernel<S2D_MODE_CONT1, false>, s2d_reach_step_kernel<S2D_MODE_CONT1, true>},
       {s2d_reach_step_kernel<S2D_MODE_TURN4, false>, s2d_reach_step_kernel<S2D_MODE_TURN4, true>}};
-  hipLaunchKernelGGL(table[h->mode][h->noise ? 1 : 0], dim3(grid_for(h->n)), dim3(kBlock), 0,
+  // main workgroups + (with auto-reset) as many refill workgroups: they keep the prepared episodes of StepOut::prep topped up
+  const int main_blocks = grid_for(h->n), refill_blocks = h->cfg.auto_reset ? main_blocks : 0;
+  hipLaunchKernelGGL(table[h->mode][h->noise ? 1 : 0], dim3(main_blocks + refill_blocks), dim3(kBlock), 0,
                      static_cast<hipStream_t>(stream), h->hot, h->rare_dev,
-                     reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, actions_dev, action_kind, h->out);
+                     reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, actions_dev, action_kind, h->out,
+                     refill_blocks);
   HIP_TRY(hipGetLastError());
   h->last_kernel = "s2d_reach_step_kernel";
   return S2D_OK;

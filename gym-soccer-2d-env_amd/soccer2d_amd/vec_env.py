@@ -72,6 +72,9 @@ class Soccer2DVecEnv:
         if seed is None:
             seed = int(torch.seed()) & 0xFFFFFFFFFFFFFFFF
         self.engine.set_seed(seed)
+        # the draw counters are part of the stream position (episode index: reset sampler; policy_step: policy / noise)
+        self.engine.episode.zero_()
+        self.engine.policy_step.zero_()
         self.reset()
         return [int(seed)]
 

@@ -197,7 +197,9 @@ def test_league_rollout_exchange_single_rank_overlaps_streams():
     b = make_sharded_vec_env(4096, 0, 1, device='cuda:0', **KW)
     a.reset(); b.reset()
     ex = LeagueRolloutExchange(a, 16)
-    got = [ex.step() for _ in range(3)] + [ex.flush()]
+    # a handed-out rollout is a view of one of the exchange's two gathered slabs: valid until the call after next
+    keep = lambda g: None if g is None else {k: v.clone() for k, v in g.items()}
+    got = [keep(ex.step()) for _ in range(3)] + [keep(ex.flush())]
     assert got[0] is None
     for g in got[1:]:
         ref = b.rollout(16)
@@ -268,8 +270,9 @@ def test_rccl_single_rank_exchange_on_device():
         assert ex.bytes_per_exchange['sent'] >= T * n * 50
         calls, real = [], dist.all_gather_into_tensor
         dist.all_gather_into_tensor = lambda *a, **k: (calls.append(a[0].device), real(*a, **k))[1]
+        keep = lambda g: None if g is None else {k: v.clone() for k, v in g.items()}
         try:
-            got = [ex.step(), ex.step(), ex.step(), ex.flush()]
+            got = [keep(ex.step()), keep(ex.step()), keep(ex.step()), keep(ex.flush())]
         finally:
             dist.all_gather_into_tensor = real
         assert got[0] is None and len(calls) == 3 and all(d.type == 'cuda' for d in calls)
