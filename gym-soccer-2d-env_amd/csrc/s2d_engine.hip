@@ -51,13 +51,17 @@ struct StepOut {
 // the rejection loop, a simulator cycle, the first observation: ~2.8 us with one or two active lanes) therefore cost EVERY
 // launch those 2.8 us, because some wave always has an episode ending (profiles/r02/ab_step.txt: 7.3 us per launch against
 // 4.5 us for a workload whose episodes never end).  Episode j of env g is a function of (g, j) alone, so every env keeps its
-// next two episodes prepared in the arena: slot j & 1 holds episode j, tagged with j.  A step prefetches slot
-// (episode + 1) & 1 together with the state; a reset is a register copy.  Slots are refilled off the critical path by extra
+// next two episodes prepared in the arena: slot j & 1 holds episode j, tagged with j.  A slot is the seven words of the
+// post-reset state that depend on the draw (player x, y, body; ball x, y, vx, vy after the reset's command-less cycle); the
+// rest is constant (player at rest, stamina model one cycle after a recover) or a function of those seven (first
+// observation, reward carry) and is rebuilt in the few waves that reset -- every extra load of a step costs all waves
+// ~15 ns (profiles/r02/ab_step.txt), a rebuilt word only the resetting ones.  A step loads both slots with the state (no
+// load waits for another one's result); a reset is a register copy plus ~0.4 us of arithmetic.  Slots are refilled off the critical path by extra
 // workgroups appended to the same launch's grid: each looks at its envs' `episode` e and prepares episode e + 2 if slot
 // e & 1 does not hold it yet -- never the slot a main wave may be reading in the same launch -- and finishes well inside
 // the launch.  s2d_reset prepares both slots of the envs it resets; a slot whose tag does not match (first use after the
 // rollout kernels advanced the episode counter) is ignored and the reset is drawn inline, once.
-enum { PS_FIRST = 13, PS_DIST = PS_FIRST + S2D_OBS_DIM, PS_REL, PS_WORDS };   // NextEpisode (13 words) + FirstObs (12)
+enum { PS_PX, PS_PY, PS_BODY, PS_BX, PS_BY, PS_BVX, PS_BVY, PS_WORDS };
 S2D_DEV uint32_t* prep_tags(float* prep, int64_t stride) { return reinterpret_cast<uint32_t*>(prep + 2 * PS_WORDS * stride); }
 
 // LDS ops of one wave execute in order, so a wave-private tile needs no s_barrier; the
@@ -243,13 +247,21 @@ S2D_DEV void prep_store(const S2DHot& p, const S2DRare* __restrict__ rp, float* 
                         uint32_t gl, uint32_t gh, uint32_t episode) {
   const S2DRare r = *rp;
   const NextEpisode q = episode_prepare<NOISE>(p, rp, r, gl, gh, episode);
-  const FirstObs f = first_obs(p, q);
   float* d = prep + (int64_t)(episode & 1u) * PS_WORDS * stride + i;
-  const float w[PS_WORDS] = {q.px, q.py, q.vx, q.vy, q.body, q.stamina, q.effort, q.recovery, q.capacity, q.bx, q.by, q.bvx, q.bvy,
-                             f.o[0], f.o[1], f.o[2], f.o[3], f.o[4], f.o[5], f.o[6], f.o[7], f.o[8], f.o[9], f.dist, f.rel};
+  const float w[PS_WORDS] = {q.px, q.py, q.body, q.bx, q.by, q.bvx, q.bvy};
 #pragma unroll
   for (int k = 0; k < PS_WORDS; ++k) d[k * stride] = w[k];
   prep_tags(prep, stride)[(int64_t)(episode & 1u) * stride + i] = episode;
+}
+// the post-reset state from a slot: the drawn words + what every reset leaves behind (reset_apply: player at rest -- its
+// velocity stays +0 through the command-less cycle, with noise on too: the noise magnitude is proportional to the speed --
+// and the stamina model one update after a recover)
+S2D_DEV NextEpisode prep_episode(const S2DHot& p, const S2DRare* __restrict__ rp, const float* w) {
+  Env t{};
+  t.stamina = p.stamina_max; t.recovery = rp->recover_init; t.effort = p.effort_init; t.capacity = p.stamina_capacity;
+  update_stamina(p, t);
+  return NextEpisode{w[PS_PX], w[PS_PY], 0.0f, 0.0f, w[PS_BODY], t.stamina, t.effort, t.recovery, t.capacity,
+                     w[PS_BX], w[PS_BY], w[PS_BVX], w[PS_BVY]};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -377,11 +389,13 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
       float pw[PS_WORDS];
 #pragma unroll
       for (int w = 0; w < PS_WORDS; ++w) pw[w] = odd ? pw1[w] : pw0[w];
-      if (ptag == (uint32_t)e.episode + 1u) {            // prepared: a copy
-        episode_begin(e, NextEpisode{pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7], pw[8], pw[9], pw[10], pw[11], pw[12]});
+      if (ptag == (uint32_t)e.episode + 1u) {            // prepared: a copy + the words that follow from it
+        const NextEpisode q = prep_episode(p, rp, pw);
+        episode_begin(e, q);
+        const FirstObs f = first_obs(p, q);
 #pragma unroll
-        for (int w = 0; w < S2D_OBS_DIM; ++w) ob.o[w] = pw[PS_FIRST + w];
-        e.prev_dist = pw[PS_DIST]; e.prev_angle = pw[PS_REL];   // reach_ball_env.py:166: carry seeded
+        for (int w = 0; w < S2D_OBS_DIM; ++w) ob.o[w] = f.o[w];
+        e.prev_dist = f.dist; e.prev_angle = f.rel;      // reach_ball_env.py:166: carry seeded
       } else {                                           // slot not (yet) valid: draw it here
         d2 = env_reset<NOISE>(p, rp, e, gl, gh);
         int dn2, r2; float w2;
