@@ -556,17 +556,20 @@ enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_FLAGS, WS_WORDS }
 enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_NPM, WA_NPS, WA_NPC, WA_NBM, WA_NBS, WA_NBC, WA_NTU, WA_WORDS };   // command + prepared noise
 enum { SL_FIRST = 13, SL_DIST = SL_FIRST + S2D_OBS_DIM, SL_REL, SL_WORDS };   // slot = NextEpisode (13 words) + FirstObs (12)
 static constexpr int kSlots = 3;
-// Issue priority of the four role waves of a group (s_setprio): a SIMD holds one wave of each role (of four
-// different groups, profiles/r01/wave_placement.txt), and the arbiter should prefer them by their slack --
-// simulate (none) first, the policy wave (half a cycle of slack) last.  Overridable for experiments.
+// Issue priority of the four role waves of a group (s_setprio): a SIMD holds one wave of each role (of four different
+// groups, profiles/r01/wave_placement.txt) and the arbiter should prefer them by their slack.  Round 1's simulate wave had
+// the longest chain (2/1/1/0); with the dash-only fast path it is the observing waves that have none left -- steady clocks,
+// 65 536 envs x 64 cycles, us per launch, simulate/agent/ball/policy (profiles/r02/ab_prio.txt): 0/0/0/0 51.2, 2/1/1/0 47.9,
+// 1/1/1/0 48.2, 2/2/2/0 48.2, 2/2/1/0 48.0, 3/2/1/0 47.8, 1/2/2/0 46.7; second box: 1/2/2/0 45.9, 1/3/2/0 45.6, 1/2/3/0 46.0,
+// 0/2/2/0 46.8, 1/3/3/0 46.2, 0/1/1/0 46.7, 2/3/3/0 46.0 (noise on: 1/2/2/0 58.7, 0/2/2/0 64.6).  Overridable for experiments.
 #ifndef S2D_PRIO_S
-#define S2D_PRIO_S 2
+#define S2D_PRIO_S 1
 #endif
 #ifndef S2D_PRIO_A
-#define S2D_PRIO_A 1
+#define S2D_PRIO_A 2
 #endif
 #ifndef S2D_PRIO_B
-#define S2D_PRIO_B 1
+#define S2D_PRIO_B 2
 #endif
 static constexpr int kWsBlock = 4 * kWave;
 

@@ -102,6 +102,19 @@ def test_device_math_bit_exact():
     assert np.array_equal(bits(got), bits(exp))   # hypot spec = sqrtf(fmaf(x,x,y*y))
     true = np.sqrt(yx[:, 0].astype(np.float64) ** 2 + yx[:, 1].astype(np.float64) ** 2)
     assert (np.abs(got - true) <= 1.2e-7 * np.maximum(true, 1e-30)).all()
+    # the device takes its square roots with a lean correctly-rounded sequence (sqrt_cr, s2d_device.h): every magnitude,
+    # squares that are exact / just off a representable root, the 2^-96 hand-over to the general sequence, denormals, zero
+    mag = 10.0 ** rs.uniform(-24, 18, 60000)
+    wide = np.stack([mag * rs.uniform(-1, 1, 60000), mag * rs.uniform(-1, 1, 60000)], axis=1).astype(np.float32)
+    k = np.arange(1, 2001, dtype=np.float32)
+    exact = np.stack([k * 0.25, np.zeros_like(k)], axis=1)
+    off = np.stack([np.nextafter(k, np.float32(np.inf)), np.zeros_like(k)], axis=1)
+    edge = np.array([[0, 0], [2.0 ** -48, 0], [2.0 ** -48, 2.0 ** -48], [2.0 ** -49, 2.0 ** -49], [2.0 ** -50, 0], [1e-30, 1e-31],
+                     [1e-20, 0], [3e-20, 4e-20], [1e-22, 0], [1e19, 1e19], [5, 0], [3, 4], [52.5, 34]], dtype=np.float32)
+    for arr in (wide, exact, off, edge):
+        got = run(5, arr, (len(arr),))
+        exp = np.array([O.hypot(float(a), float(b)) for a, b in arr], dtype=np.float32)
+        assert np.array_equal(bits(got), bits(exp)), arr[np.argwhere(bits(got) != bits(exp))[0, 0]]
     ck = rs.randint(0, 2 ** 32, (512, 6), dtype=np.uint64).astype(np.uint32)
     ck[0] = 0
     ck[1] = 0xffffffff
