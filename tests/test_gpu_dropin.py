@@ -319,3 +319,57 @@ def test_seed_gives_a_new_reproducible_stream():
         assert torch.equal(ra[k], rb[k]), k
     a.seed(1235)
     assert not torch.equal(a.rollout(40)['action'], rb['action']) and not torch.equal(before, ra['obs'][:8])
+
+
+def test_tensor_level_hooks_restate_reach_ball():
+    """The reference's extension point -- four per-env Python hooks (soccer_2d_env.py:317-354) -- at tensor level
+    (soccer2d_amd.custom_task.TensorTaskEnv): ReachBallEnv's own hooks (reach_ball_env.py:87-161) written as torch ops on
+    world_model() tensors reproduce the fused kernels' observations, rewards and labels on the same trajectories."""
+    from soccer2d_amd.custom_task import TensorTaskEnv
+    from soccer2d_amd.vec_env import Soccer2DVecEnv
+    n, max_steps, min_dist = 2048, 25, 5.0
+
+    def norm(a):
+        return torch.where(a > 180, a - 360, torch.where(a < -180, a + 360, a))
+
+    def my_obs(wm):                                                     # reach_ball_env.py:87-111
+        bx, by = wm['world_model.ball.position.x'], wm['world_model.ball.position.y']
+        px, py, body = wm['world_model.self.position.x'], wm['world_model.self.position.y'], wm['world_model.self.body_direction']
+        rel = norm(wm['world_model.ball.angle_from_self'] - body)
+        return torch.stack([rel / 180, body / 180, px / 52.5, py / 34, bx / 52.5, by / 34,
+                            wm['world_model.ball.velocity.dist'] / 3, wm['world_model.ball.velocity.angle'] / 360,
+                            wm['world_model.ball.velocity.x'] / 3, wm['world_model.ball.velocity.y'] / 3], dim=1)
+
+    def my_check(wm, env):                                              # reach_ball_env.py:113-161
+        d = wm['world_model.ball.dist_from_self']
+        rel = norm(wm['world_model.ball.angle_from_self'] - wm['world_model.self.body_direction'])
+        c = env.carry
+        if not c:
+            c['dist'], c['angle'] = torch.zeros_like(d), torch.zeros_like(d)
+        reward = (c['dist'] - d) + (c['angle'].abs() - rel.abs()) / 180
+        px, py = wm['world_model.self.position.x'], wm['world_model.self.position.y']
+        goal, out, tmo = d < min_dist, (px.abs() > 52.5) | (py.abs() > 34), env.episode_step > max_steps
+        reward = reward + 10.0 * goal + 10.0 * out - 5.0 * tmo              # the "-= -10" of :144 kept
+        result = torch.where(tmo, 3, torch.where(out, 2, torch.where(goal, 1, 0))).to(torch.uint8)
+        c['dist'], c['angle'] = d.clone(), rel.clone()
+        return goal | out | tmo, reward, result
+
+    kw = dict(use_continuous_action=False, action_space_size=16, change_ball_velocity=True, noise=False)
+    custom = TensorTaskEnv(n, my_obs, my_check, max_steps=max_steps, **kw)
+    builtin = Soccer2DVecEnv(n, max_steps=max_steps, min_distance_to_ball=min_dist, **kw)
+    o1, o2 = custom.reset(), builtin.reset()
+    assert torch.allclose(o1, o2, atol=2e-6)
+    rs = np.random.RandomState(5)
+    ends = 0
+    for t in range(80):
+        a = torch.as_tensor(rs.randint(0, 16, n), device='cuda:0')
+        o1, r1, d1, i1 = custom.step(a)
+        o2, r2, d2, i2 = builtin.step(a)
+        assert torch.equal(d1, d2.bool()) and torch.equal(i1['result'], i2['result']), t
+        assert torch.allclose(r1, r2, atol=2e-4) and torch.allclose(o1, o2, atol=2e-6), t
+        if bool(d1.any()):
+            m = d1
+            assert torch.allclose(i1['terminal_observation'][m], i2['terminal_observation'][m], atol=2e-6)
+        ends += int(d1.sum())
+    assert ends > n                                                     # every env finished at least one episode
+    custom.close(); builtin.close()
