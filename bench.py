@@ -247,7 +247,7 @@ def bench_match(args):
     if dist is not None:
         dist.barrier()
     elapsed = max_over_ranks(dist, dev, time.perf_counter() - t0)
-    state_b, rec_b = 23 * 11 * 4 + 13 * 4, 24 * 5 * 4 + 4 + 4 + 1   # 23 objects x 11 words + 13 game ints; rollout record
+    state_b, rec_b = 23 * 11 * 4 + 15 * 4, 24 * 5 * 4 + 4 + 4 + 1   # 23 objects x 11 words + 15 game ints; rollout record
     per_launch_steps = T if args.mode == 'rollout' else 1
     alg = n * (2 * state_b + (per_launch_steps * rec_b if args.mode == 'rollout' else 5))
     launch_s = e0.elapsed_time(e1) * 1e-3 / launches

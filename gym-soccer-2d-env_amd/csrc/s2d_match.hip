@@ -47,7 +47,7 @@ enum { MF_X, MF_Y, MF_VX, MF_VY, MF_BODY, MF_STAMINA, MF_EFFORT, MF_RECOVERY, MF
 enum { PT_SPEED_MAX, PT_SPEED_MAX2, PT_STAMINA_INC, PT_DECAY, PT_INERTIA, PT_DASH_RATE, PT_SIZE, PT_INV_KICK_MARGIN,
        PT_KICKABLE_AREA2, PT_KICK_RAND, PT_EXTRA_STAMINA, PT_EFFORT_MAX, PT_EFFORT_MIN, PT_KICK_RATE, PT_CATCH_LEN, PT_WORDS };
 enum { ME_CYCLE, ME_MODE, ME_MODE_SIDE, ME_SCORE_L, ME_SCORE_R, ME_LAST_TOUCH, ME_TIMER, ME_OFFSIDE, ME_REWARD, ME_NEAREST_L,
-       ME_NEAREST_R, ME_HOLDER, ME_MOVES, ME_ENV_PLANES };
+       ME_NEAREST_R, ME_HOLDER, ME_MOVES, ME_TAKER, ME_LAST_KICKER, ME_ENV_PLANES };
 
 struct MParams {   // every field rounded once on the host (double -> float); per-PlayerType values live in the PT table
   float half_l, half_w, ball_size, player_rand, ball_rand;
@@ -65,7 +65,7 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
   float goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
   float catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle, goalie_max_moves;
-  int after_goal_wait;
+  int after_goal_wait, kick_off_wait, back_passes, free_kick_faults;
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
 };
@@ -73,7 +73,8 @@ typedef float PTab[kHalf];   // one row of the per-slot table
 
 struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int tackle, catch_ban; };
 struct MGame { int cycle, mode, mode_side, score_l, score_r, last_touch, timer, offside; float reward; int done, nearest_l, nearest_r;
-               int holder, moves; /* 1 + index of the goalie holding a caught ball (0 = nobody), his remaining moves */ };
+               int holder, moves; /* 1 + index of the goalie holding a caught ball (0 = nobody), his remaining moves */
+               int taker, last_kicker; /* 1 + index (0 = nobody): set-play taker not yet followed by another touch; last Kick-command kicker */ };
 
 __constant__ float kFormX[11] = {-50.0f, -35.0f, -35.0f, -35.0f, -35.0f, -20.0f, -20.0f, -20.0f, -20.0f, -10.5f, -10.5f};
 __constant__ float kFormY[11] = {0.0f, -20.0f, -7.0f, 7.0f, 20.0f, -22.0f, -8.0f, 8.0f, 22.0f, -6.0f, 6.0f};
@@ -106,7 +107,7 @@ S2D_DEV void m_recover(const MParams& p, float effort_max, MObj& o, bool with_ca
 }
 S2D_DEV void m_reset(const MParams& p, float effort_max, MObj& o, MGame& g, int l) {
   o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  g = MGame{0, S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0, 0, 0, 0.0f, 0, 10, 20, 0, 0};
+  g = MGame{0, p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0, 0, 0, 0.0f, 0, 10, 20, 0, 0, 0, 0};
   if (l < NP) m_recover(p, effort_max, o, true);
   m_place(o, l, SIDE_LEFT);
 }
@@ -256,11 +257,11 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
 
   // ---- 1. commands + player movement (lane-local)
   float ax = 0.0f, ay = 0.0f, kx = 0.0f, ky = 0.0f;
-  bool kicked = false;
+  bool kicked = false, by_kick = false;                    // by_kick: the impulse came from a Kick command (not a tackle)
   if (!is_player || o.tackle > 0 || mode0 == S2D_GM_TIME_OVER) cmd = S2D_MCMD_NONE;
   U4 nz{0, 0, 0, 0}, nk{0, 0, 0, 0};
   if (p.noise) { nz = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, (uint32_t)l); nk = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, 32u + (uint32_t)l); }
-  const bool may_touch = !is_setplay(mode0) || (side_of(l) == side0 && mode0 != S2D_GM_AFTER_GOAL);   // after a goal the ball is dead
+  const bool may_touch = !is_setplay(mode0) || (side_of(l) == side0 && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_BEFORE_KICK_OFF);   // after a goal / before the kick-off the ball is dead
   bool caught = false, hold_moved = false;
   if (cmd == S2D_MCMD_DASH) m_dash(p, pt, l, o, a, bb, ax, ay);
   else if (cmd == S2D_MCMD_TURN) m_turn(p, pt[PT_INERTIA][l], o, a, rnd_u01(nz.z));
@@ -277,7 +278,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
     // while holding a caught ball, goalie_max_moves times inside the own penalty area
     const float sgn = side_of(l) == SIDE_LEFT ? 1.0f : -1.0f;
     const bool holds = mode0 == S2D_GM_FREE_KICK && g.holder == l + 1 && g.moves > 0;
-    if (mode0 == S2D_GM_KICK_OFF || mode0 == S2D_GM_AFTER_GOAL || holds) {
+    if (mode0 == S2D_GM_KICK_OFF || mode0 == S2D_GM_AFTER_GOAL || mode0 == S2D_GM_BEFORE_KICK_OFF || holds) {
       float tx = clampf(a, -p.half_l, holds ? -p.pen_x : 0.0f);
       float ty = holds ? clampf(bb, -p.pen_half_w, p.pen_half_w) : clampf(bb, -p.half_w, p.half_w);
       o.x = sgn * tx; o.y = sgn * ty; o.vx = 0.0f; o.vy = 0.0f;
@@ -285,7 +286,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
     }
   } else if (cmd == S2D_MCMD_KICK) {
     bool ok = m_kick(p, pt, l, o, bx0, by0, bvx0, bvy0, a, bb, rnd_u01(nk.x), rnd_u01(nk.y), kx, ky);
-    if (ok && may_touch) { kicked = true; cnt.kicks++; } else { kx = 0.0f; ky = 0.0f; }
+    if (ok && may_touch) { kicked = true; by_kick = true; cnt.kicks++; } else { kx = 0.0f; ky = 0.0f; }
   } else if (cmd == S2D_MCMD_TACKLE) {
     bool ok = false;
     if (m_tackle_in_reach(p, o, bx0, by0)) {               // rare: most tackles are nowhere near the ball
@@ -314,7 +315,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   const uint32_t hmask = hballot(hold_moved, half) & ((1u << S2D_MATCH_GOALIE_LEFT) | (1u << S2D_MATCH_GOALIE_RIGHT));
   const int hold_move = hmask ? __ffs((int)hmask) - 1 : -1;
   if (caught_by >= 0 && l == caught_by) cnt.kicks++;
-  if (caught_by >= 0 || hold_move >= 0) { kicked = false; kx = 0.0f; ky = 0.0f; }
+  if (caught_by >= 0 || hold_move >= 0) { kicked = false; by_kick = false; kx = 0.0f; ky = 0.0f; }
   // ---- 2. ball: impulses summed in player order
   const uint32_t kmask = hballot(kicked, half) & 0x3FFFFFu;
   const bool any_kick = kmask != 0u;
@@ -328,6 +329,18 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
     }
   }
   if (any_kick) g.last_touch = side_of(last_kicker);
+  // free-kick fault / back-pass bookkeeping (oracle: match_step, same decisions from the same masks)
+  const int taker0 = g.taker;
+  const uint32_t cmask2 = hballot(by_kick, half) & 0x3FFFFFu;                  // Kick-command kickers
+  const uint32_t taker_bit = taker0 > 0 ? (1u << (taker0 - 1)) : 0u;
+  const bool other_touch = (kmask & ~taker_bit) != 0u;
+  const bool fk_fault = p.free_kick_faults && mode0 == S2D_GM_PLAY_ON && taker0 != 0 && any_kick && !other_touch;
+  if (any_kick) {
+    if (is_setplay(mode0)) g.taker = last_kicker + 1;        // this kick puts the ball into play
+    else if (other_touch) g.taker = 0;
+    const int last_kick_cmd = cmask2 ? 31 - __clz(cmask2) : -1;
+    g.last_kicker = (last_kick_cmd == last_kicker) ? last_kick_cmd + 1 : 0;
+  }
   const bool ball_live = !is_setplay(mode0) || any_kick;
   if (caught_by >= 0) {                                   // held: the ball rests where it was caught
     g.last_touch = side_of(caught_by);
@@ -400,6 +413,8 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
     coll_touch_side = side_of(touch_player);
     g.last_touch = coll_touch_side;
+    if (touch_player + 1 != g.taker) g.taker = 0;
+    if (touch_player + 1 != g.last_kicker) g.last_kicker = 0;
   }
   // ---- 4. set play: opponents keep their distance
   {
@@ -437,7 +452,11 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
         const int ks = other_side(side0);
         restart_form = true; form_side = ks;
         g.mode = S2D_GM_KICK_OFF; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        g.taker = 0; g.last_kicker = 0;
       }
+    } else if (mode0 == S2D_GM_BEFORE_KICK_OFF) {          // nobody plays the ball, players may Move
+      g.timer += 1;
+      if (g.timer >= p.kick_off_wait) { g.mode = S2D_GM_KICK_OFF; g.timer = 0; }
     } else if (is_setplay(mode0)) {
       if (any_kick) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; }
       else { g.timer += 1; if (g.timer > p.drop_ball_time) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; } }
@@ -462,10 +481,24 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
       if (caught_by >= 0) {                                // goalie holds the ball
         const int gs = side_of(caught_by);
         const bool in_area = fabsf(by) <= p.pen_half_w && (gs == SIDE_LEFT ? bx <= -p.pen_x : bx >= p.pen_x);
-        // inside the own penalty area: free kick for the goalie's side; outside: catch fault
-        place_ball = true; pbx = bx; pby = by;
-        g.mode = S2D_GM_FREE_KICK; g.mode_side = in_area ? gs : other_side(gs); g.timer = 0; g.offside = 0;
-        if (in_area) { g.holder = caught_by + 1; g.moves = p.goalie_max_moves; }
+        // back pass: the goalie catches a ball a team-mate kicked to him -> indirect free kick for the other side from the
+        // nearer front corner of the penalty area; otherwise, inside the own penalty area: free kick for the goalie's side;
+        // outside: catch fault
+        const int lk = g.last_kicker - 1;
+        const bool back_pass = p.back_passes && in_area && lk >= 0 && lk != caught_by && side_of(lk) == gs;
+        place_ball = true; g.timer = 0; g.offside = 0; g.taker = 0; g.last_kicker = 0;
+        if (back_pass) {
+          pbx = gs == SIDE_LEFT ? -p.pen_x : p.pen_x; pby = by > 0.0f ? p.pen_half_w : -p.pen_half_w;
+          g.mode = S2D_GM_BACK_PASS; g.mode_side = other_side(gs);
+        } else {
+          pbx = bx; pby = by;
+          g.mode = S2D_GM_FREE_KICK; g.mode_side = in_area ? gs : other_side(gs);
+          if (in_area) { g.holder = caught_by + 1; g.moves = p.goalie_max_moves; }
+        }
+      } else if (fk_fault) {                                // the taker touched the ball twice
+        place_ball = true; pbx = clampf(bx, -p.half_l, p.half_l); pby = clampf(by, -p.half_w, p.half_w);
+        g.mode = S2D_GM_FREE_KICK_FAULT; g.mode_side = other_side(side_of(taker0 - 1)); g.timer = 0; g.offside = 0;
+        g.taker = 0; g.last_kicker = 0;
       } else if (bx > p.half_l && fabsf(by) < p.goal_half_width) {
         g.score_l += 1; g.reward = 1.0f; if (is_ball) cnt.goals_l++;
         g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
@@ -512,8 +545,9 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
       int k = g.cycle / p.half_time_cycles;
       int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
       recover_half = true; restart_form = true; form_side = ks; place_ball = false;
-      g.mode = S2D_GM_KICK_OFF; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+      g.mode = p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
     }
+    if (place_ball || restart_form) { g.taker = 0; g.last_kicker = 0; }   // every restart ends the double-touch / back-pass bookkeeping
     if (g.mode != S2D_GM_FREE_KICK) { g.holder = 0; g.moves = 0; }   // nobody holds the ball any more
   }
   // resolve the offside spot (uniform shuffle, then apply)
@@ -596,6 +630,7 @@ S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g) {
   g.timer = q.env[ME_TIMER * q.env_stride + e]; g.offside = q.env[ME_OFFSIDE * q.env_stride + e];
   g.reward = 0.0f; g.done = 0; g.nearest_l = q.env[ME_NEAREST_L * q.env_stride + e]; g.nearest_r = q.env[ME_NEAREST_R * q.env_stride + e];
   g.holder = q.env[ME_HOLDER * q.env_stride + e]; g.moves = q.env[ME_MOVES * q.env_stride + e];
+  g.taker = q.env[ME_TAKER * q.env_stride + e]; g.last_kicker = q.env[ME_LAST_KICKER * q.env_stride + e];
 }
 S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGame& g) {
   if (l < SLOTS) {
@@ -615,6 +650,7 @@ S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGam
     q.env[ME_TIMER * q.env_stride + e] = g.timer; q.env[ME_OFFSIDE * q.env_stride + e] = g.offside;
     q.env[ME_NEAREST_L * q.env_stride + e] = g.nearest_l; q.env[ME_NEAREST_R * q.env_stride + e] = g.nearest_r;
     q.env[ME_HOLDER * q.env_stride + e] = g.holder; q.env[ME_MOVES * q.env_stride + e] = g.moves;
+    q.env[ME_TAKER * q.env_stride + e] = g.taker; q.env[ME_LAST_KICKER * q.env_stride + e] = g.last_kicker;
     q.reward[e] = g.reward; q.done[e] = (uint8_t)g.done;
   }
 }
@@ -863,6 +899,7 @@ S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
   m.catch_ban_cycle = 5; m.catchable_area_l = 1.2; m.catch_area_w = 1.0; m.catch_probability = 1.0;
   m.max_catch_angle = 90.0; m.min_catch_angle = -90.0; m.penalty_area_length = 16.5; m.penalty_area_half_width = 20.16;
   m.goalie_max_moves = 2; m.after_goal_wait = 50;
+  m.kick_off_wait = 0; m.back_passes = 1; m.free_kick_faults = 1;
   c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
   for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) c->player_types[t] = m_default_type(c->sp, m);   // homogeneous
 }
@@ -877,7 +914,8 @@ S2D_API int s2d_match_validate_config(const S2DMatchConfig* c) {
   if (c->mp.half_time_cycles < 1 || c->mp.nr_normal_halfs < 1) return mfail(S2D_EINVAL, "half_time_cycles and nr_normal_halfs must be >= 1");
   if (c->mp.tackle_cycles < 0 || c->mp.drop_ball_time < 0) return mfail(S2D_EINVAL, "tackle_cycles / drop_ball_time must be >= 0");
   if (c->env_id_offset < 0) return mfail(S2D_EINVAL, "env_id_offset must be >= 0");
-  if (c->mp.goalie_max_moves < 0 || c->mp.after_goal_wait < 0) return mfail(S2D_EINVAL, "goalie_max_moves / after_goal_wait must be >= 0");
+  if (c->mp.goalie_max_moves < 0 || c->mp.after_goal_wait < 0 || c->mp.kick_off_wait < 0)
+    return mfail(S2D_EINVAL, "goalie_max_moves / after_goal_wait / kick_off_wait must be >= 0");
   if (c->mp.catch_ban_cycle < 0 || !(c->mp.catch_area_w > 0) || !(c->mp.catchable_area_l > 0))
     return mfail(S2D_EINVAL, "catch_ban_cycle must be >= 0, catch_area_w and catchable_area_l > 0");
   for (int i = 0; i < S2D_MATCH_PLAYERS; ++i)
@@ -932,6 +970,7 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   p.tackle_cycles = m.tackle_cycles; p.half_time_cycles = m.half_time_cycles;
   p.nr_normal_halfs = m.nr_normal_halfs; p.drop_ball_time = m.drop_ball_time; p.use_offside = m.use_offside;
   p.catch_ban_cycle = m.catch_ban_cycle; p.goalie_max_moves = m.goalie_max_moves; p.after_goal_wait = m.after_goal_wait;
+  p.kick_off_wait = m.kick_off_wait; p.back_passes = m.back_passes; p.free_kick_faults = m.free_kick_faults;
   p.auto_reset = c.auto_reset; p.noise = c.noise;
   p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
   p.gid_lo = (uint32_t)(uint64_t)c.env_id_offset; p.gid_hi = (uint32_t)((uint64_t)c.env_id_offset >> 32);
@@ -1020,6 +1059,7 @@ S2D_API int s2d_match_create(const S2DMatchConfig* cfg, int64_t n_envs, int devi
   b.score_left = env + ME_SCORE_L * es; b.score_right = env + ME_SCORE_R * es; b.last_touch_side = env + ME_LAST_TOUCH * es;
   b.setplay_timer = env + ME_TIMER * es; b.offside_mask = env + ME_OFFSIDE * es;
   b.ball_holder = env + ME_HOLDER * es; b.goalie_moves = env + ME_MOVES * es;
+  b.set_play_taker = env + ME_TAKER * es; b.last_kicker = env + ME_LAST_KICKER * es;
   b.reward_left = reinterpret_cast<float*>(h->arena + L.reward);
   b.done = reinterpret_cast<uint8_t*>(h->arena + L.done);
   b.nearest_left = env + ME_NEAREST_L * es; b.nearest_right = env + ME_NEAREST_R * es;
@@ -1060,10 +1100,10 @@ S2D_API int s2d_match_buffer_offsets(S2DMatchHandle h, int64_t* offsets, int n_o
   const S2DMatchBuffers& b = h->buf;
   const void* ptrs[] = {b.x, b.y, b.vx, b.vy, b.body, b.stamina, b.effort, b.recovery, b.stamina_capacity, b.tackle_cycles,
                         b.catch_ban, b.cycle, b.mode, b.mode_side, b.score_left, b.score_right, b.last_touch_side, b.setplay_timer,
-                        b.offside_mask, b.ball_holder, b.goalie_moves, b.reward_left, b.done, b.nearest_left, b.nearest_right,
+                        b.offside_mask, b.ball_holder, b.goalie_moves, b.set_play_taker, b.last_kicker, b.reward_left, b.done, b.nearest_left, b.nearest_right,
                         b.stats};
   const int count = 1 + (int)(sizeof ptrs / sizeof ptrs[0]);
-  if (n_offsets < count) return mfail(S2D_EINVAL, "offsets array too small (need 27)");
+  if (n_offsets < count) return mfail(S2D_EINVAL, "offsets array too small (need 29)");
   offsets[0] = (int64_t)h->arena_bytes;
   for (int k = 1; k < count; ++k) offsets[k] = (int64_t)(static_cast<const char*>(ptrs[k - 1]) - h->arena);
   return S2D_OK;

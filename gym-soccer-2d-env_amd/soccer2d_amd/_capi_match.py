@@ -7,7 +7,9 @@ MATCH_PLAYERS, MATCH_SLOTS, MATCH_BALL, MATCH_OBJ_WORDS = 22, 24, 22, 5
 MCMD_NONE, MCMD_DASH, MCMD_TURN, MCMD_KICK, MCMD_TACKLE, MCMD_CATCH, MCMD_MOVE = 0, 1, 2, 3, 4, 5, 6
 MATCH_PLAYER_TYPES, GOALIE_LEFT, GOALIE_RIGHT = 18, 0, 11
 GM_TIME_OVER, GM_PLAY_ON, GM_KICK_OFF, GM_KICK_IN, GM_FREE_KICK, GM_CORNER_KICK, GM_GOAL_KICK, GM_AFTER_GOAL, GM_OFF_SIDE = 1, 2, 3, 4, 5, 6, 7, 8, 9
-GM_NAMES = {1: 'TimeOver', 2: 'PlayOn', 3: 'KickOff_', 4: 'KickIn_', 5: 'FreeKick_', 6: 'CornerKick_', 7: 'GoalKick_', 8: 'AfterGoal_', 9: 'OffSide_'}
+GM_BEFORE_KICK_OFF, GM_BACK_PASS, GM_FREE_KICK_FAULT = 0, 18, 19          # idl/service.proto:268, 286-287
+GM_NAMES = {0: 'BeforeKickOff', 1: 'TimeOver', 2: 'PlayOn', 3: 'KickOff_', 4: 'KickIn_', 5: 'FreeKick_', 6: 'CornerKick_', 7: 'GoalKick_',
+            8: 'AfterGoal_', 9: 'OffSide_', 18: 'BackPass_', 19: 'FreeKickFault_'}
 
 
 class S2DMatchParams(C.Structure):
@@ -19,7 +21,8 @@ class S2DMatchParams(C.Structure):
             'tackle_cycles', 'half_time_cycles', 'nr_normal_halfs', 'drop_ball_time', 'use_offside', 'catch_ban_cycle')] + [
                 (n, C.c_double) for n in ('catchable_area_l', 'catch_area_w', 'catch_probability', 'max_catch_angle',
                                           'min_catch_angle', 'penalty_area_length', 'penalty_area_half_width')] + [
-                    ('goalie_max_moves', C.c_int32), ('after_goal_wait', C.c_int32)]
+                    ('goalie_max_moves', C.c_int32), ('after_goal_wait', C.c_int32), ('kick_off_wait', C.c_int32),
+                    ('back_passes', C.c_int32), ('free_kick_faults', C.c_int32), ('reserved_mp', C.c_int32)]
 
 
 PLAYER_TYPE_FIELDS = ('player_speed_max', 'stamina_inc_max', 'player_decay', 'inertia_moment', 'dash_power_rate',
@@ -57,7 +60,8 @@ MATCH_BUFFER_FIELDS = tuple(
     [(n, _F, 'float32', (MATCH_SLOTS,)) for n in ('x', 'y', 'vx', 'vy', 'body', 'stamina', 'effort', 'recovery', 'stamina_capacity')]
     + [('tackle_cycles', _I, 'int32', (MATCH_SLOTS,)), ('catch_ban', _I, 'int32', (MATCH_SLOTS,))]
     + [(n, _I, 'int32', ()) for n in ('cycle', 'mode', 'mode_side', 'score_left', 'score_right', 'last_touch_side',
-                                      'setplay_timer', 'offside_mask', 'ball_holder', 'goalie_moves')]
+                                      'setplay_timer', 'offside_mask', 'ball_holder', 'goalie_moves', 'set_play_taker',
+                                      'last_kicker')]
     + [('reward_left', _F, 'float32', ()), ('done', _U8, 'uint8', ()),
        ('nearest_left', _I, 'int32', ()), ('nearest_right', _I, 'int32', ()),
        ('stats', C.POINTER(C.c_ulonglong), 'int64', None)])

@@ -86,8 +86,8 @@ class MatchEngine:
                                            self._stream(), C.byref(h))
         _capi.check(self.lib, rc, 's2d_match_create')
         self._h = h
-        off = (C.c_int64 * 27)()
-        _capi.check(self.lib, self.lib.s2d_match_buffer_offsets(self._h, off, 27), 's2d_match_buffer_offsets')
+        off = (C.c_int64 * 29)()
+        _capi.check(self.lib, self.lib.s2d_match_buffer_offsets(self._h, off, 29), 's2d_match_buffer_offsets')
         n = self.num_envs
         for k, (name, _ct, dt, trail) in enumerate(M.MATCH_BUFFER_FIELDS):
             o = off[k + 1]

@@ -37,8 +37,9 @@ enum { S2D_MCMD_NONE = 0, S2D_MCMD_DASH = 1, S2D_MCMD_TURN = 2, S2D_MCMD_KICK = 
        S2D_MCMD_CATCH = 5, S2D_MCMD_MOVE = 6 };
 /* GameModeType values used (idl/service.proto:267-301); the taking side is in mode_side */
 enum {
-  S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4, S2D_GM_FREE_KICK = 5,
-  S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_AFTER_GOAL = 8, S2D_GM_OFF_SIDE = 9
+  S2D_GM_BEFORE_KICK_OFF = 0, S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4,
+  S2D_GM_FREE_KICK = 5, S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_AFTER_GOAL = 8, S2D_GM_OFF_SIDE = 9,
+  S2D_GM_BACK_PASS = 18, S2D_GM_FREE_KICK_FAULT = 19
 };
 
 /* ServerParam fields the match needs beyond S2DServerParams (same names as idl/service.proto:
@@ -57,6 +58,14 @@ typedef struct S2DMatchParams {
   int32_t goalie_max_moves;               /* 2: Move commands a goalie may issue while he holds a caught ball */
   int32_t after_goal_wait;                /* 50: cycles of AfterGoal_ (mode side = the scorer) between a goal and the
                                              kick-off formation; 0 = kick-off at once */
+  int32_t kick_off_wait;                  /* 0: cycles of BeforeKickOff (idl/service.proto:268) before the kick-off of each
+                                             half -- nobody may play the ball, players may Move inside their own half
+                                             (rcssserver's auto_mode waits kick_off_wait = 100); 0 = KickOff_ at once */
+  int32_t back_passes;                    /* 1: a goalie catching a ball a team-mate kicked concedes an indirect free kick
+                                             (BackPass_, idl/service.proto:286; ServerParam.back_passes :1579) */
+  int32_t free_kick_faults;               /* 1: the taker of a set play may not play the ball twice in a row
+                                             (FreeKickFault_, :287; ServerParam.free_kick_faults :1578) */
+  int32_t reserved_mp;
 } S2DMatchParams;
 
 /* PlayerType (idl/service.proto:1697-1732): the members that enter the dynamics.  Type 0 is the
@@ -107,6 +116,8 @@ typedef struct S2DMatchBuffers {
   int32_t *cycle, *mode, *mode_side, *score_left, *score_right;
   int32_t *last_touch_side, *setplay_timer, *offside_mask;     /* bit i = player i flagged */
   int32_t *ball_holder, *goalie_moves;  /* 1 + index of the goalie holding a caught ball (0 = nobody), his remaining moves */
+  int32_t *set_play_taker, *last_kicker;   /* 1 + index (0 = nobody): who put the ball into play from the last set play and has
+                                            not been followed by another touch; who last moved it with a Kick command */
   float *reward_left;      /* [N] +1 left goal, -1 right goal this cycle */
   uint8_t *done;           /* [N] 1 when the match reached TimeOver this cycle */
   int32_t *nearest_left, *nearest_right;              /* [N] index of the player closest to the ball, per team */

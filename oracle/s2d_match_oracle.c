@@ -39,6 +39,7 @@ typedef struct MP {
   REAL goal_half_width, offside_area2, free_kick_distance, inv_speed_decay;
   int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle, goalie_max_moves;
   int after_goal_wait;
+  int kick_off_wait, back_passes, free_kick_faults;
   REAL catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
   /* heterogeneous players: the parameters of every player slot's PlayerType (idl/service.proto:1697-1732) */
@@ -91,6 +92,7 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   p->nr_normal_halfs = m->nr_normal_halfs; p->drop_ball_time = m->drop_ball_time; p->use_offside = m->use_offside;
   p->catch_ban_cycle = m->catch_ban_cycle; p->goalie_max_moves = m->goalie_max_moves;
   p->after_goal_wait = m->after_goal_wait;
+  p->kick_off_wait = m->kick_off_wait; p->back_passes = m->back_passes; p->free_kick_faults = m->free_kick_faults;
   p->catch_half_w = (REAL)(m->catch_area_w * 0.5); p->catch_probability = (REAL)m->catch_probability;
   p->max_catch_angle = (REAL)m->max_catch_angle; p->min_catch_angle = (REAL)m->min_catch_angle;
   p->pen_x = (REAL)(s->pitch_half_length - m->penalty_area_length); p->pen_half_w = (REAL)m->penalty_area_half_width;
@@ -118,6 +120,10 @@ typedef struct Match {
   Obj o[NOBJ];
   int32_t cycle, mode, mode_side, score_left, score_right, last_touch_side, setplay_timer, offside_mask;
   int32_t ball_holder, goalie_moves;    /* 1 + index of the goalie holding a caught ball (0 = nobody), remaining moves */
+  int32_t set_play_taker;               /* 1 + index of the player who put the ball into play from the last set play and whom
+                                           nobody else has touched the ball after (0 = nobody): a second touch is a free-kick fault */
+  int32_t last_kicker;                  /* 1 + index of the last player who moved the ball with a Kick command and whom no other
+                                           touch (tackle, collision) followed (0 = nobody): the back-pass rule */
   REAL reward_left; uint8_t done; int32_t nearest_left, nearest_right;
 } Match;
 
@@ -152,7 +158,7 @@ static void match_reset(const MP *p, Match *m) {
   memset(m, 0, sizeof *m);
   recover_all(p, m, 1);
   place_formation(m, SIDE_LEFT);
-  m->mode = S2D_GM_KICK_OFF; m->mode_side = SIDE_LEFT;
+  m->mode = p->kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF; m->mode_side = SIDE_LEFT;
   m->nearest_left = 10; m->nearest_right = 20;
 }
 
@@ -278,6 +284,7 @@ static void restart(Match *m, int mode, int side, REAL bx, REAL by) {
   Obj *b = &m->o[BALL];
   b->x = bx; b->y = by; b->vx = R(0.0); b->vy = R(0.0);
   m->mode = mode; m->mode_side = side; m->setplay_timer = 0; m->offside_mask = 0;
+  m->set_play_taker = 0; m->last_kicker = 0;
 }
 
 typedef struct MatchStats { unsigned long long v[8]; } MatchStats;
@@ -293,21 +300,21 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
 
   /* 1. commands */
   REAL ax[NP], ay[NP], kx[NP], ky[NP];
-  int kicked[NP];
+  int kicked[NP], by_kick[NP];           /* by_kick: the impulse came from a Kick command (not a tackle) */
   int caught_by = -1, hold_move = -1;
   uint32_t nzb[4] = {0, 0, 0, 0};
   if (p->noise) draw(p->seed, gid, cyc, ST_NOISE, BALL, nzb);
   for (int i = 0; i < NP; ++i) {
     Obj *o = &m->o[i];
     const PT *t = &p->pt[i];
-    ax[i] = ay[i] = kx[i] = ky[i] = R(0.0); kicked[i] = 0;
+    ax[i] = ay[i] = kx[i] = ky[i] = R(0.0); kicked[i] = 0; by_kick[i] = 0;
     int cmd = (int)act[i * 3 + 0];
     REAL a = (REAL)act[i * 3 + 1], bb = (REAL)act[i * 3 + 2];
     if (o->tackle > 0 || mode0 == S2D_GM_TIME_OVER) cmd = S2D_MCMD_NONE;
     uint32_t nz[4] = {0, 0, 0, 0}, nk[4] = {0, 0, 0, 0};
     if (p->noise) { draw(p->seed, gid, cyc, ST_NOISE, (uint32_t)i, nz); draw(p->seed, gid, cyc, ST_NOISE, 32u + (uint32_t)i, nk); }
     /* set play: only the taking side plays the ball; after a goal nobody does */
-    int may_touch = !is_setplay(mode0) || (side_of(i) == side0 && mode0 != S2D_GM_AFTER_GOAL);
+    int may_touch = !is_setplay(mode0) || (side_of(i) == side0 && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_BEFORE_KICK_OFF);
     if (cmd == S2D_MCMD_DASH) m_dash(p, t, o, a, bb, &ax[i], &ay[i]);
     else if (cmd == S2D_MCMD_TURN) m_turn(p, t, o, a, rnd_u01(nz[2]));
     else if (cmd == S2D_MCMD_CATCH) {
@@ -323,7 +330,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
        * half; while holding a caught ball, goalie_max_moves times inside the own penalty area */
       REAL sgn = side_of(i) == SIDE_LEFT ? R(1.0) : R(-1.0);
       int holds = mode0 == S2D_GM_FREE_KICK && m->ball_holder == i + 1 && m->goalie_moves > 0;
-      if (mode0 == S2D_GM_KICK_OFF || mode0 == S2D_GM_AFTER_GOAL || holds) {
+      if (mode0 == S2D_GM_KICK_OFF || mode0 == S2D_GM_AFTER_GOAL || mode0 == S2D_GM_BEFORE_KICK_OFF || holds) {
         REAL tx = clampr(a, -p->half_l, holds ? -p->pen_x : R(0.0));
         REAL ty = holds ? clampr(bb, -p->pen_half_w, p->pen_half_w) : clampr(bb, -p->half_w, p->half_w);
         o->x = sgn * tx; o->y = sgn * ty; o->vx = R(0.0); o->vy = R(0.0);
@@ -331,7 +338,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
       }
     } else if (cmd == S2D_MCMD_KICK) {
       int ok = m_kick(p, t, o, b, a, bb, rnd_u01(nk[0]), rnd_u01(nk[1]), &kx[i], &ky[i]);
-      if (ok && may_touch) { kicked[i] = 1; st->v[4]++; } else { kx[i] = ky[i] = R(0.0); }
+      if (ok && may_touch) { kicked[i] = 1; by_kick[i] = 1; st->v[4]++; } else { kx[i] = ky[i] = R(0.0); }
     } else if (cmd == S2D_MCMD_TACKLE) {
       uint32_t w[4];
       draw(p->seed, gid, cyc, ST_TACKLE, (uint32_t)i, w);
@@ -353,12 +360,25 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   }
   if (caught_by >= 0) st->v[4]++;
   if (caught_by >= 0 || hold_move >= 0)                    /* a catch / a move with the ball wins the cycle: kicks are dropped */
-    for (int i = 0; i < NP; ++i) { kicked[i] = 0; kx[i] = ky[i] = R(0.0); }
+    for (int i = 0; i < NP; ++i) { kicked[i] = 0; by_kick[i] = 0; kx[i] = ky[i] = R(0.0); }
   /* 2. ball: accelerations summed in player order */
   REAL bax = R(0.0), bay = R(0.0);
-  int any_kick = 0, last_kicker = -1;
-  for (int i = 0; i < NP; ++i) if (kicked[i]) { bax += kx[i]; bay += ky[i]; any_kick = 1; last_kicker = i; }
+  int any_kick = 0, last_kicker = -1, last_kick_cmd = -1, other_touch = 0;
+  const int taker0 = m->set_play_taker;                   /* who may not touch the ball twice in a row */
+  for (int i = 0; i < NP; ++i) if (kicked[i]) {
+    bax += kx[i]; bay += ky[i]; any_kick = 1; last_kicker = i;
+    if (by_kick[i]) last_kick_cmd = i;
+    if (i + 1 != taker0) other_touch = 1;
+  }
   if (any_kick) m->last_touch_side = side_of(last_kicker);
+  /* free-kick fault (FreeKickFault_, idl/service.proto:287): the taker of a set play plays the ball again before anybody else */
+  const int fk_fault = p->free_kick_faults && mode0 == S2D_GM_PLAY_ON && taker0 != 0 && any_kick && !other_touch;
+  if (any_kick) {
+    if (is_setplay(mode0)) m->set_play_taker = last_kicker + 1;    /* this kick puts the ball into play */
+    else if (other_touch) m->set_play_taker = 0;
+    /* back-pass bookkeeping: the last Kick command counts; a tackle touch ends it */
+    m->last_kicker = (last_kick_cmd == last_kicker) ? last_kick_cmd + 1 : 0;
+  }
   const int ball_live = !is_setplay(mode0) || any_kick;
   if (caught_by >= 0) {                                   /* held: the ball rests where it was caught */
     b->vx = R(0.0); b->vy = R(0.0); m->last_touch_side = side_of(caught_by);
@@ -412,6 +432,8 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
     coll_touch_side = side_of(touch_player);
     m->last_touch_side = coll_touch_side;
+    if (touch_player + 1 != m->set_play_taker) m->set_play_taker = 0;
+    if (touch_player + 1 != m->last_kicker) m->last_kicker = 0;
   }
   /* 4. set play: opponents keep free_kick_distance from the ball (nobody has to after a goal) */
   if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL) {
@@ -435,6 +457,9 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
         place_formation(m, ks);
         restart(m, S2D_GM_KICK_OFF, ks, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
       }
+    } else if (mode0 == S2D_GM_BEFORE_KICK_OFF) {        /* BeforeKickOff (idl/service.proto:268): nobody plays the ball, players may Move */
+      m->setplay_timer += 1;
+      if (m->setplay_timer >= p->kick_off_wait) { m->mode = S2D_GM_KICK_OFF; m->setplay_timer = 0; }
     } else if (is_setplay(mode0)) {
       if (any_kick) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; }
       else { m->setplay_timer += 1; if (m->setplay_timer > p->drop_ball_time) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; } }
@@ -469,9 +494,16 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
       if (caught_by >= 0) {                                                  /* goalie holds the ball */
         int gs = side_of(caught_by);
         int in_area = R(fabs)(by) <= p->pen_half_w && (gs == SIDE_LEFT ? bx <= -p->pen_x : bx >= p->pen_x);
-        /* inside the own penalty area: free kick for the goalie's side; outside: catch fault */
-        restart(m, S2D_GM_FREE_KICK, in_area ? gs : other_side(gs), bx, by);
-        if (in_area) { m->ball_holder = caught_by + 1; m->goalie_moves = p->goalie_max_moves; }
+        /* back pass (BackPass_, idl/service.proto:286): the goalie catches a ball a team-mate kicked to him -- indirect free
+         * kick for the other side from the nearer front corner of the penalty area */
+        const int lk = m->last_kicker - 1;
+        const int back_pass = p->back_passes && in_area && lk >= 0 && lk != caught_by && side_of(lk) == gs;
+        /* otherwise, inside the own penalty area: free kick for the goalie's side; outside: catch fault */
+        if (back_pass) restart(m, S2D_GM_BACK_PASS, other_side(gs), gs == SIDE_LEFT ? -p->pen_x : p->pen_x, by > R(0.0) ? p->pen_half_w : -p->pen_half_w);
+        else restart(m, S2D_GM_FREE_KICK, in_area ? gs : other_side(gs), bx, by);
+        if (in_area && !back_pass) { m->ball_holder = caught_by + 1; m->goalie_moves = p->goalie_max_moves; }
+      } else if (fk_fault) {                                                 /* the taker touched the ball twice */
+        restart(m, S2D_GM_FREE_KICK_FAULT, other_side(side_of(taker0 - 1)), clampr(bx, -p->half_l, p->half_l), clampr(by, -p->half_w, p->half_w));
       } else if (bx > p->half_l && R(fabs)(by) < p->goal_half_width) {       /* goal for the left team */
         m->score_left += 1; m->reward_left = R(1.0); st->v[1]++;
         if (p->after_goal_wait > 0) restart(m, S2D_GM_AFTER_GOAL, SIDE_LEFT, bx, by);   /* the ball rests in the net */
@@ -513,7 +545,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
       int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
       recover_all(p, m, 0);
       place_formation(m, ks);
-      restart(m, S2D_GM_KICK_OFF, ks, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
+      restart(m, p->kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, ks, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
     }
     if (m->mode != S2D_GM_FREE_KICK) { m->ball_holder = 0; m->goalie_moves = 0; }   /* nobody holds the ball any more */
   }
@@ -620,6 +652,7 @@ API int s2dmo_get(const S2DMOEngine *h, int field, double *out) {
         case 16: v = m->setplay_timer; break; case 17: v = m->offside_mask; break; case 18: v = m->reward_left; break;
         case 19: v = m->done; break; case 20: v = m->nearest_left; break; case 21: v = m->nearest_right; break;
         case 23: v = m->ball_holder; break; case 24: v = m->goalie_moves; break;
+        case 25: v = m->set_play_taker; break; case 26: v = m->last_kicker; break;
         default: return -1;
       }
       out[e] = v;
@@ -634,6 +667,11 @@ API int s2dmo_set_obj(S2DMOEngine *h, int64_t e, int slot, const double *v10) {
   o->x = (REAL)v10[0]; o->y = (REAL)v10[1]; o->vx = (REAL)v10[2]; o->vy = (REAL)v10[3]; o->body = (REAL)v10[4];
   o->stamina = (REAL)v10[5]; o->effort = (REAL)v10[6]; o->recovery = (REAL)v10[7]; o->capacity = (REAL)v10[8];
   o->tackle = (int32_t)v10[9]; o->catch_ban = 0;
+  return 0;
+}
+API int s2dmo_set_touch(S2DMOEngine *h, int64_t e, int set_play_taker, int last_kicker) {
+  if (e < 0 || e >= h->n) return -1;
+  h->m[e].set_play_taker = set_play_taker; h->m[e].last_kicker = last_kicker;
   return 0;
 }
 API int s2dmo_set_game(S2DMOEngine *h, int64_t e, const int32_t *v8) {

@@ -15,7 +15,8 @@ MATCH_DEFAULTS = dict(
     goal_width=14.02, offside_active_area_size=2.5, free_kick_distance=9.15,
     tackle_cycles=10, half_time_cycles=3000, nr_normal_halfs=2, drop_ball_time=100, use_offside=1, catch_ban_cycle=5,
     catchable_area_l=1.2, catch_area_w=1.0, catch_probability=1.0, max_catch_angle=90.0, min_catch_angle=-90.0,
-    penalty_area_length=16.5, penalty_area_half_width=20.16, goalie_max_moves=2, after_goal_wait=50)
+    penalty_area_length=16.5, penalty_area_half_width=20.16, goalie_max_moves=2, after_goal_wait=50,
+    kick_off_wait=0, back_passes=1, free_kick_faults=1)
 
 
 def default_player_type(sp, mp):
@@ -29,7 +30,7 @@ def default_player_type(sp, mp):
 
 OBJ_FIELDS = ('x', 'y', 'vx', 'vy', 'body', 'stamina', 'effort', 'recovery', 'stamina_capacity', 'tackle_cycles')
 EXTRA_OBJ_FIELDS = {'catch_ban': 22}      # s2dmo_get field ids beyond the contiguous block
-EXTRA_ENV_FIELDS = {'ball_holder': 23, 'goalie_moves': 24}
+EXTRA_ENV_FIELDS = {'ball_holder': 23, 'goalie_moves': 24, 'set_play_taker': 25, 'last_kicker': 26}
 ENV_FIELDS = ('cycle', 'mode', 'mode_side', 'score_left', 'score_right', 'last_touch_side', 'setplay_timer',
               'offside_mask', 'reward_left', 'done', 'nearest_left', 'nearest_right')
 
@@ -83,6 +84,7 @@ def lib():
         L.s2dmo_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]; L.s2dmo_get.restype = C.c_int
         L.s2dmo_set_obj.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]; L.s2dmo_set_obj.restype = C.c_int
         L.s2dmo_set_game.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]; L.s2dmo_set_game.restype = C.c_int
+        L.s2dmo_set_touch.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]; L.s2dmo_set_touch.restype = C.c_int
         L.s2dmo_stats.argtypes = [C.c_void_p]; L.s2dmo_stats.restype = C.POINTER(C.c_ulonglong)
         L.s2dmo_random_actions.argtypes = [C.c_void_p, C.c_void_p]; L.s2dmo_random_actions.restype = None
         L.s2dmo_relative.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; L.s2dmo_relative.restype = None
@@ -156,6 +158,11 @@ class MatchOracle:
         assert self.L.s2dmo_set_obj(self.h, e, slot, a.ctypes.data_as(C.POINTER(C.c_double))) == 0
 
     def set_game(self, e, **kw):
+        touch = {k: kw.pop(k) for k in ('set_play_taker', 'last_kicker') if k in kw}
+        if touch:
+            cur_t = [int(self.get('set_play_taker')[e]), int(self.get('last_kicker')[e])]
+            cur_t[0] = int(touch.get('set_play_taker', cur_t[0])); cur_t[1] = int(touch.get('last_kicker', cur_t[1]))
+            assert self.L.s2dmo_set_touch(self.h, e, cur_t[0], cur_t[1]) == 0
         names = ENV_FIELDS[:8]
         cur = [int(self.get(f)[e]) for f in names]
         for k, v in kw.items():

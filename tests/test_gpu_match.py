@@ -32,7 +32,7 @@ def _bits(a):
 
 def assert_match_same(eng, orc, tag):
     torch.cuda.synchronize()
-    for f in MO.OBJ_FIELDS + ('catch_ban',) + MO.ENV_FIELDS + ('ball_holder', 'goalie_moves'):
+    for f in MO.OBJ_FIELDS + ('catch_ban',) + MO.ENV_FIELDS + ('ball_holder', 'goalie_moves', 'set_play_taker', 'last_kicker'):
         g = getattr(eng, f).cpu().numpy()
         c = orc.get(f)
         if not np.array_equal(_bits(g), _bits(c)):
@@ -61,6 +61,8 @@ def test_match_reset_parity(n):
     ('noise', dict(half_time_cycles=120, noise=True)),
     ('no-offside-no-autoreset', dict(half_time_cycles=100, use_offside=0, auto_reset=False)),
     ('short-drop', dict(half_time_cycles=200, drop_ball_time=3, tackle_cycles=2)),
+    ('before-kick-off', dict(half_time_cycles=110, kick_off_wait=7, drop_ball_time=20)),
+    ('no-fault-rules', dict(half_time_cycles=130, back_passes=0, free_kick_faults=0)),
 ])
 def test_match_step_parity_random_policy(name, kw):
     """In-kernel Philox policy, per-step launches, 330 cycles (kick-offs, restarts, half time,
@@ -340,3 +342,41 @@ def test_match_random_parameters_parity(seed):
         if t % 20 == 19:
             assert_match_same(eng, orc, f'mcfg{seed} t={t}')
     assert list(eng.stats.cpu().numpy()) == list(orc.stats())
+
+
+def test_match_round2_rules_on_device():
+    """BeforeKickOff, free-kick fault and back pass (tests/test_match_oracle.py holds the hand-built scenarios): the same scripted
+    sequences on the device, every word equal to the oracle after every cycle, and the three modes do occur."""
+    from soccer2d_amd._capi_match import GM_BACK_PASS, GM_BEFORE_KICK_OFF, GM_FREE_KICK_FAULT, MCMD_CATCH, MCMD_DASH, MCMD_KICK, MCMD_MOVE
+    n = 8
+    eng, orc = _pair(n, kick_off_wait=3, half_time_cycles=400)
+    seen = set()
+
+    def both(a):
+        eng.step(torch.as_tensor(a, device='cuda:0')); orc.step(a)
+        assert_match_same(eng, orc, 'rules')
+        seen.update(int(m) for m in orc.get('mode'))
+
+    def acts(**pp):
+        a = np.zeros((n, 22, 3), dtype=np.float32)
+        for k, v in pp.items():
+            a[:, int(k[1:])] = v
+        return a
+    assert (orc.get('mode') == GM_BEFORE_KICK_OFF).all()
+    both(acts(p10=[MCMD_KICK, 100, 0], p3=[MCMD_MOVE, -20.0, 5.0]))     # dead ball, Move allowed
+    both(acts()); both(acts())                                           # -> KickOff_
+    both(acts(p10=[MCMD_KICK, 20, 0]))                                   # taker plays the ball ...
+    both(acts(p10=[MCMD_DASH, 100, 0]))
+    both(acts(p10=[MCMD_KICK, 50, 0]))                                   # ... twice: FreeKickFault_
+    assert (orc.get('mode') == GM_FREE_KICK_FAULT).all()
+    # back pass: play on, a left field player kicks, the ball is put in front of the goalie, who catches
+    for e in range(n):
+        orc.set_game(e, mode=2, mode_side=0); eng.mode[e] = 2; eng.mode_side[e] = 0
+        orc.set_obj(e, 2, x=-45.0, y=0.3, body=180.0); eng.x[e, 2] = -45.0; eng.y[e, 2] = 0.3; eng.body[e, 2] = 180.0
+        orc.set_obj(e, 22, x=-45.5, y=0.3, vx=0.0, vy=0.0); eng.x[e, 22] = -45.5; eng.y[e, 22] = 0.3; eng.vx[e, 22] = 0.0; eng.vy[e, 22] = 0.0
+    both(acts(p2=[MCMD_KICK, 100, 0]))
+    for e in range(n):
+        orc.set_obj(e, 22, x=-49.2, y=0.3, vx=-1.0, vy=0.0); eng.x[e, 22] = -49.2; eng.y[e, 22] = 0.3; eng.vx[e, 22] = -1.0; eng.vy[e, 22] = 0.0
+    both(acts(p0=[MCMD_CATCH, 0, 0]))
+    assert (orc.get('mode') == GM_BACK_PASS).all() and (eng.mode.cpu().numpy() == GM_BACK_PASS).all()
+    assert {GM_BEFORE_KICK_OFF, GM_FREE_KICK_FAULT, GM_BACK_PASS} <= seen

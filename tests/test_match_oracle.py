@@ -343,3 +343,96 @@ def test_move_before_kick_off_and_with_a_caught_ball():
     assert m.get('x')[0][0] == -36.0
     m.step(acts(p0=[MCMD_KICK, 60, 0]))                    # the kick puts the ball in play and ends the hold
     assert m.get('mode')[0] == GM_PLAY_ON and m.get('ball_holder')[0] == 0 and m.get('vx')[0][22] > 0
+
+
+# ---- round 2: BeforeKickOff, free-kick fault, back pass (rcssserver rules restated; parity unpinned) ----------------------
+def test_before_kick_off_mode_waits_and_lets_players_move():
+    from soccer2d_amd._capi_match import GM_BEFORE_KICK_OFF
+    m = fresh(kick_off_wait=4, half_time_cycles=20)
+    assert m.get('mode')[0] == GM_BEFORE_KICK_OFF and m.get('mode_side')[0] == LEFT
+    # nobody may play the ball (not even the side that will kick off); Move inside the own half is allowed
+    m.step(acts(p10=[MCMD_KICK, 100, 0], p3=[MCMD_MOVE, -20.0, 5.0], p14=[MCMD_MOVE, -12.0, -3.0]))
+    assert m.get('x')[0][22] == 0 and m.get('mode')[0] == GM_BEFORE_KICK_OFF and m.stats()[4] == 0
+    assert m.get('x')[0][3] == pytest.approx(-20.0) and m.get('y')[0][3] == pytest.approx(5.0)
+    assert m.get('x')[0][14] == pytest.approx(12.0) and m.get('y')[0][14] == pytest.approx(3.0)      # right team: mirrored frame
+    for _ in range(2):
+        m.step(acts())
+        assert m.get('mode')[0] == GM_BEFORE_KICK_OFF
+    m.step(acts())                                  # 4th cycle: the wait is over
+    assert m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == LEFT and m.get('setplay_timer')[0] == 0
+    m.step(acts(p10=[MCMD_KICK, 100, 0]))
+    assert m.get('mode')[0] == GM_PLAY_ON
+    # half time goes through BeforeKickOff again, for the side that kicks off the second half
+    while m.get('cycle')[0] < 20:
+        m.step(acts())
+    assert m.get('mode')[0] == GM_BEFORE_KICK_OFF and m.get('mode_side')[0] == RIGHT
+    for _ in range(4):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == RIGHT
+
+
+def test_free_kick_fault_on_a_second_touch_by_the_taker():
+    from soccer2d_amd._capi_match import GM_FREE_KICK_FAULT
+    m = fresh()
+    m.step(acts(p10=[MCMD_KICK, 20, 0]))           # the kick-off taker plays the ball softly (0.54 m/cycle) ...
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('set_play_taker')[0] == 11
+    m.step(acts(p10=[MCMD_DASH, 100, 0]))          # ... runs after it ...
+    assert m.get('set_play_taker')[0] == 11 and m.get('mode')[0] == GM_PLAY_ON
+    bx = m.get('x')[0][22]
+    m.step(acts(p10=[MCMD_KICK, 50, 0]))           # ... and kicks again before anybody else touched it: fault
+    assert m.get('mode')[0] == GM_FREE_KICK_FAULT and m.get('mode_side')[0] == RIGHT and m.get('set_play_taker')[0] == 0
+    assert m.get('vx')[0][22] == 0 and m.get('x')[0][22] > bx          # ball placed where it was after the kick, at rest
+    # the free kick is a set play for the other side: the offender cannot play it, the right team can
+    m.set_obj(0, 15, x=float(m.get('x')[0][22]) + 0.5, y=0.0, body=180.0)
+    m.step(acts(p10=[MCMD_KICK, 50, 0]))
+    assert m.get('mode')[0] == GM_FREE_KICK_FAULT
+    m.step(acts(p15=[MCMD_KICK, 50, 0]))
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('set_play_taker')[0] == 16
+
+
+def test_no_fault_after_another_touch_and_switch():
+    m = fresh()
+    m.step(acts(p10=[MCMD_KICK, 20, 0]))
+    # a team-mate touches the ball in between: the taker may play it again
+    m.set_obj(0, 9, x=float(m.get('x')[0][22]) - 0.5, y=0.0, body=0.0)
+    m.step(acts(p9=[MCMD_KICK, 10, 0]))
+    assert m.get('set_play_taker')[0] == 0
+    m.set_obj(0, 10, x=float(m.get('x')[0][22]) - 0.5, y=0.0, body=0.0)
+    m.step(acts(p10=[MCMD_KICK, 10, 0]))
+    assert m.get('mode')[0] == GM_PLAY_ON
+    # free_kick_faults = 0 switches the rule off
+    m = fresh(free_kick_faults=0)
+    m.step(acts(p10=[MCMD_KICK, 20, 0])); m.step(acts(p10=[MCMD_DASH, 100, 0])); m.step(acts(p10=[MCMD_KICK, 50, 0]))
+    assert m.get('mode')[0] == GM_PLAY_ON
+
+
+def test_back_pass_to_the_goalie_is_an_indirect_free_kick():
+    from soccer2d_amd._capi_match import GM_BACK_PASS, GM_FREE_KICK, MCMD_CATCH
+    m = fresh(); play_on(m)
+    # left #3 (index 2) kicks the ball towards his own goalie ...
+    m.set_obj(0, 2, x=-45.0, y=0.3, body=180.0)
+    m.set_obj(0, 22, x=-45.5, y=0.3, vx=0.0, vy=0.0)
+    m.step(acts(p2=[MCMD_KICK, 100, 0]))
+    assert m.get('last_kicker')[0] == 3 and m.get('vx')[0][22] < -2.0
+    m.step(acts())
+    assert m.get('last_kicker')[0] == 3                    # nobody else touched it on the way
+    m.set_obj(0, 22, x=-49.2, y=0.3, vx=-1.0, vy=0.0)      # (the rolling ball, placed in front of the goalie)
+    # ... who catches it inside his penalty area: BackPass_, free kick for the RIGHT side from the nearer front corner
+    m.step(acts(p0=[MCMD_CATCH, 0, 0]))
+    assert m.get('mode')[0] == GM_BACK_PASS and m.get('mode_side')[0] == RIGHT
+    assert m.get('x')[0][22] == pytest.approx(-36.0) and m.get('y')[0][22] == pytest.approx(20.16) and m.get('vx')[0][22] == 0
+    assert m.get('ball_holder')[0] == 0 and m.get('last_kicker')[0] == 0
+    # an opponent's kick before the catch is no back pass; nor is the goalie's own kick; nor with back_passes = 0
+    for kicker, kw in ((13, {}), (0, {}), (2, dict(back_passes=0))):
+        m = fresh(**kw); play_on(m)
+        m.set_game(0, last_kicker=kicker + 1)
+        m.set_obj(0, 22, x=-49.2, y=0.3, vx=-1.0, vy=0.0)
+        m.step(acts(p0=[MCMD_CATCH, 0, 0]))
+        assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == LEFT and m.get('ball_holder')[0] == 1
+    # a tackle or a collision with another player in between ends the back pass
+    m = fresh(); play_on(m)
+    m.set_game(0, last_kicker=3)
+    m.set_obj(0, 22, x=-30.0, y=0.0, vx=0.0, vy=0.0)
+    m.set_obj(0, 15, x=-30.2, y=0.0)                # an opponent standing on the ball: collision touch
+    m.step(acts())
+    assert m.get('last_kicker')[0] == 0
