@@ -28,6 +28,14 @@ def _wrap(a):
     return torch.remainder(a + 180.0, 360.0) - 180.0
 
 
+def _barred(engine, side):
+    """bool[N,11]: the player who put the ball into play from the last set play and whom nobody else has touched the ball
+    after -- he must not play it again (FreeKickFault_, idl/service.proto:287), so the scripted policies let a team-mate go."""
+    taker = engine.set_play_taker.view(-1, 1).long() - 1 - (0 if side == 1 else 11)       # index inside the team, or out of range
+    in_play = (engine.mode == M.GM_PLAY_ON).view(-1, 1)
+    return (torch.arange(11, device=engine.device).view(1, 11) == taker) & in_play
+
+
 def chaser_policy(engine, side, kick_power=100.0):
     """Scripted baseline: the player nearest to the ball chases it (turn, then dash) and kicks it
     towards the opponent goal; the others hold position.  Returns actions float[N,11,3]."""
@@ -38,9 +46,10 @@ def chaser_policy(engine, side, kick_power=100.0):
     dist = torch.hypot(dx, dy)
     to_ball = _wrap(torch.rad2deg(torch.atan2(dy, dx)) - body)
     to_goal = _wrap(torch.rad2deg(torch.atan2(-y, 52.5 - x)) - body)
-    nearest = dist.argmin(dim=1, keepdim=True)
+    barred = _barred(engine, side)
+    nearest = torch.where(barred, torch.full_like(dist, 1e9), dist).argmin(dim=1, keepdim=True)
     is_chaser = torch.zeros_like(dist, dtype=torch.bool).scatter_(1, nearest, True)
-    kickable = dist <= 1.0
+    kickable = (dist <= 1.0) & ~barred
     turn = is_chaser & ~kickable & (to_ball.abs() > 15.0)
     dash = is_chaser & ~kickable & ~turn
     kick = kickable
@@ -152,9 +161,10 @@ class ParamChaser:
         dist = torch.hypot(dx, dy)
         to_ball = _wrap(torch.rad2deg(torch.atan2(dy, dx)) - body)
         to_goal = _wrap(torch.rad2deg(torch.atan2(aim_y - y, 52.5 - x)) - body)
-        rank = dist.argsort(dim=1).argsort(dim=1)
-        is_chaser = rank < int(round(nch))
-        kickable = dist <= 1.0
+        barred = _barred(engine, side)
+        rank = torch.where(barred, torch.full_like(dist, 1e9), dist).argsort(dim=1).argsort(dim=1)
+        is_chaser = (rank < int(round(nch))) & ~barred
+        kickable = (dist <= 1.0) & ~barred
         turn = is_chaser & ~kickable & (to_ball.abs() > tol)
         dash = is_chaser & ~kickable & ~turn
         act[..., 0] = torch.where(kickable, 3.0, torch.where(turn, 2.0, torch.where(dash, 1.0, 0.0)))
