@@ -299,7 +299,9 @@ def test_population_based_training_on_the_league():
     span = LG.ParamChaser.HIGH - LG.ParamChaser.LOW
     init = [LG.ParamChaser(LG.ParamChaser.LOW + torch.rand(4, generator=g) * span) for _ in range(6)]
     init[0] = LG.ParamChaser([6.0, 25.0, 80.0, 1.0])          # a deliberately poor member: feeble kicks, sloppy turns
-    eng = MatchEngine(96, 'cuda:0', half_time_cycles=3000)
+    # noise on: without it every match of a pairing is the same game (one formation, deterministic policies), and a whole
+    # round is all-or-nothing -- one rounding difference in a policy's atan2 decides 96 matches at once
+    eng = MatchEngine(96, 'cuda:0', half_time_cycles=3000, noise=True)
     pop = [LG.ParamChaser(p.theta) for p in init]
     league, pop, hist = LG.evolve_league(eng, pop, rounds=5, n_cycles=300, seed=3)
     assert len(hist) == 5 and int(league.games.sum()) == 2 * 96 * 5
@@ -380,3 +382,43 @@ def test_match_round2_rules_on_device():
     both(acts(p0=[MCMD_CATCH, 0, 0]))
     assert (orc.get('mode') == GM_BACK_PASS).all() and (eng.mode.cpu().numpy() == GM_BACK_PASS).all()
     assert {GM_BEFORE_KICK_OFF, GM_FREE_KICK_FAULT, GM_BACK_PASS} <= seen
+
+
+def test_match_parity_under_scripted_policies():
+    """Dribbling / shooting policies produce long sequences of kicks by the same player, set plays taken and re-taken, goals and
+    restarts -- the paths the round-2 rules (free-kick fault, back pass) hang on, which a uniform random policy rarely strings
+    together.  Left: a naive dribbler that ignores the double-touch rule (so faults do occur); right: the league's rule-aware
+    ParamChaser.  Device == oracle after every cycle."""
+    from soccer2d_amd import league as LG
+    from soccer2d_amd._capi_match import GM_FREE_KICK_FAULT
+
+    def naive(engine, side, kp=25.0):
+        x, y, body, bx, by = LG.team_view(engine, side)
+        act = torch.zeros((x.shape[0], 11, 3), device=x.device)
+        dx, dy = bx - x, by - y
+        dist = torch.hypot(dx, dy)
+        to_ball = LG._wrap(torch.rad2deg(torch.atan2(dy, dx)) - body)
+        to_goal = LG._wrap(torch.rad2deg(torch.atan2(-y, 52.5 - x)) - body)
+        chaser = torch.zeros_like(dist, dtype=torch.bool).scatter_(1, dist.argmin(dim=1, keepdim=True), True)
+        kick = dist <= 1.0
+        turn = chaser & ~kick & (to_ball.abs() > 15.0)
+        dash = chaser & ~kick & ~turn
+        act[..., 0] = torch.where(kick, 3.0, torch.where(turn, 2.0, torch.where(dash, 1.0, 0.0)))
+        act[..., 1] = torch.where(kick, torch.full_like(dist, kp), torch.where(turn, to_ball, torch.where(dash, 100.0, 0.0)))
+        act[..., 2] = torch.where(kick, to_goal, torch.zeros_like(dist))
+        return act
+    n = 24
+    eng, orc = _pair(n, half_time_cycles=260, noise=True)     # noise: 24 different games instead of one game 24 times
+    right = LG.ParamChaser([60.0, 10.0, 20.0, 2.0])
+    modes = set()
+    for t in range(560):
+        act = torch.zeros((n, 22, 3), device='cuda:0')
+        act[:, :11] = naive(eng, 1); act[:, 11:] = right(eng, 2)
+        a = act.cpu().numpy()
+        eng.step(act); orc.step(a)
+        if t % 4 == 0 or t < 40:
+            assert_match_same(eng, orc, f'scripted t={t}')
+        modes.update(int(m) for m in orc.get('mode'))
+    assert_match_same(eng, orc, 'scripted final')
+    st = orc.stats()
+    assert st[4] > 500 and GM_FREE_KICK_FAULT in modes, (modes, list(st))      # many kicks, and faults were called
