@@ -210,17 +210,32 @@ S2D_DEV NextEpisode prep_take_episode(const PrepTile& t, int lane) {
                      t.v[7][lane], t.v[8][lane], t.v[9][lane], t.v[10][lane], t.v[11][lane], t.v[12][lane]};
 }
 
+S2D_DEV const S2DTables* tables_of(const S2DRare* rp) {
+  return reinterpret_cast<const S2DTables*>(reinterpret_cast<const char*>(rp) + 256);
+}
+
 // A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269) for the env held in registers, given the
 // decoded command.  Returns the observation to hand back (post auto-reset), reward/done/result.
 // prep == nullptr: the reset sample is drawn on the spot (per-step API).
-template <bool NOISE>
+// FAST: the dash-only fast path (s2d_device.h, S2DTables): ep_lds = effort * power by step number, sc_lut = (sin, cos) of the
+// whole degrees -180 .. 180; the caller has checked that the env sits on the table.
+template <bool NOISE, bool FAST = false>
 S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
                       uint32_t k, int cmd, const CmdPrep& c, ObsOut& ob, float& reward, int& done, int& result,
-                      float* __restrict__ terminal_row, PrepTile* prep, int lane, bool& have_prep) {
-  e.step_number += 1;                                    // reach_ball_env.py:55
+                      float* __restrict__ terminal_row, PrepTile* prep, int lane, bool& have_prep,
+                      const float* ep_lds = nullptr, const float2* sc_lut = nullptr) {
   NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   if (NOISE) nz = noise_prepare(p, gid_lo, gid_hi, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);
-  float d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);   // trainer forces PlayOn each cycle (:242)
+  float d2;
+  if constexpr (FAST) {
+    const float ep = ep_lds[e.step_number];
+    const float2 sc = sc_lut[(int)norm_deg(e.body + c.dir) + 180];
+    e.step_number += 1;                                  // reach_ball_env.py:55
+    d2 = sim_cycle_dash_fast<NOISE>(p, rp, e, ep, c.dir_rate, sc.x, sc.y, nz);
+  } else {
+    e.step_number += 1;                                  // reach_ball_env.py:55
+    d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);   // trainer forces PlayOn each cycle (:242)
+  }
   observe_and_check(p, e, d2, ob, done, reward, result);
   if (done && p.auto_reset) {                  // SB3 VecEnv convention
 #pragma unroll
@@ -267,9 +282,6 @@ S2D_DEV NextEpisode prep_episode(const S2DHot& p, const S2DRare* __restrict__ rp
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-S2D_DEV const S2DTables* tables_of(const S2DRare* rp) {
-  return reinterpret_cast<const S2DTables*>(reinterpret_cast<const char*>(rp) + 256);
-}
 __global__ void s2d_tables_kernel(S2DHot p, const S2DRare* __restrict__ rp, S2DTables* __restrict__ t) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && rp->tab_len > 0) tables_build(p, rp->recover_init, rp->tab_power, rp->tab_len, *t);
 }
@@ -431,10 +443,23 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
   __shared__ PrepTile prep[kWavesPerBlock];
   __shared__ float4 act_lut[kWavesPerBlock][kWave];        // decoded commands of a small discrete action space (per wave)
+  __shared__ float ep_lds[S2D_TAB_MAX];                    // dash-only fast path (shared by the block's waves): effort * power
+  __shared__ float2 sc_lut[361];                           //   by step number, (sin, cos) of the whole degrees -180 .. 180
   const S2DHot p = hot_in_vgprs(p_sgpr);
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t wave_first = i - lane;
+  const S2DTables* const tb = tables_of(rp);
+  const int tab_len = MODE != S2D_MODE_TURN4 ? rp->tab_len : 0;
+  if (tab_len > 0) {                                       // every wave of the block helps, before any of them may leave
+    for (int k = threadIdx.x; k < tab_len; k += kBlock) ep_lds[k] = tb->ep[k];
+    for (int k = threadIdx.x; k <= 360; k += kBlock) {
+      float sn, cs;
+      sincos_deg((float)(k - 180), sn, cs);
+      sc_lut[k] = make_float2(sn, cs);
+    }
+    __syncthreads();
+  }
   if (wave_first >= n) return;
   const bool active = i < n;
   int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
@@ -454,6 +479,19 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
     asm volatile("" ::"v"(e.px), "v"(e.py), "v"(e.vx), "v"(e.vy), "v"(e.body), "v"(e.stamina), "v"(e.effort),
                  "v"(e.recovery), "v"(e.capacity), "v"(e.bx), "v"(e.by), "v"(e.bvx), "v"(e.bvy), "v"(e.prev_dist),
                  "v"(e.prev_angle), "v"(e.step_number), "v"(e.cycle), "v"(k0));
+  }
+  // this wave's envs all sit on the stamina table and have whole-degree body angles? (see the pipeline kernel's simulate wave)
+  bool fast = false;
+  if (tab_len > 0) {
+    bool ok = true;
+    if (active) {
+      const int sn = e.step_number;
+      ok = sn >= 0 && sn < tab_len;
+      const int q = ok ? sn : 0;
+      ok = ok && e.stamina == tb->stamina[q] && e.effort == tb->effort[q] && e.recovery == tb->recovery[q] &&
+           e.capacity == tb->capacity[q] && e.body == rintf(e.body) && fabsf(e.body) <= 180.0f;
+    }
+    fast = __ballot(active && !ok) == 0ull;
   }
   ObsOut ob;
   float reward = 0.0f, dir = 0.0f; int done = 0, res = 0, cmd = 0;
@@ -491,7 +529,8 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
       } else {
         c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, t == 0 || (k & 3u) == 0u, quad, squad, ro.action, cmd, dir);
       }
-      step_env<NOISE>(p, rp, e, gl, gh, k, cmd, c, ob, reward, done, res, term_row, &prep[wv], lane, have_prep);
+      if (fast) step_env<NOISE, true>(p, rp, e, gl, gh, k, cmd, c, ob, reward, done, res, term_row, &prep[wv], lane, have_prep, ep_lds, sc_lut);
+      else step_env<NOISE, false>(p, rp, e, gl, gh, k, cmd, c, ob, reward, done, res, term_row, &prep[wv], lane, have_prep);
       if (p.auto_reset) n_missing += __popcll(__ballot(done != 0));   // samples consumed by this cycle's resets
       if (ro.reward) ro.reward[row + i] = reward;
       if (ro.done) ro.done[row + i] = (uint8_t)done;
@@ -501,6 +540,10 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
     if (ro.obs) store_obs_tile(lds[wv], ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
   }
   if (active) {
+    if (fast) {                                            // the stamina words the fast path did not carry
+      const int q = e.step_number;
+      e.stamina = tb->stamina[q]; e.effort = tb->effort[q]; e.recovery = tb->recovery[q]; e.capacity = tb->capacity[q];
+    }
     env_store(e, S, stride, i);
     if (use_k) kplane[i] = k0 + (uint32_t)n_steps;
     o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;

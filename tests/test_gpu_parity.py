@@ -376,13 +376,14 @@ def test_short_rollouts_pipeline_fill_and_drain(name, ws, monkeypatch):
     assert int(eng.policy_step.min()) == int(eng.policy_step.max()) > 0
 
 
+@pytest.mark.parametrize('ws', ['1', '0'])
 @pytest.mark.parametrize('noise', [False, True])
-def test_dash_fast_path_and_its_fallback(noise, monkeypatch):
+def test_dash_fast_path_and_its_fallback(noise, ws, monkeypatch):
     """The four-wave pipeline's dash-only fast path (stamina table + whole-degree sine table) is taken by groups whose envs
     sit on the table; a group holding a foreign state (another stamina word, a fractional body angle, a step number beyond
     the table) must run the generic loop -- both bit-equal to the oracle, in the same launch.  Also: more than kSlots = 3
     episodes ending inside one launch (the inline-prepare path), forced by max_steps = 4."""
-    monkeypatch.setenv('S2D_ROLLOUT_WS', '1')
+    monkeypatch.setenv('S2D_ROLLOUT_WS', ws)                # the four-wave pipeline and the unified kernel both have the fast path
     kw = dict(use_continuous_action=False, action_space_size=16, change_ball_velocity=True, max_steps=4, noise=noise)
     n = 64 * 6 + 17
     eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
