@@ -244,10 +244,23 @@ S2D_DEV void wave_fence() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Collision tile of one match: kTileSlots float4 (x, y, size, -).  Object l lives in slot l and again in slot l + 23;
+// pad lanes (l > 22) put both of their writes behind the copies (slots 46 ..), so no two lanes ever write one slot.
+constexpr int kTileSlots = 2 * kHalf;
+S2D_DEV int tile_slot(int l) { return l <= BALL ? l : l + (BALL + 1); }
+S2D_DEV void tile_put(float4* row, int l, float x, float y) {
+  float2 v = make_float2(x, y);
+  *reinterpret_cast<float2*>(row + tile_slot(l)) = v;
+  *reinterpret_cast<float2*>(row + l + (BALL + 1)) = v;
+}
+S2D_DEV void tile_init(float4* row, int l, float size) {
+  row[tile_slot(l)] = make_float4(0.0f, 0.0f, size, 0.0f);
+  row[l + (BALL + 1)] = make_float4(0.0f, 0.0f, size, 0.0f);
+}
 // `last` = this is the final cycle of the launch: nearest_left / nearest_right are outputs only (nothing in
 // the dynamics reads them), so the reduction that produces them runs once per launch.
 S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, int l, int half, uint32_t gl, uint32_t gh,
-                         int cmd, float a, float bb, MCounts& cnt, float2* pos, bool last) {
+                         int cmd, float a, float bb, MCounts& cnt, float4* pos, bool last) {
   const bool is_player = l < NP, is_ball = l == BALL;
   const uint32_t cyc = (uint32_t)g.cycle;
   const int mode0 = g.mode, side0 = g.mode_side;
@@ -259,8 +272,10 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   float ax = 0.0f, ay = 0.0f, kx = 0.0f, ky = 0.0f;
   bool kicked = false, by_kick = false;                    // by_kick: the impulse came from a Kick command (not a tackle)
   if (!is_player || o.tackle > 0 || mode0 == S2D_GM_TIME_OVER) cmd = S2D_MCMD_NONE;
-  U4 nz{0, 0, 0, 0}, nk{0, 0, 0, 0};
-  if (p.noise) { nz = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, (uint32_t)l); nk = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, 32u + (uint32_t)l); }
+  // one noise block per object and cycle: x, y = movement noise; z, w = the command's own noise (a player sends ONE body
+  // command per cycle: Turn uses z, Kick uses z and w)
+  U4 nz{0, 0, 0, 0};
+  if (p.noise) nz = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, (uint32_t)l);
   const bool may_touch = !is_setplay(mode0) || (side_of(l) == side0 && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_BEFORE_KICK_OFF);   // after a goal / before the kick-off the ball is dead
   bool caught = false, hold_moved = false;
   if (cmd == S2D_MCMD_DASH) m_dash(p, pt, l, o, a, bb, ax, ay);
@@ -285,7 +300,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
       hold_moved = holds;
     }
   } else if (cmd == S2D_MCMD_KICK) {
-    bool ok = m_kick(p, pt, l, o, bx0, by0, bvx0, bvy0, a, bb, rnd_u01(nk.x), rnd_u01(nk.y), kx, ky);
+    bool ok = m_kick(p, pt, l, o, bx0, by0, bvx0, bvy0, a, bb, rnd_u01(nz.z), rnd_u01(nz.w), kx, ky);
     if (ok && may_touch) { kicked = true; by_kick = true; cnt.kicks++; } else { kx = 0.0f; ky = 0.0f; }
   } else if (cmd == S2D_MCMD_TACKLE) {
     bool ok = false;
@@ -371,28 +386,33 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   // detection pass that costs half of it: 23 is odd, so "lane l against objects l+1 .. l+11 (mod 23)"
   // visits every unordered pair exactly once.  Same comparison (d2 < (ri + rj)^2, both symmetric in the
   // pair), so a wave skips the scan only when the scan would have found nothing.
+  // The tile row of a match holds (x, y, size) of its 23 objects TWICE (slots l and l + 23, tile_put), so "object
+  // l + m" is slot l + m without a wrap and every read of the unrolled loop is one ds_read_b128 at a constant offset
+  // from the lane's own slot; the sizes are written once per launch (tile_init).  Pad lanes (23 .. 31) compare
+  // whatever their slots hold and are masked out at the end.
   bool overlap = false;
-  pos[l] = make_float2(o.x, o.y);
+  tile_put(pos, l, o.x, o.y);
   wave_fence();
-  if (l <= BALL) {
-#pragma unroll 1
+  {
+    const float4* mine = pos + l;
+#pragma unroll
     for (int m = 1; m <= 11; ++m) {
-      int j = l + m; j = j > BALL ? j - (BALL + 1) : j;
-      const float2 pj = pos[j];
+      const float4 pj = mine[m];
       float dx = o.x - pj.x, dy = o.y - pj.y;
-      float r = ri + pt[PT_SIZE][j];
+      float r = ri + pj.z;
       overlap |= sq2(dx, dy) < r * r;
     }
+    overlap &= l <= BALL;
   }
   wave_fence();
   for (int pass = 0; pass < 10 && __ballot(overlap) != 0ull; ++pass) {
     float sx = 0.0f, sy = 0.0f; int c = 0; int tp = -1;
-    pos[l] = make_float2(o.x, o.y);                       // wave-private tile: LDS ops of a wave are in order
+    tile_put(pos, l, o.x, o.y);                           // wave-private tile: LDS ops of a wave are in order
     wave_fence();
     for (int j = 0; j <= BALL; ++j) {
-      const float2 pj = pos[j];                           // same address for the whole half: broadcast read
+      const float4 pj = pos[j];                           // same address for the whole half: broadcast read
       float xj = pj.x, yj = pj.y;
-      float rj = pt[PT_SIZE][j];                          // uniform address: broadcast read
+      float rj = pj.z;
       float dx = o.x - xj, dy = o.y - yj;
       float d2 = sq2(dx, dy), r = ri + rj;
       if (l <= BALL && j != l && d2 < r * r) {
@@ -687,7 +707,7 @@ struct MRoll { float* obs; float* reward; int32_t* mode; uint8_t* done; };
 // n_steps cycles; actions = [T][N][22][3] or NULL (random policy).  n_steps = 1 with ro = {} is the per-step API.
 __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p_arg, MPtrs q, int64_t n, int n_steps,
                                                                      const float* __restrict__ actions, MRoll ro) {
-  __shared__ float2 pos_tile[kEnvsPerBlock][kHalf];
+  __shared__ float4 pos_tile[kEnvsPerBlock][kTileSlots];
   __shared__ PTab pt[PT_WORDS];                       // per-slot PlayerType parameters, shared by the 8 matches
   __shared__ unsigned int lds_cnt[8];
   // The ~60 uniform parameters are read from LDS (broadcast reads) where they are used instead of
@@ -707,6 +727,7 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
   const int64_t ec = valid ? e : n - 1;              // lanes of out-of-range matches shadow the last match (no stores)
   MObj o; MGame g;
   m_load(q, ec, l, o, g);
+  tile_init(pos_tile[threadIdx.x / kHalf], l, pt[PT_SIZE][l]);
   const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)ec;
   const uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
   MCounts cnt{0, 0, 0, 0, 0, 0, 0};

@@ -311,8 +311,8 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     int cmd = (int)act[i * 3 + 0];
     REAL a = (REAL)act[i * 3 + 1], bb = (REAL)act[i * 3 + 2];
     if (o->tackle > 0 || mode0 == S2D_GM_TIME_OVER) cmd = S2D_MCMD_NONE;
-    uint32_t nz[4] = {0, 0, 0, 0}, nk[4] = {0, 0, 0, 0};
-    if (p->noise) { draw(p->seed, gid, cyc, ST_NOISE, (uint32_t)i, nz); draw(p->seed, gid, cyc, ST_NOISE, 32u + (uint32_t)i, nk); }
+    uint32_t nz[4] = {0, 0, 0, 0};                       /* x, y: movement noise; z, w: the command's noise (Turn: z; Kick: z, w) */
+    if (p->noise) draw(p->seed, gid, cyc, ST_NOISE, (uint32_t)i, nz);
     /* set play: only the taking side plays the ball; after a goal nobody does */
     int may_touch = !is_setplay(mode0) || (side_of(i) == side0 && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_BEFORE_KICK_OFF);
     if (cmd == S2D_MCMD_DASH) m_dash(p, t, o, a, bb, &ax[i], &ay[i]);
@@ -337,7 +337,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
         if (holds) hold_move = i;
       }
     } else if (cmd == S2D_MCMD_KICK) {
-      int ok = m_kick(p, t, o, b, a, bb, rnd_u01(nk[0]), rnd_u01(nk[1]), &kx[i], &ky[i]);
+      int ok = m_kick(p, t, o, b, a, bb, rnd_u01(nz[2]), rnd_u01(nz[3]), &kx[i], &ky[i]);
       if (ok && may_touch) { kicked[i] = 1; by_kick[i] = 1; st->v[4]++; } else { kx[i] = ky[i] = R(0.0); }
     } else if (cmd == S2D_MCMD_TACKLE) {
       uint32_t w[4];
