@@ -621,9 +621,11 @@ S2D_DEV void m_random_action(const MParams& p, uint32_t gl, uint32_t gh, uint32_
   const uint32_t w0 = (cyc & 1u) ? w.z : w.x, w1 = (cyc & 1u) ? w.w : w.y;
   cmd = 1 + (int)(w0 >> 30);
   float u = rnd_u01(w0 << 2), s = rnd_u01(w1) * 2.0f - 1.0f;
-  b = 0.0f;
-  if (cmd == S2D_MCMD_DASH || cmd == S2D_MCMD_KICK) { a = u * 100.0f; b = s * 180.0f; }
-  else { a = s * 180.0f; }
+  // selects, not conditional stores through the references: those made {a, b} a stack array in scratch memory
+  const bool two = cmd == S2D_MCMD_DASH || cmd == S2D_MCMD_KICK;
+  const float ang = s * 180.0f;
+  a = two ? u * 100.0f : ang;
+  b = two ? ang : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------
