@@ -106,16 +106,20 @@ S2D_DEV void store_obs_tile(float* tile, const ObsOut& ob, int lane, bool active
   wave_lds_fence();
 }
 
-// episode counters: one popcount of a 64-lane ballot per label, one atomic per wave
-S2D_DEV unsigned long long* stats_stripe(unsigned long long* stats) { return stats + (blockIdx.x % S2D_STATS_STRIPES) * 8; }
-S2D_DEV void wave_count_results(int res, bool active, int lane, unsigned long long* stats) {
-  stats = stats_stripe(stats);
-#pragma unroll
-  for (int r = S2D_RESULT_GOAL; r <= S2D_RESULT_TIMEOUT; ++r) {
-    unsigned long long m = __ballot(active && res == r);
-    if (m != 0ull && lane == 0) atomicAdd(&stats[r], (unsigned long long)__popcll(m));
-  }
+// Episode counters: every group of 64 envs owns one row of stats[S2D_STATS_ROWS(n)][8], and in every kernel that group is
+// one wave (or the agent wave of one workgroup), so the row is updated with a plain load at the start of the launch and a plain
+// store at its end -- lanes 0 .. 3 hold counters 0 .. 3; the env-step counter of the whole batch is kept by the first group, so a
+// wave in which no episode ended stores nothing.  (Round 1 used striped atomics: no contention to speak of, yet the
+// three atomics at the end of a wave cost s2d_step 0.3 us per launch, profiles/r02/ab_step_ablation.txt.)
+S2D_DEV unsigned long long* stats_row(unsigned long long* stats, int64_t wave_first) { return stats + (wave_first / kWave) * 8; }
+S2D_DEV unsigned long long stats_load(const unsigned long long* row, int lane) { return lane < 4 ? row[lane] : 0ull; }
+// steps / goal / out / timeout: wave-uniform increments
+S2D_DEV void stats_store(unsigned long long* row, int lane, unsigned long long old, unsigned long long steps, unsigned int goal,
+                         unsigned int out, unsigned int timeout) {
+  const unsigned long long add = lane == 0 ? steps : lane == 1 ? goal : lane == 2 ? out : timeout;
+  if (lane < 4 && add != 0ull) row[lane] = old + add;
 }
+S2D_DEV unsigned int wave_count(bool pred) { return (unsigned int)__popcll(__ballot(pred)); }
 
 // caller-provided action of env i at rollout step t (layouts of include/s2d.h)
 template <int MODE>
@@ -358,6 +362,8 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
   const bool active = i < n;
   const bool use_k = uses_policy_step<MODE, NOISE>(kind);
   uint32_t* const kplane = reinterpret_cast<uint32_t*>(S + F_POLICY * stride);
+  unsigned long long* const srow = stats_row(o.stats, wave_first);
+  const unsigned long long sold = stats_load(srow, lane);
   ObsOut ob;
   int res = 0;
   if (active) {
@@ -425,8 +431,8 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
   }
   int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
   store_obs_tile(lds[wv], ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, (int)rows * S2D_OBS_DIM);
-  wave_count_results(res, active, lane, o.stats);
-  if (main_block == 0 && threadIdx.x == 0) atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n);
+  stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n : 0ull, wave_count(active && res == S2D_RESULT_GOAL),
+              wave_count(active && res == S2D_RESULT_OUT), wave_count(active && res == S2D_RESULT_TIMEOUT));
 }
 
 // T fused cycles per launch: the 17 state words stay in registers, only the rollout record
@@ -550,18 +556,14 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
     o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
   }
   store_obs_tile(lds[wv], ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, valid);
-  // wave-level reduction of the per-lane episode counters (shuffle tree), one atomic per wave
+  // wave-level reduction of the per-lane episode counters (butterfly: every lane ends with the sums), then the wave's row
   if (!active) { cnt1 = cnt2 = cnt3 = 0; }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    cnt1 += __shfl_down(cnt1, off); cnt2 += __shfl_down(cnt2, off); cnt3 += __shfl_down(cnt3, off);
+    cnt1 += __shfl_xor(cnt1, off); cnt2 += __shfl_xor(cnt2, off); cnt3 += __shfl_xor(cnt3, off);
   }
-  if (lane == 0) {
-    if (cnt1) atomicAdd(&stats_stripe(o.stats)[1], (unsigned long long)cnt1);
-    if (cnt2) atomicAdd(&stats_stripe(o.stats)[2], (unsigned long long)cnt2);
-    if (cnt3) atomicAdd(&stats_stripe(o.stats)[3], (unsigned long long)cnt3);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n * (unsigned long long)n_steps);
+  unsigned long long* const srow = stats_row(o.stats, wave_first);
+  stats_store(srow, lane, stats_load(srow, lane), wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, cnt1, cnt2, cnt3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -838,6 +840,8 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     float oa[S2D_OBS_DIM];                                 // only oa[0..3] are produced here
     float reward = 0.0f; int res = 0, done = 0;
     unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    unsigned long long* const srow = stats_row(o.stats, wave_first);
+    const unsigned long long sold = stats_load(srow, lane);  // this group's row of the episode counters (stored after the loop)
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
     int64_t row = 0;
     __syncthreads();                                       // prepared episodes published
@@ -885,15 +889,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     if (!active) { cnt1 = cnt2 = cnt3 = 0; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      cnt1 += __shfl_down(cnt1, off); cnt2 += __shfl_down(cnt2, off); cnt3 += __shfl_down(cnt3, off);
+      cnt1 += __shfl_xor(cnt1, off); cnt2 += __shfl_xor(cnt2, off); cnt3 += __shfl_xor(cnt3, off);
     }
-    if (lane == 0) {
-      if (cnt1) atomicAdd(&stats_stripe(o.stats)[1], (unsigned long long)cnt1);
-      if (cnt2) atomicAdd(&stats_stripe(o.stats)[2], (unsigned long long)cnt2);
-      if (cnt3) atomicAdd(&stats_stripe(o.stats)[3], (unsigned long long)cnt3);
-    }
-    if (blockIdx.x == 0 && lane == 0)
-      atomicAdd(&stats_stripe(o.stats)[0], (unsigned long long)n * (unsigned long long)n_steps);
+    stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, cnt1, cnt2, cnt3);
   } else {
     // ------------------------------------------------------------------ B-wave (ball half, observation stream)
     __builtin_amdgcn_s_setprio(S2D_PRIO_B);
@@ -1084,7 +1082,7 @@ static ArenaLayout layout_for(int64_t n) {
   L.terminal_obs = off; off += align_up(s * S2D_OBS_DIM * 4, 256);
   L.action_dir = off; off += align_up(s * 4, 256);
   L.action_cmd = off; off += align_up(s, 256);
-  L.stats = off; off += (size_t)S2D_STATS_STRIPES * 8 * sizeof(unsigned long long);
+  L.stats = off; off += align_up((size_t)S2D_STATS_ROWS(n) * 8 * sizeof(unsigned long long), 256);
   L.prep = off; off += align_up((size_t)(2 * PS_WORDS + 2) * s * 4, 256);
   L.rare = off; off += align_up(sizeof(S2DRare), 256);
   L.tables = off; off += align_up(sizeof(S2DTables), 256);   // directly behind S2DRare: kernels find them at rp + 256 bytes
@@ -1439,7 +1437,7 @@ S2D_API int s2d_world_model(S2DHandle h, const S2DWorldModel* out, void* stream)
 S2D_API int s2d_stats_reset(S2DHandle h, void* stream) {
   if (!h) return fail(S2D_EINVAL, "NULL handle");
   DeviceGuard guard(h->device);
-  HIP_TRY(hipMemsetAsync(h->buf.stats, 0, (size_t)S2D_STATS_STRIPES * 8 * sizeof(unsigned long long), static_cast<hipStream_t>(stream)));
+  HIP_TRY(hipMemsetAsync(h->buf.stats, 0, (size_t)S2D_STATS_ROWS(h->n) * 8 * sizeof(unsigned long long), static_cast<hipStream_t>(stream)));
   return S2D_OK;
 }
 

@@ -91,8 +91,9 @@ class Engine:
         self.buffers = {}
         for k, (name, _ct, dt, trail) in enumerate(BUFFER_FIELDS):
             o = off[k + 1]
-            if trail is None:          # stats: [S2D_STATS_STRIPES][8] striped counters
-                count, shape = 64 * 8, (64, 8)
+            if trail is None:          # stats: [S2D_STATS_ROWS(n)][8], one row per group of 64 envs
+                rows = max(64, (n + 63) // 64)
+                count, shape = rows * 8, (rows, 8)
                 name = 'stats_striped'
             else:
                 count = n

@@ -120,6 +120,8 @@ typedef struct S2DConfig {
  * s2d_step / s2d_reset / s2d_rollout.                                                     */
 #define S2D_OBS_DIM 10
 #define S2D_STATS_STRIPES 64
+/* rows of S2DBuffers.stats of an engine of n envs: one per group of 64 envs (its wave owns it), at least S2D_STATS_STRIPES */
+#define S2D_STATS_ROWS(n) ((((n) + 63) / 64) > S2D_STATS_STRIPES ? (((n) + 63) / 64) : S2D_STATS_STRIPES)
 typedef struct S2DBuffers {
   int64_t n_envs;
   /* state, row S of SURVEY.md 8(a): 15 float + 2 int32 words per env (+ policy_step, which only
@@ -143,8 +145,8 @@ typedef struct S2DBuffers {
   float *terminal_obs;   /* [N][10] observation of the finished episode (valid where done) */
   float *action_dir;     /* [N] decoded relative direction in degrees of the last command  */
   uint8_t *action_cmd;   /* [N] S2D_CMD_* of the last command                              */
-  /* episode statistics, striped to keep device atomics off one address:
-   * stats[S2D_STATS_STRIPES][8]; the value of counter k is the sum over stripes of [s][k].
+  /* episode statistics, one row per group of 64 envs (plain load / store by the wave that owns the group, no atomics):
+   * stats[S2D_STATS_ROWS(n_envs)][8]; the value of counter k is the sum over rows of [r][k].
    * k: 0 = env-steps, 1 = Goal, 2 = Out, 3 = Timeout, 4..7 reserved                        */
   unsigned long long *stats;
 } S2DBuffers;
