@@ -377,6 +377,13 @@ def secondary_measurements(args, dev, stream, rank, n, T):
     alg_step = n * (2 * STATE_BYTES + 4 + RECORD_BYTES - 4)
     out['step_api'] = {'value': n * 2048 / dt, 'unit': 'env-steps/s', 'launches': 2048,
                        'roofline': roofline_of(alg_step, dt / 2048, eng.kernel_name(), load_traffic('step', T, n), n, 1)}
+    # (c') the same with the caller's actions (what dqn_stable_baselines3.py does: the learner hands a tensor of 65 536 discrete
+    # actions to every step; (c) lets the engine draw them, which costs a Philox block per env and step)
+    acts = torch.randint(0, DQN_KWARGS['action_space_size'], (n,), device=dev, dtype=torch.int32)
+    settle(lambda k: [eng.step(acts) for _ in range(k)], 2048, args.settle_ms)
+    dt = time_graph(graph_of(lambda: [eng.step(acts) for _ in range(2048)]), stream)
+    out['step_api_caller_actions'] = {'value': n * 2048 / dt, 'unit': 'env-steps/s', 'launches': 2048, 'actions': 'int32[N] device tensor',
+                                      'roofline': roofline_of(alg_step, dt / 2048, eng.kernel_name(), None, n, 1)}
     del eng
     # (d) noise on (the drop-in default: rcssserver's stock player_rand / ball_rand)
     eng = fresh(noise=True)
