@@ -608,6 +608,25 @@ struct ResetSample { float px, py, body, bx, by, bvx, bvy; };
 // simulation, off the simulating wave, and a reset becomes a copy.
 S2D_DEV uint32_t reset_key(const Env& e) { return (uint32_t)e.episode + 1u; }
 
+// one velocity candidate of get_ball_velocity (reach_ball_env.py:202-212): speed, direction -> velocity; accepted when the ball
+// would come to rest inside the pitch
+S2D_DEV bool vel_candidate(const S2DHot& p, const S2DRare& r, float bx, float by, uint32_t ws, uint32_t wd, float& bvx, float& bvy) {
+  float speed = rnd_u01(ws) * 3.0f;
+  float dir = (float)rnd_below(wd, 361);
+  float sn, cs;
+  sincos_deg(dir, sn, cs);
+  bvx = speed * cs; bvy = speed * sn;
+  float travel = speed * r.travel_factor;
+  float tx = bx + travel * cs, ty = by + travel * sn;
+  return fabsf(tx) <= p.half_l && fabsf(ty) <= p.half_w;
+}
+// candidate k >= 1 of an env: two candidates per Philox block (block 2 + (k - 1) / 2; try 0 rides in block 1)
+S2D_DEV bool vel_try(const S2DHot& p, const S2DRare& r, uint32_t gid_lo, uint32_t gid_hi, uint32_t c0, float bx, float by, int k,
+                     float& bvx, float& bvy) {
+  const U4 wb = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 2 + ((k - 1) >> 1));
+  const bool odd = ((k - 1) & 1) != 0;
+  return vel_candidate(p, r, bx, by, odd ? wb.z : wb.x, odd ? wb.w : wb.y, bvx, bvy);
+}
 S2D_DEV ResetSample reset_sample(const S2DHot& p, const S2DRare& r, uint32_t gid_lo, uint32_t gid_hi, uint32_t c0) {
   U4 w = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 0);
   U4 w1 = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 1);
@@ -622,22 +641,81 @@ S2D_DEV ResetSample reset_sample(const S2DHot& p, const S2DRare& r, uint32_t gid
   }
   float bvx = 0.0f, bvy = 0.0f;
   if (r.change_ball_velocity) {                          // :202-212
-    bool ok = false;
-    uint32_t ws = w1.y, wd = w1.z;                       // try 0 rides in block 1
+    bool ok = vel_candidate(p, r, bx, by, w1.y, w1.z, bvx, bvy);   // try 0 rides in block 1
     U4 wb{0, 0, 0, 0};
-    for (int k = 0; k < S2D_MAX_VEL_TRIES && !ok; ++k) {  // bounded: every lane leaves the loop
-      if (k >= 1) {                                      // two candidates per Philox call
-        if ((k - 1) & 1) { ws = wb.z; wd = wb.w; }
-        else { wb = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 2 + ((k - 1) >> 1)); ws = wb.x; wd = wb.y; }
+    for (int k = 1; k < S2D_MAX_VEL_TRIES && !ok; ++k) {  // bounded: every lane leaves the loop
+      uint32_t ws, wd;                                   // two candidates per Philox call
+      if ((k - 1) & 1) { ws = wb.z; wd = wb.w; }
+      else { wb = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 2 + ((k - 1) >> 1)); ws = wb.x; wd = wb.y; }
+      ok = vel_candidate(p, r, bx, by, ws, wd, bvx, bvy);
+    }
+    if (!ok) { bvx = 0.0f; bvy = 0.0f; }
+  } else {                                               // :213-216
+    float sn, cs;
+    sincos_deg(r.ball_direction, sn, cs);
+    bvx = r.ball_speed * cs; bvy = r.ball_speed * sn;
+  }
+  o.bx = bx; o.by = by; o.bvx = bvx; o.bvy = bvy;
+  return o;
+}
+// The same sample drawn by a whole wave together (call it from wave-uniform control flow, with ALL 64 lanes; `need` = this lane
+// wants one).  The sequential loop above runs as long as the unluckiest of its lanes keeps being rejected -- the acceptance rate of
+// the stock task is ~1/2, so a wave of 64 needs ~8 rounds and the unluckiest of a launch's 200 000 draws ~17.  Here, after
+// everybody's try 0, the lanes of the wave are handed to the envs still pending: h = 64 / pending (a power of two) lanes evaluate
+// tries k .. k + h - 1 of one env side by side, the env takes the FIRST accepted one -- what the sequential loop would have
+// reached -- and k advances by h: three rounds for almost every wave.  `scratch` = 64 wave-private LDS words.
+S2D_DEV void coop_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+S2D_DEV ResetSample reset_sample_coop(const S2DHot& p, const S2DRare& r, uint32_t gid_lo, uint32_t gid_hi, uint32_t c0, bool need,
+                                      int lane, uint32_t* scratch) {
+  U4 w = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 0);
+  U4 w1 = s2d_draw(p, gid_lo, gid_hi, c0, S2D_ST_RESET, 1);
+  ResetSample o;
+  o.px = (float)(-50 + rnd_below(w.x, 101));             // :173
+  o.py = (float)(-30 + rnd_below(w.y, 61));              // :174
+  o.body = norm_deg((float)rnd_below(w.z, 361));         // :175
+  float bx = r.ball_position_x, by = r.ball_position_y;
+  if (r.change_ball_position) {                          // :176-181
+    bx = (float)(-50 + rnd_below(w.w, 101));
+    by = (float)(-30 + rnd_below(w1.x, 61));
+  }
+  float bvx = 0.0f, bvy = 0.0f;
+  if (r.change_ball_velocity) {                          // :202-212 (uniform: r is the same for every lane)
+    bool ok = vel_candidate(p, r, bx, by, w1.y, w1.z, bvx, bvy);
+    bool pending = need && !ok;
+    int k = 1;                                           // next try of every pending lane (they advance together)
+    unsigned long long P = __ballot(pending);
+    while (P != 0ull && k < S2D_MAX_VEL_TRIES) {
+      const int np = (int)__popcll(P);
+      int hs = 0;                                        // h = 2^hs helpers per pending env, h * np <= 64
+      while ((np << (hs + 1)) <= 64) ++hs;
+      const int mine = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(P >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)P, 0u));   // my rank among the pending
+      if (pending) scratch[mine] = (uint32_t)lane;
+      coop_fence();
+      const int q = lane >> hs, t = lane & ((1 << hs) - 1);
+      const bool helper = q < np;
+      const int owner = helper ? (int)scratch[q] : lane;
+      coop_fence();
+      const uint32_t ogl = (uint32_t)__shfl((int)gid_lo, owner), ogh = (uint32_t)__shfl((int)gid_hi, owner);
+      const uint32_t oc0 = (uint32_t)__shfl((int)c0, owner);
+      const float obx = __shfl(bx, owner), oby = __shfl(by, owner);
+      float cvx = 0.0f, cvy = 0.0f;
+      bool ok_t = false;
+      if (helper && k + t < S2D_MAX_VEL_TRIES) ok_t = vel_try(p, r, ogl, ogh, oc0, obx, oby, k + t, cvx, cvy);
+      const unsigned long long A = __ballot(ok_t);
+      int src = lane;
+      bool got = false;
+      if (pending) {
+        const unsigned long long grp = (A >> (mine << hs)) & (hs == 6 ? ~0ull : ((1ull << (1 << hs)) - 1ull));
+        if (grp != 0ull) { got = true; src = (mine << hs) + (int)__ffsll((long long)grp) - 1; }
       }
-      float speed = rnd_u01(ws) * 3.0f;
-      float dir = (float)rnd_below(wd, 361);
-      float sn, cs;
-      sincos_deg(dir, sn, cs);
-      bvx = speed * cs; bvy = speed * sn;
-      float travel = speed * r.travel_factor;
-      float tx = bx + travel * cs, ty = by + travel * sn;
-      if (fabsf(tx) <= p.half_l && fabsf(ty) <= p.half_w) ok = true;
+      const float nvx = __shfl(cvx, src), nvy = __shfl(cvy, src);
+      if (got) { bvx = nvx; bvy = nvy; ok = true; pending = false; }
+      k += 1 << hs;
+      P = __ballot(pending);
     }
     if (!ok) { bvx = 0.0f; bvy = 0.0f; }
   } else {                                               // :213-216
@@ -669,6 +747,14 @@ template <bool NOISE>
 S2D_DEV NextEpisode episode_prepare(const S2DHot& p, const S2DRare* __restrict__ rp, const S2DRare& r, uint32_t gid_lo,
                                     uint32_t gid_hi, uint32_t key) {
   const ResetSample o = reset_sample(p, r, gid_lo, gid_hi, key);
+  Env t{};
+  reset_apply<NOISE>(p, rp, t, gid_lo, gid_hi, o, r.recover_init, key);
+  return NextEpisode{t.px, t.py, t.vx, t.vy, t.body, t.stamina, t.effort, t.recovery, t.capacity, t.bx, t.by, t.bvx, t.bvy};
+}
+template <bool NOISE>
+S2D_DEV NextEpisode episode_prepare_coop(const S2DHot& p, const S2DRare* __restrict__ rp, const S2DRare& r, uint32_t gid_lo,
+                                         uint32_t gid_hi, uint32_t key, bool need, int lane, uint32_t* scratch) {
+  const ResetSample o = reset_sample_coop(p, r, gid_lo, gid_hi, key, need, lane, scratch);
   Env t{};
   reset_apply<NOISE>(p, rp, t, gid_lo, gid_hi, o, r.recover_init, key);
   return NextEpisode{t.px, t.py, t.vx, t.vy, t.body, t.stamina, t.effort, t.recovery, t.capacity, t.bx, t.by, t.bvx, t.bvy};

@@ -209,6 +209,23 @@ S2D_DEV void prep_fill(const S2DHot& p, const S2DRare* __restrict__ rp, PrepTile
   for (int k = 0; k < S2D_OBS_DIM; ++k) t.v[13 + k][lane] = f.o[k];
   t.v[13 + S2D_OBS_DIM][lane] = f.dist; t.v[14 + S2D_OBS_DIM][lane] = f.rel;
 }
+// the same by the whole wave together (reset_sample_coop; wave-uniform call, `need` = this lane's tile entry is to be drawn;
+// `scratch` = 64 wave-private LDS words)
+template <bool NOISE>
+S2D_DEV void prep_fill_coop(const S2DHot& p, const S2DRare* __restrict__ rp, PrepTile& t, int lane, uint32_t key,
+                            uint32_t gid_lo, uint32_t gid_hi, bool need, uint32_t* scratch) {
+  const S2DRare r = *rp;
+  const NextEpisode q = episode_prepare_coop<NOISE>(p, rp, r, gid_lo, gid_hi, key, need, lane, scratch);
+  const FirstObs f = first_obs(p, q);
+  if (need) {
+    t.v[0][lane] = q.px; t.v[1][lane] = q.py; t.v[2][lane] = q.vx; t.v[3][lane] = q.vy; t.v[4][lane] = q.body;
+    t.v[5][lane] = q.stamina; t.v[6][lane] = q.effort; t.v[7][lane] = q.recovery; t.v[8][lane] = q.capacity;
+    t.v[9][lane] = q.bx; t.v[10][lane] = q.by; t.v[11][lane] = q.bvx; t.v[12][lane] = q.bvy;
+#pragma unroll
+    for (int k = 0; k < S2D_OBS_DIM; ++k) t.v[13 + k][lane] = f.o[k];
+    t.v[13 + S2D_OBS_DIM][lane] = f.dist; t.v[14 + S2D_OBS_DIM][lane] = f.rel;
+  }
+}
 S2D_DEV NextEpisode prep_take_episode(const PrepTile& t, int lane) {
   return NextEpisode{t.v[0][lane], t.v[1][lane], t.v[2][lane], t.v[3][lane], t.v[4][lane], t.v[5][lane], t.v[6][lane],
                      t.v[7][lane], t.v[8][lane], t.v[9][lane], t.v[10][lane], t.v[11][lane], t.v[12][lane]};
@@ -505,7 +522,11 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
   float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
   U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
   bool have_prep = false;
-  if (active && p.auto_reset) { prep_fill<NOISE>(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }   // full wave
+  uint32_t* const coop_scratch = reinterpret_cast<uint32_t*>(&lds[wv][0]);   // the observation tile is idle between cycles
+  if (p.auto_reset) {                                      // full wave, drawn together (reset_sample_coop)
+    prep_fill_coop<NOISE>(p, rp, prep[wv], lane, active ? reset_key(e) : 0u, gl, gh, active, coop_scratch);
+    have_prep = active;
+  }
   int n_missing = 0;                                       // wave-uniform: lanes whose prepared sample is used up
   int64_t row = 0;
   // in-engine policy of a small discrete action space: one table entry per action (see the pipeline kernel's P-wave).
@@ -520,7 +541,9 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
   for (int t = 0; t < n_steps; ++t, row += n) {
     res = 0;
     if (n_missing >= kRefillMin) {                         // batched refill (wave-uniform counter: no ballot per cycle)
-      if (active && !have_prep) { prep_fill<NOISE>(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }
+      const bool need = active && !have_prep;
+      prep_fill_coop<NOISE>(p, rp, prep[wv], lane, need ? reset_key(e) : 0u, gl, gh, need, coop_scratch);
+      have_prep = active;
       n_missing = 0;
     }
     if (active) {
@@ -537,12 +560,14 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
       }
       if (fast) step_env<NOISE, true>(p, rp, e, gl, gh, k, cmd, c, ob, reward, done, res, term_row, &prep[wv], lane, have_prep, ep_lds, sc_lut);
       else step_env<NOISE, false>(p, rp, e, gl, gh, k, cmd, c, ob, reward, done, res, term_row, &prep[wv], lane, have_prep);
-      if (p.auto_reset) n_missing += __popcll(__ballot(done != 0));   // samples consumed by this cycle's resets
       if (ro.reward) ro.reward[row + i] = reward;
       if (ro.done) ro.done[row + i] = (uint8_t)done;
       if (ro.result) ro.result[row + i] = (uint8_t)res;
       cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
     }
+    // samples consumed by this cycle's resets -- counted by EVERY lane of the wave (also those past the last env), so that the refill
+    // above is entered by the whole wave: its cooperative draw hands tries to all 64 lanes
+    if (p.auto_reset) n_missing += __popcll(__ballot(active && done != 0));
     if (ro.obs) store_obs_tile(lds[wv], ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
   }
   if (active) {
@@ -632,6 +657,22 @@ S2D_DEV void slot_fill(const S2DHot& p, const S2DRare* __restrict__ rp, float (*
   for (int k = 0; k < S2D_OBS_DIM; ++k) slot[SL_FIRST + k][lane] = f.o[k];
   slot[SL_DIST][lane] = f.dist; slot[SL_REL][lane] = f.rel;
 }
+// the prologue's form: the whole wave draws together (reset_sample_coop; `need` = this lane has an env)
+template <bool NOISE>
+S2D_DEV void slot_fill_coop(const S2DHot& p, const S2DRare* __restrict__ rp, float (*slot)[kWave], int lane, uint32_t gl,
+                            uint32_t gh, uint32_t episode, bool need, uint32_t* scratch) {
+  const S2DRare r = *rp;
+  const NextEpisode q = episode_prepare_coop<NOISE>(p, rp, r, gl, gh, episode, need, lane, scratch);
+  const FirstObs f = first_obs(p, q);
+  if (need) {
+    slot[0][lane] = q.px; slot[1][lane] = q.py; slot[2][lane] = q.vx; slot[3][lane] = q.vy; slot[4][lane] = q.body;
+    slot[5][lane] = q.stamina; slot[6][lane] = q.effort; slot[7][lane] = q.recovery; slot[8][lane] = q.capacity;
+    slot[9][lane] = q.bx; slot[10][lane] = q.by; slot[11][lane] = q.bvx; slot[12][lane] = q.bvy;
+#pragma unroll
+    for (int k = 0; k < S2D_OBS_DIM; ++k) slot[SL_FIRST + k][lane] = f.o[k];
+    slot[SL_DIST][lane] = f.dist; slot[SL_REL][lane] = f.rel;
+  }
+}
 S2D_DEV NextEpisode slot_take(const float (*slot)[kWave], int lane) {
   return NextEpisode{slot[0][lane], slot[1][lane], slot[2][lane], slot[3][lane], slot[4][lane], slot[5][lane], slot[6][lane],
                      slot[7][lane], slot[8][lane], slot[9][lane], slot[10][lane], slot[11][lane], slot[12][lane]};
@@ -661,13 +702,13 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   const int n_iter = n_steps + 3;
 
   // ---- before the loop: the three waves that idle while the pipeline fills prepare one future episode each
-  if (role != 1) {
-    if (active && p_sgpr.auto_reset) {
-      const uint64_t gid = (((uint64_t)p_sgpr.gid_hi << 32) | p_sgpr.gid_lo) + (uint64_t)i;
-      const uint32_t ep0 = reinterpret_cast<const uint32_t*>(S + F_EPISODE * stride)[i];
-      const int k = role == 0 ? 0 : role - 1;
-      slot_fill<NOISE>(p_sgpr, rp, slots[k], lane, (uint32_t)gid, (uint32_t)(gid >> 32), ep0 + 1u + (uint32_t)k);
-    }
+  if (role != 1 && p_sgpr.auto_reset) {                    // wave-uniform: the wave draws together (reset_sample_coop)
+    const uint64_t gid = (((uint64_t)p_sgpr.gid_hi << 32) | p_sgpr.gid_lo) + (uint64_t)i;
+    uint32_t ep0 = 0u;
+    if (active) ep0 = reinterpret_cast<const uint32_t*>(S + F_EPISODE * stride)[i];
+    const int k = role == 0 ? 0 : role - 1;
+    slot_fill_coop<NOISE>(p_sgpr, rp, slots[k], lane, (uint32_t)gid, (uint32_t)(gid >> 32), ep0 + 1u + (uint32_t)k, active,
+                          reinterpret_cast<uint32_t*>(&tile[0][0]) + role * kWave);   // the observation tiles are idle before the loop
   }
 
   if (role == 0) {
@@ -983,6 +1024,19 @@ __global__ __launch_bounds__(kBlock) void s2d_validate_kernel(S2DHot p, const fl
 // diagnostic: evaluate the math spec / Philox on the device (tests compare with the oracle)
 __global__ void s2d_debug_eval_kernel(int op, const float* __restrict__ in, float* __restrict__ out, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (op == 9) {                                         // reset_sample_coop against reset_sample (whole waves: n is a multiple of 64)
+    __shared__ uint32_t scratch[256];
+    const uint32_t* u = reinterpret_cast<const uint32_t*>(in) + 4 * i;   // key, need, seed, travel factor (float bits)
+    S2DHot p{}; p.seed_lo = u[2]; p.seed_hi = 0x5EEDu; p.half_l = 52.5f; p.half_w = 34.0f;
+    S2DRare r{}; r.change_ball_position = 1; r.change_ball_velocity = 1; r.travel_factor = __uint_as_float(u[3]);
+    const int lane = threadIdx.x & 63;
+    const ResetSample a = reset_sample_coop(p, r, (uint32_t)i, 7u, u[0], u[1] != 0u, lane, scratch + (threadIdx.x & ~63u));
+    const ResetSample b = reset_sample(p, r, (uint32_t)i, 7u, u[0]);
+    float* q = out + 14 * i;
+    q[0] = a.px; q[1] = a.py; q[2] = a.body; q[3] = a.bx; q[4] = a.by; q[5] = a.bvx; q[6] = a.bvy;
+    q[7] = b.px; q[8] = b.py; q[9] = b.body; q[10] = b.bx; q[11] = b.by; q[12] = b.bvx; q[13] = b.bvy;
+    return;
+  }
   if (i >= n) return;
   switch (op) {
     case 0: { float s, c; sincos_deg(in[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break; }
@@ -1462,7 +1516,7 @@ S2D_API int s2d_set_seed(S2DHandle h, uint64_t seed) {
 }
 
 S2D_API int s2d_debug_eval(int op, const void* in_dev, void* out_dev, int64_t n, void* stream) {
-  if (!in_dev || !out_dev || n <= 0 || op < 0 || op > 8) return fail(S2D_EINVAL, "bad s2d_debug_eval argument");
+  if (!in_dev || !out_dev || n <= 0 || op < 0 || op > 9 || (op == 9 && n % 256 != 0)) return fail(S2D_EINVAL, "bad s2d_debug_eval argument");
   hipLaunchKernelGGL(s2d_debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), op, static_cast<const float*>(in_dev),
                      static_cast<float*>(out_dev), n);

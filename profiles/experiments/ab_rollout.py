@@ -21,7 +21,14 @@ def child(args):
     import torch
     from soccer2d_amd.engine import Engine, make_config
     n, T = args.envs, args.fuse
-    eng = Engine(n, 'cuda:0', cfg=make_config(noise=args.noise, **KW))
+    kw, sp = dict(KW), None
+    if args.variant != 'dqn':                              # 'timeouts': episodes end by max_steps only; 'never': they never end
+        kw.update(min_distance_to_ball=0.0)
+        sp = dict(pitch_half_length=1e6, pitch_half_width=1e6)
+        if args.variant == 'never':
+            kw.update(max_steps=1000000000)
+    make = lambda: Engine(n, 'cuda:0', cfg=make_config(noise=args.noise, server_params=sp, **kw))
+    eng = make()
     eng.reset()
     ro = eng.alloc_rollout(T)
     t0 = time.perf_counter()
@@ -39,7 +46,7 @@ def child(args):
         torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) * 1e3 / args.launches)
     # checksum of a fresh engine's first two launches (comparable across variants)
-    eng2 = Engine(n, 'cuda:0', cfg=make_config(noise=args.noise, **KW))
+    eng2 = make()
     eng2.reset()
     eng2.rollout(T, out=ro)
     eng2.rollout(T, out=ro)
@@ -56,6 +63,7 @@ def main():
     ap.add_argument('--envs', type=int, default=65536)
     ap.add_argument('--fuse', type=int, default=64)
     ap.add_argument('--noise', action='store_true')
+    ap.add_argument('--variant', default='dqn', choices=('dqn', 'timeouts', 'never'))
     ap.add_argument('--launches', type=int, default=512)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--settle', type=float, default=0.3)
@@ -67,7 +75,7 @@ def main():
     for lib in args.libs:
         env = dict(os.environ, S2D_LIB=os.path.abspath(lib))
         cmd = [sys.executable, os.path.abspath(__file__), '--child', '--envs', str(args.envs), '--fuse', str(args.fuse),
-               '--launches', str(args.launches), '--reps', str(args.reps), '--settle', str(args.settle)]
+               '--launches', str(args.launches), '--reps', str(args.reps), '--settle', str(args.settle), '--variant', args.variant]
         if args.noise:
             cmd.append('--noise')
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

@@ -137,6 +137,32 @@ def test_reset_parity(n):
     assert int(eng.cycle.min()) == 1 and int(eng.step_number.max()) == 0
 
 
+def test_cooperative_reset_draw_equals_the_sequential_one():
+    """reset_sample_coop (the whole wave shares the rejection loop of get_ball_velocity, reach_ball_env.py:202-212) must return
+    what reset_sample returns, bit for bit: for full waves, sparse `need` patterns (the refill of a few lanes) and acceptance
+    rates from ~1 (short travel) to a few per cent (a travel factor that puts most candidates outside the pitch)."""
+    from soccer2d_amd import _capi
+    lib = _capi.load_library()
+    rs = np.random.RandomState(7)
+    n = 256 * 64
+    for travel, p_need in ((16.0, 1.0), (16.0, 0.15), (1.0, 1.0), (60.0, 1.0), (60.0, 0.05), (200.0, 0.5)):
+        u = np.zeros((n, 4), np.uint32)
+        u[:, 0] = rs.randint(1, 1 << 30, n)
+        u[:, 1] = rs.uniform(size=n) < p_need
+        u[:, 2] = rs.randint(0, 1 << 31)
+        u[:, 3] = np.float32(travel).view(np.uint32)
+        x = torch.as_tensor(u.view(np.float32), device='cuda:0').contiguous()
+        y = torch.zeros((n, 14), dtype=torch.float32, device='cuda:0')
+        _capi.check(lib, lib.s2d_debug_eval(9, x.data_ptr(), y.data_ptr(), n, None), 's2d_debug_eval')
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        need = u[:, 1] != 0
+        assert need.sum() > 0
+        coop, seq = bits(got[need, :7]), bits(got[need, 7:])
+        assert np.array_equal(coop, seq), (travel, p_need, int((coop != seq).any(axis=1).sum()), np.argwhere((coop != seq).any(axis=1))[:5].ravel())
+        assert (got[need, 12] != 0).mean() > 0.5 or travel > 100      # velocities were actually drawn
+
+
 CONFIGS = {
     'dqn-discrete16': dict(use_continuous_action=False, action_space_size=16, change_ball_velocity=True),
     'discrete7-fixed-ball': dict(use_continuous_action=False, action_space_size=7, change_ball_position=False,
