@@ -541,9 +541,9 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
   for (int t = 0; t < n_steps; ++t, row += n) {
     res = 0;
     if (n_missing >= kRefillMin) {                         // batched refill (wave-uniform counter: no ballot per cycle)
-      const bool need = active && !have_prep;
-      prep_fill_coop<NOISE>(p, rp, prep[wv], lane, need ? reset_key(e) : 0u, gl, gh, need, coop_scratch);
-      have_prep = active;
+      // (sequential draw: with ~8-20 lanes to serve, the cooperative loop's three rounds cost what their ~4 tries cost, and its
+      // registers cost the 1 M-env launch 3 %)
+      if (active && !have_prep) { prep_fill<NOISE>(p, rp, prep[wv], lane, e, gl, gh); have_prep = true; }
       n_missing = 0;
     }
     if (active) {
@@ -565,8 +565,7 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
       if (ro.result) ro.result[row + i] = (uint8_t)res;
       cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
     }
-    // samples consumed by this cycle's resets -- counted by EVERY lane of the wave (also those past the last env), so that the refill
-    // above is entered by the whole wave: its cooperative draw hands tries to all 64 lanes
+    // samples consumed by this cycle's resets -- counted by EVERY lane of the wave (also those past the last env): wave-uniform
     if (p.auto_reset) n_missing += __popcll(__ballot(active && done != 0));
     if (ro.obs) store_obs_tile(lds[wv], ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
   }
