@@ -289,6 +289,20 @@ S2D_DEV void prep_store(const S2DHot& p, const S2DRare* __restrict__ rp, float* 
   for (int k = 0; k < PS_WORDS; ++k) d[k * stride] = w[k];
   prep_tags(prep, stride)[(int64_t)(episode & 1u) * stride + i] = episode;
 }
+// the refill workgroups' form: the whole wave draws together (reset_sample_coop; `need` = this lane's slot is to be drawn)
+template <bool NOISE>
+S2D_DEV void prep_store_coop(const S2DHot& p, const S2DRare* __restrict__ rp, float* __restrict__ prep, int64_t stride, int64_t i,
+                             uint32_t gl, uint32_t gh, uint32_t episode, bool need, int lane, uint32_t* scratch) {
+  const S2DRare r = *rp;
+  const NextEpisode q = episode_prepare_coop<NOISE>(p, rp, r, gl, gh, episode, need, lane, scratch);
+  if (need) {
+    float* d = prep + (int64_t)(episode & 1u) * PS_WORDS * stride + i;
+    const float w[PS_WORDS] = {q.px, q.py, q.body, q.bx, q.by, q.bvx, q.bvy};
+#pragma unroll
+    for (int k = 0; k < PS_WORDS; ++k) d[k * stride] = w[k];
+    prep_tags(prep, stride)[(int64_t)(episode & 1u) * stride + i] = episode;
+  }
+}
 // the post-reset state from a slot: the drawn words + what every reset leaves behind (reset_apply: player at rest -- its
 // velocity stays +0 through the command-less cycle, with noise on too: the noise magnitude is proportional to the speed --
 // and the stamina model one update after a recover)
@@ -363,13 +377,18 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
     // ---- refill workgroups (see StepOut::prep), the FIRST blocks of the grid so that they start first: episode e + 2 into
     // slot e & 1 where it is missing
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t* const tags = prep_tags(o.prep, stride);
-    const uint32_t t0 = tags[i], t1 = tags[stride + i];  // both tags: no load whose address waits for another load
-    const uint32_t e2 = reinterpret_cast<const uint32_t*>(S + F_EPISODE * stride)[i] + 2u;
-    if (((e2 & 1u) ? t1 : t0) == e2) return;
+    bool need = false;
+    uint32_t e2 = 0u;
+    if (i < n) {
+      const uint32_t* const tags = prep_tags(o.prep, stride);
+      const uint32_t t0 = tags[i], t1 = tags[stride + i];  // both tags: no load whose address waits for another load
+      e2 = reinterpret_cast<const uint32_t*>(S + F_EPISODE * stride)[i] + 2u;
+      need = ((e2 & 1u) ? t1 : t0) != e2;
+    }
+    if (__ballot(need) == 0ull) return;                    // wave-uniform
     const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
-    prep_store<NOISE>(p, rp, o.prep, stride, i, (uint32_t)gid, (uint32_t)(gid >> 32), e2);
+    prep_store_coop<NOISE>(p, rp, o.prep, stride, i, (uint32_t)gid, (uint32_t)(gid >> 32), e2, need, lane,
+                           reinterpret_cast<uint32_t*>(&lds[wv][0]));   // the wave draws together: bounded number of rounds
     return;
   }
   const int main_block = (int)blockIdx.x - refill_blocks;
