@@ -1530,6 +1530,11 @@ S2D_API int s2d_set_seed(S2DHandle h, uint64_t seed) {
   if (!h) return fail(S2D_EINVAL, "NULL handle");
   h->cfg.seed = seed;
   h->hot.seed_lo = (uint32_t)seed; h->hot.seed_hi = (uint32_t)(seed >> 32);
+  // the per-step API's prepared episodes were drawn with the old key: drop their tags (s2d_set_seed has no stream argument, so
+  // this is a synchronous memset; the next s2d_step draws inline and its refill workgroups prepare the slots again)
+  DeviceGuard guard(h->device);
+  const ArenaLayout L = layout_for(h->n);
+  HIP_TRY(hipMemset(h->arena + L.prep + (size_t)2 * PS_WORDS * (size_t)h->stride * 4, 0, 2 * (size_t)h->stride * 4));
   return S2D_OK;
 }
 

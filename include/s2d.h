@@ -221,7 +221,8 @@ const char *s2d_kernel_name(S2DHandle h);
  * distance carry, [5] a non-finite observation; [6..7] reserved.  All zero for every state the engine produces. */
 int s2d_validate_state(S2DHandle h, uint32_t *counts_dev, void *stream);
 /* new Philox key for all later draws (gym's env.seed(); the reference's `random` / `np.random` are unseeded).  Takes
- * effect at the next launch; callers normally follow it with s2d_reset. */
+ * effect at the next launch (synchronises with the device once: the episodes s2d_step keeps prepared are dropped); callers
+ * normally follow it with s2d_reset. */
 int s2d_set_seed(S2DHandle h, uint64_t seed);
 /* diagnostic: evaluate one primitive of the fp32 math spec / Philox on the device so that
  * tests can compare it bit for bit with the CPU oracle.  op: 0 sincos_deg (in[n] -> out[n][2]),

@@ -321,6 +321,31 @@ def test_seed_gives_a_new_reproducible_stream():
     assert not torch.equal(a.rollout(40)['action'], rb['action']) and not torch.equal(before, ra['obs'][:8])
 
 
+def test_set_seed_drops_the_prepared_episodes(monkeypatch):
+    """s2d_set_seed without a reset: the episodes s2d_step keeps prepared in the arena were drawn with the old key and must not
+    be used.  Stepping after the new seed has to equal a fused rollout from the same state (the rollout kernels draw every
+    episode inside the launch)."""
+    from soccer2d_amd.engine import Engine, make_config
+    monkeypatch.setenv('S2D_ROLLOUT_WS', '0')
+    kw = dict(use_continuous_action=False, change_ball_velocity=True, max_steps=12, noise=False)
+    a, b = Engine(1500, 'cuda:0', cfg=make_config(seed=7, **kw)), Engine(1500, 'cuda:0', cfg=make_config(seed=7, **kw))
+    for e in (a, b):
+        e.reset()
+        for _ in range(20):
+            e.step(None)                                   # both slots of every env prepared under seed 7
+        e.set_seed(4242)
+    T = 40
+    ref = b.rollout(T)
+    obs = []
+    for _ in range(T):
+        obs.append(a.step(None)[0].clone())
+    torch.cuda.synchronize()
+    assert torch.equal(torch.stack(obs), ref['obs'])
+    assert int(ref['done'].sum()) > 3000                   # every env went through several resets under the new seed
+    for f in ('player_x', 'ball_vx', 'episode', 'step_number'):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+
+
 def test_tensor_level_hooks_restate_reach_ball():
     """The reference's extension point -- four per-env Python hooks (soccer_2d_env.py:317-354) -- at tensor level
     (soccer2d_amd.custom_task.TensorTaskEnv): ReachBallEnv's own hooks (reach_ball_env.py:87-161) written as torch ops on
