@@ -217,6 +217,20 @@ def test_step_parity(name):
 
 
 @pytest.mark.parametrize('ws', ['0', '1'])
+@pytest.mark.parametrize('n', [1, 63, 65, 130])
+def test_rollout_parity_at_ragged_sizes(n, ws, monkeypatch):
+    """Waves with one env, one missing env, one env more than a wave: the prepared episodes are drawn by the whole wave together
+    (reset_sample_coop), lanes without an env included, and must not depend on how many lanes have one."""
+    monkeypatch.setenv('S2D_ROLLOUT_WS', ws)
+    kw = dict(use_continuous_action=False, change_ball_velocity=True, max_steps=9)
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    for T in (70, 3):                                      # several episodes per env and launch, then a short launch
+        _compare_rollout(eng.rollout(T), orc.rollout(T), f'n={n} ws={ws} T={T}')
+    assert_state_same(eng, orc, f'n={n} ws={ws}')
+
+
+@pytest.mark.parametrize('ws', ['0', '1'])
 @pytest.mark.parametrize('name', ['dqn-discrete16', 'turning4', 'noise-on'])
 def test_random_policy_and_rollout_parity(name, ws, monkeypatch):
     """In-kernel Philox policy (S2D_ACT_RANDOM): per-step launches == one fused rollout launch
