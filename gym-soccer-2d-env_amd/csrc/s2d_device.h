@@ -26,11 +26,6 @@
 #include "../../include/s2d.h"
 
 #define S2D_DEV __device__ __forceinline__
-// S2D_XSKIP: timing-only experiment builds (profiles/experiments/ab_rollout.py) that drop one piece of the cycle
-// to bound what it costs -- WRONG results by construction; never defined in the product build.
-#ifndef S2D_XSKIP
-#define S2D_XSKIP 0
-#endif
 
 // action decoding mode (template parameter): reach_ball_env.py:39-47
 enum { S2D_MODE_DISCRETE = 0, S2D_MODE_CONT1 = 1, S2D_MODE_TURN4 = 2 };
@@ -322,11 +317,7 @@ S2D_DEV int judge_sq(const S2DHot& p, float px, float py, float d2, int step_num
 // ball half (o[4..9]).
 S2D_DEV float observe_player(const S2DHot& p, float px, float py, float body, float bx, float by, float* o) {
   float dx = bx - px, dy = by - py;
-#if S2D_XSKIP & 4
-  float player_to_ball = dx + dy;
-#else
   float player_to_ball = atan2_deg(dy, dx);              // :95 / :123
-#endif
   float rel = norm_deg(player_to_ball - body);           // :96 / :124
   o[0] = rel * 0.005555555555555556f;                    // :98-101  (x/180, x/52.5, x/34)
   o[1] = body * 0.005555555555555556f;
@@ -335,12 +326,8 @@ S2D_DEV float observe_player(const S2DHot& p, float px, float py, float body, fl
   return rel;
 }
 S2D_DEV void observe_ball(const S2DHot& p, float bx, float by, float bvx, float bvy, float* o) {
-#if S2D_XSKIP & 8
-  float ball_speed = bvx + bvy, ball_direction = bvx - bvy;
-#else
   float ball_speed = hypot2(bvx, bvy);                   // :91
   float ball_direction = atan2_deg(bvy, bvx);            // :92
-#endif
   o[4] = bx * p.inv_half_l;                              // :102-107  (x/52.5, x/34, x/3, x/360)
   o[5] = by * p.inv_half_w;
   o[6] = ball_speed * 0.3333333333333333f;
@@ -406,11 +393,7 @@ S2D_DEV void dash_apply(const S2DHot& p, Env& e, const CmdPrep& c, float& ax, fl
   float acc = fabsf(e.effort * power * c.dir_rate * p.dash_power_rate);
   float dir = back ? c.dir + 180.0f : c.dir;
   float sn, cs;
-#if S2D_XSKIP & 2
-  sn = dir * 0.001f; cs = 0.8f;
-#else
   sincos_deg(norm_deg(e.body + dir), sn, cs);
-#endif
   ax = acc * cs;
   ay = acc * sn;
 }
@@ -445,9 +428,6 @@ S2D_DEV void add_noise(float& vx, float& vy, float rnd, float u_mag, float sn, f
   vx += mag * cs; vy += mag * sn;
 }
 S2D_DEV void update_stamina(const S2DHot& p, Env& e) {
-#if S2D_XSKIP & 1
-  return;
-#endif
   float st = e.stamina;
   float rdec = e.recovery - p.recover_dec;
   rdec = rdec > p.recover_min ? rdec : p.recover_min;

@@ -422,11 +422,6 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
     }
     U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
     float reward, dir; int done, cmd;
-#if S2D_XSKIP & 16
-    cmd = 1; dir = e.vx; reward = e.vy; done = 0;
-    ob.o[0] = e.px; ob.o[1] = e.py; ob.o[2] = e.body; ob.o[3] = e.stamina; ob.o[4] = e.effort; ob.o[5] = e.bx; ob.o[6] = e.by;
-    ob.o[7] = e.bvx; ob.o[8] = e.bvy; ob.o[9] = e.prev_dist; e.cycle += 1;
-#else
     CmdPrep c = decide<MODE>(p, actions, kind, i, gl, gh, k, true, quad, squad, nullptr, cmd, dir);
     // A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269), as step_env(), with the reset served from the prefetched slot
     e.step_number += 1;                                  // reach_ball_env.py:55
@@ -456,7 +451,6 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
         observe_and_check(p, e, d2, ob, dn2, w2, r2);    // reach_ball_env.py:166: carry seeded, outputs dropped
       }
     }
-#endif
     env_store(e, S, stride, i);
     if (use_k) kplane[i] = k + 1u;
     o.reward[i] = reward;
@@ -1162,7 +1156,7 @@ static ArenaLayout layout_for(int64_t n) {
   return L;
 }
 
-S2D_API const char* s2d_version(void) { return "s2d-hip 0.2 (gfx950, abi 2)"; }
+S2D_API const char* s2d_version(void) { return "s2d-hip 0.3 (gfx950, abi 3)"; }
 S2D_API const char* s2d_last_error(void) { return g_err.c_str(); }
 
 S2D_API void s2d_default_config(S2DConfig* c) {
@@ -1526,15 +1520,18 @@ S2D_API int s2d_validate_state(S2DHandle h, uint32_t* counts_dev, void* stream) 
   return S2D_OK;
 }
 
-S2D_API int s2d_set_seed(S2DHandle h, uint64_t seed) {
+S2D_API int s2d_set_seed(S2DHandle h, uint64_t seed, void* stream) {
   if (!h) return fail(S2D_EINVAL, "NULL handle");
-  h->cfg.seed = seed;
-  h->hot.seed_lo = (uint32_t)seed; h->hot.seed_hi = (uint32_t)(seed >> 32);
-  // the per-step API's prepared episodes were drawn with the old key: drop their tags (s2d_set_seed has no stream argument, so
-  // this is a synchronous memset; the next s2d_step draws inline and its refill workgroups prepare the slots again)
+  // The per-step API's prepared episodes were drawn with the old key: drop their tags, stream-ordered behind every launch
+  // already queued on `stream` (the refill workgroups of an s2d_step still in flight there finish first) and ahead of the next
+  // one, which draws inline and whose refill workgroups prepare the slots again with the new key.  The key itself travels in the
+  // kernarg of later launches, so it needs no device write.  Capturable into a hipGraph like every other entry point.
   DeviceGuard guard(h->device);
   const ArenaLayout L = layout_for(h->n);
-  HIP_TRY(hipMemset(h->arena + L.prep + (size_t)2 * PS_WORDS * (size_t)h->stride * 4, 0, 2 * (size_t)h->stride * 4));
+  HIP_TRY(hipMemsetAsync(h->arena + L.prep + (size_t)2 * PS_WORDS * (size_t)h->stride * 4, 0, 2 * (size_t)h->stride * 4,
+                         static_cast<hipStream_t>(stream)));
+  h->cfg.seed = seed;
+  h->hot.seed_lo = (uint32_t)seed; h->hot.seed_hi = (uint32_t)(seed >> 32);
   return S2D_OK;
 }
 

@@ -11,7 +11,7 @@ The product path has no CPU fallback: if the HIP library is missing or does not 
 import ctypes as C
 import os
 
-S2D_ABI_VERSION = 2
+S2D_ABI_VERSION = 3
 S2D_OBS_DIM = 10
 
 # error codes
@@ -127,7 +127,7 @@ PROTOTYPES = (
     ('s2d_stats_reset', C.c_int, (C.c_void_p, C.c_void_p)),
     ('s2d_kernel_name', C.c_char_p, (C.c_void_p,)),
     ('s2d_validate_state', C.c_int, (C.c_void_p, C.c_void_p, C.c_void_p)),
-    ('s2d_set_seed', C.c_int, (C.c_void_p, C.c_uint64)),
+    ('s2d_set_seed', C.c_int, (C.c_void_p, C.c_uint64, C.c_void_p)),
     ('s2d_debug_eval', C.c_int, (C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)),
 )
 

@@ -173,9 +173,10 @@ class Engine:
         64 cycles takes ~48 us on the device, and the host must not be the slower side."""
         T, n = int(n_steps), self.num_envs
         keep, ptr, kind = self._action_arg(actions, leading=T)
-        if out is None:
+        fresh = out is None
+        if fresh:                  # a buffer nobody will pass again: never cached (the cache holds `out` alive)
             out = self.alloc_rollout(T, with_obs=with_obs)
-        cached = self._ro_cache.get(id(out))
+        cached = None if fresh else self._ro_cache.get(id(out))
         key = tuple(None if out.get(k) is None else out[k].data_ptr() for k in ('obs', 'action', 'reward', 'done', 'result'))
         if cached is None or cached[0] != key or cached[1] < T:
             ro = _capi.S2DRollout()
@@ -187,9 +188,11 @@ class Engine:
                         raise ValueError(f"rollout buffer {name!r} must be a contiguous [T>={T},{n},...] tensor on {self.device}")
                     setattr(ro, name, v.data_ptr())
                     t_min = v.shape[0] if t_min is None else min(t_min, v.shape[0])
-            if len(self._ro_cache) > 64:
-                self._ro_cache.clear()
-            cached = self._ro_cache[id(out)] = (key, T if t_min is None else t_min, ro, out)
+            cached = (key, T if t_min is None else t_min, ro, out)
+            if not fresh:
+                if len(self._ro_cache) >= 16:
+                    self._ro_cache.clear()
+                self._ro_cache[id(out)] = cached
         _capi.check(self.lib, self.lib.s2d_rollout(self._h, T, ptr, kind, C.byref(cached[2]), self._stream()), 's2d_rollout')
         self._keep = (keep, out)
         return out
@@ -244,8 +247,8 @@ class Engine:
         return dict(zip(self.VALIDATE_NAMES, c))
 
     def set_seed(self, seed):
-        """New Philox key for all later draws (takes effect at the next launch)."""
-        _capi.check(self.lib, self.lib.s2d_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF), 's2d_set_seed')
+        """New Philox key for all later draws (takes effect at the next launch; ordered on torch's current stream)."""
+        _capi.check(self.lib, self.lib.s2d_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, self._stream()), 's2d_set_seed')
         self.cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
 
     @property

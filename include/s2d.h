@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define S2D_ABI_VERSION 2
+#define S2D_ABI_VERSION 3
 
 /* ---- error codes (0 = ok, negative = failure; text via s2d_last_error()) ------------ */
 enum {
@@ -221,9 +221,10 @@ const char *s2d_kernel_name(S2DHandle h);
  * distance carry, [5] a non-finite observation; [6..7] reserved.  All zero for every state the engine produces. */
 int s2d_validate_state(S2DHandle h, uint32_t *counts_dev, void *stream);
 /* new Philox key for all later draws (gym's env.seed(); the reference's `random` / `np.random` are unseeded).  Takes
- * effect at the next launch (synchronises with the device once: the episodes s2d_step keeps prepared are dropped); callers
- * normally follow it with s2d_reset. */
-int s2d_set_seed(S2DHandle h, uint64_t seed);
+ * effect at the next launch on `stream`; stream-ordered like every other call (abi 3: the episodes s2d_step keeps prepared
+ * are dropped by a hipMemsetAsync on `stream`, behind whatever is already queued there); callers normally follow it with
+ * s2d_reset on the same stream. */
+int s2d_set_seed(S2DHandle h, uint64_t seed, void *stream);
 /* diagnostic: evaluate one primitive of the fp32 math spec / Philox on the device so that
  * tests can compare it bit for bit with the CPU oracle.  op: 0 sincos_deg (in[n] -> out[n][2]),
  * 1 atan2_deg (in[n][2]=y,x -> out[n]), 2 exp, 3 norm_deg, 4 philox4x32-10 (in = uint32[n][6]
