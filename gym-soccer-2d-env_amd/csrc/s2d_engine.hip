@@ -734,7 +734,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
       gl = (uint32_t)gid; gh = (uint32_t)(gid >> 32);
     }
-    U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
+    U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0}, nblk{0, 0, 0, 0};
     float dir = 0.0f; int cmd = 0;
     int64_t row = 0;
     // The in-engine policy of a small discrete action space picks one of n_actions decoded commands: the action map and
@@ -765,11 +765,13 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         if (MODE == S2D_MODE_TURN4) act[b][WA_CMD][lane] = __int_as_float(cmd);
         act[b][WA_POWER][lane] = c.power;
         act[b][WA_DIR][lane] = c.dir; act[b][WA_RATE][lane] = c.dir_rate;
-        if constexpr (NOISE) {                             // the state-independent half of this cycle's noise
-          const NoiseIn nz = noise_prepare(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);
-          act[b][WA_NPM][lane] = nz.pm; act[b][WA_NPS][lane] = nz.ps; act[b][WA_NPC][lane] = nz.pc;
-          act[b][WA_NBM][lane] = nz.bm; act[b][WA_NBS][lane] = nz.bs; act[b][WA_NBC][lane] = nz.bc;
-          if (MODE == S2D_MODE_TURN4) act[b][WA_NTU][lane] = nz.tu;
+        if constexpr (NOISE) {                             // the state-independent half of this cycle's noise; the sine / cosine of
+          // the whole-degree directions are entries of the table the simulating wave built before the first barrier
+          const NoiseWords nw = noise_words(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN, nblk, s == 0 || (k & 1u) == 0u);
+          const float2 ps = sc_lut[noise_dir_index(nw.wp)], bs = sc_lut[noise_dir_index(nw.wb)];
+          act[b][WA_NPM][lane] = noise_mag(nw.wp); act[b][WA_NPS][lane] = ps.x; act[b][WA_NPC][lane] = ps.y;
+          act[b][WA_NBM][lane] = noise_mag(nw.wb); act[b][WA_NBS][lane] = bs.x; act[b][WA_NBC][lane] = bs.y;
+          if (MODE == S2D_MODE_TURN4) act[b][WA_NTU][lane] = nw.tu;
         }
         row += n;
       }
@@ -810,13 +812,14 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
              e.capacity == tb->capacity[q] && e.body == rintf(e.body) && fabsf(e.body) <= 180.0f;
       }
       fast = __ballot(active && !ok) == 0ull;
-      if (fast) {
+      if (fast)
         for (int k = lane; k < tab_len; k += kWave) ep_lds[k] = tb->ep[k];
-        for (int k = lane; k <= 360; k += kWave) {
-          float sn, cs;
-          sincos_deg((float)(k - 180), sn, cs);
-          sc_lut[k] = make_float2(sn, cs);
-        }
+    }
+    if (fast || NOISE) {                                   // (sin, cos) of the whole degrees: dash directions and noise directions
+      for (int k = lane; k <= 360; k += kWave) {
+        float sn, cs;
+        sincos_deg((float)(k - 180), sn, cs);
+        sc_lut[k] = make_float2(sn, cs);
       }
     }
     __syncthreads();                                       // prepared episodes (and this wave's tables) published

@@ -87,6 +87,13 @@ def all_gather_rollout(rollout, group=None, time_major=True, out=None):
     world = dist.get_world_size(group)
     if out is None:
         out = torch.empty((world, slab.numel()), dtype=torch.uint8, device=slab.device)
+    if slab.is_cuda and dist.get_backend(group) != 'nccl':
+        # rehearsal only (several ranks on one GPU, gloo): gloo gathers host memory, so the slab is staged through the host.
+        # On the GPUs of a node the backend is "nccl" (= RCCL) and the slab travels device to device over xGMI, below.
+        host = torch.empty((world, slab.numel()), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host.view(-1), slab.cpu(), group=group)
+        out.copy_(host)
+        return _views(out, layout, world, time_major)
     dist.all_gather_into_tensor(out.view(-1), slab, group=group)
     return _views(out, layout, world, time_major)
 
@@ -105,9 +112,10 @@ class LeagueRolloutExchange:
     once, up front, two of each: nothing is allocated on the side stream, so the caching allocator never hands a block that
     compute-stream kernels still read to the next gather."""
 
-    def __init__(self, env, n_steps, group=None):
+    def __init__(self, env, n_steps, group=None, timing=False):
         import torch.distributed as dist
         self.env, self.T, self.group = env, int(n_steps), group
+        self.timings = [] if timing else None                 # (start, end) HIP events of every gather, on the side stream
         self.bufs = [env.engine.alloc_rollout(self.T, slab=True), env.engine.alloc_rollout(self.T, slab=True)]
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         nbytes = self.bufs[0]['_slab'].numel()
@@ -131,9 +139,14 @@ class LeagueRolloutExchange:
             # `ready` also orders this gather behind every read the caller queued on the compute stream from gathered[b],
             # which was handed out two calls ago
             self.side.wait_event(ready)
+            if self.timings is not None:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record(self.side)
             gathered = all_gather_rollout(buf, group=self.group, time_major=False, out=self.gathered[b])
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=self.timings is not None)
             done.record(self.side)
+            if self.timings is not None:
+                self.timings.append((t0, done))
         self._pending = (gathered, done, b)
         self.k += 1
         if prev is None:

@@ -343,7 +343,7 @@ static void cmd_turn(const P *p, Env *e, REAL moment, REAL noise_u) {
 /* MPObject::_inc for one object (accel clamp, vel += accel, speed clamp, noise, pos += vel).
  * The magnitude tests compare squares (|a|^2 > max^2), the sqrt is taken only when clamping. */
 static void obj_inc(REAL *x, REAL *y, REAL *vx, REAL *vy, int has_accel, REAL ax, REAL ay, REAL accel_max,
-                    REAL accel_max2, REAL speed_max, REAL speed_max2, int noise, REAL rnd, REAL u_mag, REAL u_ang) {
+                    REAL accel_max2, REAL speed_max, REAL speed_max2, int noise, REAL rnd, uint32_t noise_word) {
   if (has_accel) {
     REAL a2 = sq2(ax, ay);
     if (a2 > accel_max2) { REAL k = accel_max / R(sqrt)(a2); ax *= k; ay *= k; }
@@ -351,11 +351,12 @@ static void obj_inc(REAL *x, REAL *y, REAL *vx, REAL *vy, int has_accel, REAL ax
   }
   REAL s2 = sq2(*vx, *vy);
   if (s2 > speed_max2) { REAL k = speed_max / R(sqrt)(s2); *vx *= k; *vy *= k; }
-  if (noise) {
+  if (noise) {   /* polar(U(0, rand * |vel|), U(-180, 180)): magnitude from the word's high half, direction = a WHOLE degree from its low half */
     REAL s = hypot2(*vx, *vy);
+    REAL u_mag = (REAL)(noise_word >> 16) * R(1.52587890625e-05);
     REAL mag = u_mag * (rnd * s);
     REAL sn, cs;
-    sincos_deg(u_ang * R(360.0) - R(180.0), &sn, &cs);
+    sincos_deg((REAL)(int32_t)(((noise_word & 0xffffu) * 360u) >> 16) - R(180.0), &sn, &cs);
     *vx += mag * cs; *vy += mag * sn;
   }
   *x += *vx; *y += *vy;
@@ -406,20 +407,27 @@ static void update_stamina(const P *p, Env *e) {
  * (stream NOISE), those of the command-less cycle a reset consumes by the reset's own key (stream NOISE_RESET,
  * the RESET stream's counter word): like the policy draws they must not depend on whether an episode ended
  * earlier, and the state a reset leaves behind is a function of (env id, key) alone. */
+/* One Philox block serves the movement noise of TWO commanded cycles: block 0 at counter k >> 1, words (x, y) for even k, (z, w)
+ * for odd k -- one word per object (player, ball); the reset's command-less cycle takes (x, y) of the block at its own key.
+ * The turn noise is word x of block 1 at counter k. */
 static void sim_cycle(const P *p, Env *e, uint64_t gid, int cmd, REAL power, REAL dir, uint32_t noise_ctr,
                       uint32_t noise_stream) {
   uint32_t nz[4] = {0, 0, 0, 0}, nz2[4] = {0, 0, 0, 0};
+  uint32_t wp = 0, wb = 0;
   if (p->noise) {
-    draw(p->seed, gid, noise_ctr, noise_stream, 0, nz);
-    draw(p->seed, gid, noise_ctr, noise_stream, 1, nz2);
+    const int paired = noise_stream == ST_NOISE;
+    draw(p->seed, gid, paired ? noise_ctr >> 1 : noise_ctr, noise_stream, 0, nz);
+    if (cmd == S2D_CMD_TURN) draw(p->seed, gid, noise_ctr, noise_stream, 1, nz2);
+    const int odd = paired && (noise_ctr & 1u);
+    wp = odd ? nz[2] : nz[0]; wb = odd ? nz[3] : nz[1];
   }
   REAL ax = R(0.0), ay = R(0.0);
   if (cmd == S2D_CMD_DASH) cmd_dash(p, e, power, dir, &ax, &ay);
   else if (cmd == S2D_CMD_TURN) cmd_turn(p, e, dir, rnd_u01(nz2[0]));
   obj_inc(&e->px, &e->py, &e->vx, &e->vy, cmd == S2D_CMD_DASH, ax, ay, p->player_accel_max, p->player_accel_max2,
-          p->player_speed_max, p->player_speed_max2, p->noise, p->player_rand, rnd_u01(nz[0]), rnd_u01(nz[1]));
+          p->player_speed_max, p->player_speed_max2, p->noise, p->player_rand, wp);
   obj_inc(&e->bx, &e->by, &e->bvx, &e->bvy, 0, R(0.0), R(0.0), R(0.0), R(0.0),
-          p->ball_speed_max, p->ball_speed_max2, p->noise, p->ball_rand, rnd_u01(nz[2]), rnd_u01(nz[3]));
+          p->ball_speed_max, p->ball_speed_max2, p->noise, p->ball_rand, wb);
   collide(p, e);
   e->cycle = (int32_t)((uint32_t)e->cycle + 1u);        /* referee: time += 1 (wraps, never UB) */
   e->vx *= p->player_decay; e->vy *= p->player_decay;   /* _turn */

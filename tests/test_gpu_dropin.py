@@ -282,7 +282,7 @@ def test_rccl_single_rank_exchange_on_device():
             for name in ('obs', 'action', 'reward', 'done', 'result'):
                 assert got[k + 1][name].shape == (1,) + tuple(want[name].shape)
                 assert torch.equal(got[k + 1][name][0], want[name]), (k, name)
-        assert bench.max_over_ranks(dist, dev, 1.25) == 1.25                      # the timing all-reduce of bench.py, on RCCL
+        assert bench.max_over_ranks(dist, dev, [1.25, 0.5]) == [1.25, 0.5]                     # the timing all-reduce of bench.py, on RCCL
         s = all_reduce_stats(env.engine.stats)
         assert torch.equal(s, env.engine.stats)
     finally:
@@ -454,3 +454,82 @@ def test_rollout_without_out_does_not_accumulate_buffers():
     for _ in range(5):
         e.rollout(16, out=buf)
     assert len(e._ro_cache) == 1
+
+
+def _rccl_rank(rank, world, port, n, T, q):
+    """one rank of the 2-process RCCL exchange test (own GPU each)"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from soccer2d_amd.dist import LeagueRolloutExchange, make_sharded_vec_env
+    dev = torch.device('cuda', rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    env = make_sharded_vec_env(n, rank, world, device=f'cuda:{rank}', noise=False, **KW)
+    env.reset()
+    ex = LeagueRolloutExchange(env, T, timing=True)
+    got = []
+    for _ in range(3):
+        g = ex.step()
+        if g is not None:
+            got.append({k: v.cpu() for k, v in g.items()})
+    got.append({k: v.cpu() for k, v in ex.flush().items()})
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put(([{k: v.numpy() for k, v in g.items()} for g in got], ex.bytes_per_exchange, len(ex.timings)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_two_process_exchange_over_two_gpus():
+    """BASELINE configs[4] at its smallest: two processes, one GPU each, backend "nccl" (= RCCL): every exchange is ONE
+    all_gather_into_tensor of the rollout slabs on the side stream; what rank 0 receives equals one process simulating the
+    whole env range (the oracle).  Needs >= 2 GPUs; the 1-GPU pool skips it (the rehearsal test below runs there)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs')
+    import torch.multiprocessing as mp
+    n, T, world = 4096, 16, 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_rccl_rank, args=(r, world, port, n, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, nbytes, n_timed = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert nbytes['collectives'] == 1 and nbytes['received'] == world * nbytes['sent'] and n_timed == 3
+    orc = O.OracleEngine(O.make_config(noise=0, **KW), n, 'f32')
+    orc.reset()
+    for k in range(3):
+        ref = orc.rollout(T)
+        for name in ('obs', 'action', 'reward', 'done', 'result'):
+            g = got[k][name]                                              # [world, T, n / world, ...]
+            full = np.concatenate([g[r] for r in range(world)], axis=1)
+            assert np.array_equal(full.view(np.uint8), np.ascontiguousarray(ref[name]).view(np.uint8)), (k, name)
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no torch.distributed environment starts its own two ranks (children of a parent that
+    makes no GPU call) and relays rank 0's line.  On a box with one GPU that is the rehearsal (both ranks on cuda:0, gloo) and
+    the line says so; on a multi-GPU node the same command runs over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--envs', '4096', '--steps', '3', '--warmup', '1',
+                        '--repeats', '2', '--settle-ms', '0', '--league-exchange', '--no-cpu-baseline'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_envs'] == 8192 and d['value'] > 0
+    le = d['league_exchange']
+    assert le['collectives_per_exchange'] == 1 and le['bytes_received_per_rank'] == 2 * le['bytes_sent_per_rank']
+    assert le['bytes_sent_per_rank'] >= 64 * 4096 * 50 and le['value_without_exchange'] > 0
+    if torch.cuda.device_count() >= 2:
+        assert le['backend'] == 'nccl' and le['rccl_ranks'] == 2 and 'rehearsal' not in d['config']
+    else:
+        assert le['backend'] == 'gloo' and le['rccl_ranks'] == 0 and 'NOT a multi-GPU measurement' in d['config']['rehearsal']

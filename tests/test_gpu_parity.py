@@ -531,3 +531,31 @@ def test_long_run_pipeline_vs_unified_kernels(monkeypatch):
     for f in O.STATE_FIELDS:
         assert torch.equal(getattr(a, f), getattr(b, f)), f
     assert torch.equal(a.obs, b.obs) and torch.equal(a.terminal_obs, b.terminal_obs)
+
+
+@pytest.mark.parametrize('noise', [False, True])
+@pytest.mark.parametrize('case', ['every-step-ends', 'very-short', 'mixed-256', 'long-512'])
+def test_many_episodes_per_launch_in_long_launches(case, noise, monkeypatch):
+    """The four-wave pipeline prepares three episodes per env before its loop and prepares inline from the fourth on.  Launches
+    far longer than the prepared slots last, against the oracle bit for bit: (a) min_distance_to_ball beyond the pitch -> EVERY
+    step ends an episode; (b) max_steps = 2 (every env consumes a slot every third cycle); (c) the benchmark task at T = 256
+    (bench.py's default launch) with ragged N; (d) T = 512, episodes of <= 40 cycles.  (Round 3 also built an in-loop top-up of the
+    slots by the policy wave -- profiles/experiments/ws_slot_topup.patch -- which passes these same cases and was rejected on time.)"""
+    monkeypatch.setenv('S2D_ROLLOUT_WS', '1')
+    base = dict(use_continuous_action=False, action_space_size=16, change_ball_velocity=True, noise=noise)
+    kw, n, Ts = {'every-step-ends': (dict(base, min_distance_to_ball=500.0, max_steps=200), 64 * 3 + 9, (70, 33)),
+                 'very-short': (dict(base, max_steps=2), 64 * 2 + 40, (150, 64)),
+                 'mixed-256': (dict(base, max_steps=200), 64 * 9 + 1, (256, 256)),
+                 'long-512': (dict(base, max_steps=40), 64 * 4, (512, 200))}[case]
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    for T in Ts:
+        out, ref = eng.rollout(T), orc.rollout(T)
+        assert eng.kernel_name() == 's2d_reach_rollout_ws_kernel'
+        _compare_rollout(out, ref, f'{case} T={T}')
+        assert_state_same(eng, orc, f'{case} T={T}')
+        assert_same(eng.obs, orc.obs(), f'{case} T={T} last obs')
+        assert_same(eng.terminal_obs, orc.terminal_obs(), f'{case} T={T} terminal obs')
+    o1, r1, d1, s1 = eng.step(None); o2, r2, d2, s2 = orc.step(None)
+    assert_same(o1, o2, f'{case} step after'); assert_same(r1, r2, f'{case} step after reward')
+    assert int(eng.episode.min()) >= (sum(Ts) if case == 'every-step-ends' else 2)

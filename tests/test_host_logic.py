@@ -232,6 +232,63 @@ def test_bench_step_units(monkeypatch):
     assert bench.parse().settle_ms == 0.0
     calls = []
     assert bench.settle(lambda k: calls.append(k), 64, 0) == 0 and calls == []
+    # defaults per task, the rotating-buffer headline, five timed regions
+    a = bench.parse(['--task', 'match'])
+    assert a.envs == 8192 and bench.parse([]).envs == 65536 and bench.parse([]).repeats == 5 and bench.parse([]).rotate_buffers == 0
+    assert bench.n_rotating(64 * 65536 * 50) == 3 and bench.n_rotating(64 * 65536 * 50) * 64 * 65536 * 50 > (512 << 20)
+
+
+def test_bench_names_the_workload_it_runs():
+    """metric / config.workload follow --envs / --task / --league-exchange (BASELINE.json configs[1..4]); other sizes are 'custom'."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    m, w = bench.workload_of('reach_ball', 65536, 1, False)
+    assert '65536' in m and 'configs[2]' in w
+    m, w = bench.workload_of('reach_ball', 4096, 1, False)
+    assert '4096' in m and 'configs[1]' in w and '65536' not in m + w
+    m, w = bench.workload_of('match', 8192, 1, False)
+    assert '11v11' in m and 'configs[3]' in w
+    m, w = bench.workload_of('reach_ball', 65536, 8, True)
+    assert 'all-gather' in m and 'configs[4]' in w and '65536x8' in w
+    m, w = bench.workload_of('reach_ball', 1000, 1, False)
+    assert 'custom' in w and 'configs[' not in w
+
+
+def test_bench_self_launch_builds_the_torchrun_command(monkeypatch, capsys):
+    """`python bench.py --gpus N` without WORLD_SIZE: the parent counts GPUs in a child, starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>` as a child
+    process and relays exactly rank 0's JSON line; fewer GPUs than ranks -> the shared-GPU gloo rehearsal environment."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    seen = []
+
+    def fake_run(cmd, **kw):
+        seen.append((cmd, kw.get('env')))
+        if '-c' in cmd:
+            return subprocess.CompletedProcess(cmd, 0, stdout=f'{ndev}\n', stderr='')
+        return subprocess.CompletedProcess(cmd, 0, stdout='noise\n{"metric": "m", "value": 1}\n', stderr='')
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.delenv('S2D_DIST_BACKEND', raising=False)
+    ndev = 8
+    bench.main(['--gpus', '4', '--steps', '3'])
+    cmd, env = seen[-1]
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '4', '--steps', '3']
+    assert cmd[cmd.index('--master-port') + 2].endswith('bench.py') and 'S2D_DIST_BACKEND' not in env
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert capsys.readouterr().out.strip() == '{"metric": "m", "value": 1}'
+    ndev = 1
+    bench.main(['--gpus', '2'])
+    assert seen[-1][1]['S2D_DIST_BACKEND'] == 'gloo' and seen[-1][1]['S2D_BENCH_SHARE_GPU'] == '1'
+    with pytest.raises(SystemExit):
+        bench.main(['--gpus', '8'])            # 8 ranks on one card: refused (at most 6 processes may share a GPU)
+    ndev = 0
+    with pytest.raises(SystemExit):
+        bench.main(['--gpus', '2'])
 
 
 def test_logger_utils_mirror(tmp_path, monkeypatch):
