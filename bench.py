@@ -5,7 +5,7 @@ One simulator CYCLE for every env of the batch = action decode -> dash/turn -> s
 integrate -> collide -> decay -> observation -> reward/done/result -> auto-reset, with the
 rollout record of that cycle (obs[10], action, reward, done, result per env) written to HBM.
 A bench "step" (--steps K / --warmup W) is one pass of the hot path over the batch as the mode
-issues it: ONE LAUNCH of T = 64 fused cycles in the default rollout mode, one cycle in step
+issues it: ONE LAUNCH of T = 256 fused cycles (--fuse) in the default rollout mode, one cycle in step
 mode.  `value` is env-steps (env-cycles) per second in every mode: N envs x cycles / seconds.
 Inputs are resident in HBM before the timed region; nothing is copied to the host inside it.
 
@@ -63,11 +63,11 @@ REPEATS = 5
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=None, help='timed bench steps per region (default 64 launches; 4096 in step mode)')
+    ap.add_argument('--steps', type=int, default=None, help='timed bench steps per region (default 32 launches; 4096 in step mode)')
     ap.add_argument('--warmup', type=int, default=None, help='untimed bench steps (default 4 launches; 256 in step mode)')
     ap.add_argument('--envs', type=int, default=None, help='envs per GPU (default 65 536; 8 192 matches for --task match)')
     ap.add_argument('--mode', choices=('rollout', 'step', 'graph'), default='rollout')
-    ap.add_argument('--fuse', type=int, default=64, help='cycles per launch (rollout) / per graph (graph)')
+    ap.add_argument('--fuse', type=int, default=256, help='cycles per launch (rollout) / per graph (graph); 256 = a 256-step rollout per launch')
     ap.add_argument('--noise', action='store_true', help='player_rand/ball_rand Philox noise on (the drop-in default of the product)')
     ap.add_argument('--task', choices=('reach_ball', 'match'), default='reach_ball',
                     help='reach_ball = the BASELINE.json metric (default); match = 11v11 engine, configs[3] (8 192 matches)')
@@ -90,7 +90,7 @@ def parse(argv=None):
     args = ap.parse_args(argv)
     per_cycle = args.mode == 'step'
     if args.steps is None:
-        args.steps = 4096 if per_cycle else 64
+        args.steps = 4096 if per_cycle else 32
     if args.warmup is None:
         args.warmup = 256 if per_cycle else 4
     if args.envs is None:
@@ -699,9 +699,13 @@ def secondary_measurements(args, dev, stream, rank, n, T, line, out):
     line['noise_on']['config'] = 'same workload with player_rand 0.1 / ball_rand 0.05 (make_config default)'
     del eng
     eng = reach_engine(n, dev, rank, False)
-    m = measure_rollout(eng, T, 64, 1, R, stream, args.settle_ms)
-    out['rollout_one_buffer'] = rollout_entry(m, n, T, eng.kernel_name(), 'rollout')
-    out['rollout_one_buffer']['note'] = 'the record re-writes ONE 218.6 MB buffer, which the 256 MiB Infinity Cache can hold (rounds 1-2 headline)'
+    # the rounds 1-2 launch shape: 64 cycles per launch, (a) into rotating buffers, (b) re-writing ONE 218.6 MB buffer, which the
+    # 256 MiB Infinity Cache can hold (the rounds 1-2 headline)
+    m = measure_rollout(eng, 64, 64, n_rotating(64 * n * RECORD_BYTES), R, stream, args.settle_ms)
+    out['rollout_T64_rotating'] = rollout_entry(m, n, 64, eng.kernel_name(), 'rollout-rotate')
+    m = measure_rollout(eng, 64, 64, 1, R, stream, args.settle_ms)
+    out['rollout_T64_one_buffer'] = rollout_entry(m, n, 64, eng.kernel_name(), 'rollout')
+    out['rollout_T64_one_buffer']['note'] = 'the record re-writes ONE 218.6 MB buffer, which the 256 MiB Infinity Cache can hold (rounds 1-2 headline)'
     # per-step API (what an SB3-style learner drives), 2 048 launches per region
     out['step_api'] = measure_steps(eng, 2048, R, stream, args.settle_ms)
     acts = torch.randint(0, DQN_KWARGS['action_space_size'], (n,), device=dev, dtype=torch.int32)
@@ -710,13 +714,13 @@ def secondary_measurements(args, dev, stream, rank, n, T, line, out):
     del eng
     # BASELINE configs[1]: 4 096 envs (64 workgroups on 256 CUs: chain-latency-bound)
     eng = reach_engine(4096, dev, rank, False)
-    m = measure_rollout(eng, T, 64, 2, R, stream, args.settle_ms)
+    m = measure_rollout(eng, T, 32, 2, R, stream, args.settle_ms)
     out['reach_ball_4096'] = rollout_entry(m, 4096, T, eng.kernel_name(), None)
     out['reach_ball_4096']['workload'] = workload_of('reach_ball', 4096, 1, False)[1]
     out['reach_ball_4096']['step_api'] = measure_steps(eng, 2048, R, stream, args.settle_ms)
     del eng
     # BASELINE configs[3]: 11v11, 8 192 matches
-    mm = measure_match(8192, dev, rank, T, 16, R, stream, args.settle_ms, phase='spread')
+    mm = measure_match(8192, dev, rank, 64, 16, R, stream, args.settle_ms, phase='spread')
     mm.pop('wall', None)
     mm['workload'] = workload_of('match', 8192, 1, False)[1]
     out['match_8192'] = mm
@@ -724,7 +728,7 @@ def secondary_measurements(args, dev, stream, rank, n, T, line, out):
 
 def run_match(args, dev, dist, rank, world):
     import torch
-    n, T = args.envs, max(1, args.fuse)
+    n, T = args.envs, max(1, args.fuse if args.fuse != 256 else 64)     # the 11v11 rollout record is 489 B per match-step: 64 cycles per launch
     stream = torch.cuda.current_stream(dev)
     metric, workload = workload_of('match', n, world, False)
     mm = measure_match(n, dev, rank, T, args.steps, args.repeats, stream, args.settle_ms, noise=args.noise,

@@ -171,6 +171,11 @@ template <int MODE>
 S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int kind, int64_t idx, uint32_t gid_lo,
                        uint32_t gid_hi, uint32_t k, bool refresh, U4& quad, U4& squad, void* __restrict__ action_out,
                        int& cmd, float& dir) {
+  if (kind == S2D_ACT_COMMAND) {                           // a decoded body command, executed as it is (wave-uniform branch)
+    const float4 v = static_cast<const float4*>(actions)[idx];
+    cmd = (int)v.x; dir = v.z;
+    return cmd_prepare(p, cmd, v.y, v.z);
+  }
   Action4 a = (kind == S2D_ACT_RANDOM) ? random_action<MODE>(p, gid_lo, gid_hi, k, quad, refresh)
                                        : load_action<MODE>(actions, kind, idx);
   if (action_out) store_rollout_action<MODE>(action_out, idx, a);
@@ -423,41 +428,46 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
     U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
     float reward, dir; int done, cmd;
     CmdPrep c = decide<MODE>(p, actions, kind, i, gl, gh, k, true, quad, squad, nullptr, cmd, dir);
-    // A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269), as step_env(), with the reset served from the prefetched slot
-    e.step_number += 1;                                  // reach_ball_env.py:55
-    NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (NOISE) nz = noise_prepare(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);
-    float d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);   // trainer forces PlayOn each cycle (:242)
-    observe_and_check(p, e, d2, ob, done, reward, res);
-    if (done && p.auto_reset) {                          // SB3 VecEnv convention
-      float* const terminal_row = o.terminal_obs + i * S2D_OBS_DIM;
+    if (kind == S2D_ACT_COMMAND && cmd < 0) {              // S2D_CMD_FREEZE: not part of this cycle -- keep state, outputs and the row
 #pragma unroll
-      for (int w = 0; w < S2D_OBS_DIM; ++w) terminal_row[w] = ob.o[w];
-      const bool odd = (((uint32_t)e.episode + 1u) & 1u) != 0u;
-      const uint32_t ptag = odd ? ptag1 : ptag0;
-      float pw[PS_WORDS];
+      for (int w = 0; w < S2D_OBS_DIM; ++w) ob.o[w] = o.obs[i * S2D_OBS_DIM + w];
+    } else {
+      // A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269), as step_env(), with the reset served from the prefetched slot
+      e.step_number += 1;                                  // reach_ball_env.py:55
+      NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      if (NOISE) nz = noise_prepare(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);
+      float d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);   // trainer forces PlayOn each cycle (:242)
+      observe_and_check(p, e, d2, ob, done, reward, res);
+      if (done && p.auto_reset) {                          // SB3 VecEnv convention
+        float* const terminal_row = o.terminal_obs + i * S2D_OBS_DIM;
 #pragma unroll
-      for (int w = 0; w < PS_WORDS; ++w) pw[w] = odd ? pw1[w] : pw0[w];
-      if (ptag == (uint32_t)e.episode + 1u) {            // prepared: a copy + the words that follow from it
-        const NextEpisode q = prep_episode(p, rp, pw);
-        episode_begin(e, q);
-        const FirstObs f = first_obs(p, q);
+        for (int w = 0; w < S2D_OBS_DIM; ++w) terminal_row[w] = ob.o[w];
+        const bool odd = (((uint32_t)e.episode + 1u) & 1u) != 0u;
+        const uint32_t ptag = odd ? ptag1 : ptag0;
+        float pw[PS_WORDS];
 #pragma unroll
-        for (int w = 0; w < S2D_OBS_DIM; ++w) ob.o[w] = f.o[w];
-        e.prev_dist = f.dist; e.prev_angle = f.rel;      // reach_ball_env.py:166: carry seeded
-      } else {                                           // slot not (yet) valid: draw it here
-        d2 = env_reset<NOISE>(p, rp, e, gl, gh);
-        int dn2, r2; float w2;
-        observe_and_check(p, e, d2, ob, dn2, w2, r2);    // reach_ball_env.py:166: carry seeded, outputs dropped
+        for (int w = 0; w < PS_WORDS; ++w) pw[w] = odd ? pw1[w] : pw0[w];
+        if (ptag == (uint32_t)e.episode + 1u) {            // prepared: a copy + the words that follow from it
+          const NextEpisode q = prep_episode(p, rp, pw);
+          episode_begin(e, q);
+          const FirstObs f = first_obs(p, q);
+#pragma unroll
+          for (int w = 0; w < S2D_OBS_DIM; ++w) ob.o[w] = f.o[w];
+          e.prev_dist = f.dist; e.prev_angle = f.rel;      // reach_ball_env.py:166: carry seeded
+        } else {                                           // slot not (yet) valid: draw it here
+          d2 = env_reset<NOISE>(p, rp, e, gl, gh);
+          int dn2, r2; float w2;
+          observe_and_check(p, e, d2, ob, dn2, w2, r2);    // reach_ball_env.py:166: carry seeded, outputs dropped
+        }
       }
+      env_store(e, S, stride, i);
+      if (use_k) kplane[i] = k + 1u;
+      o.reward[i] = reward;
+      o.done[i] = (uint8_t)done;
+      o.result[i] = (uint8_t)res;
+      o.action_dir[i] = dir;
+      o.action_cmd[i] = (uint8_t)cmd;
     }
-    env_store(e, S, stride, i);
-    if (use_k) kplane[i] = k + 1u;
-    o.reward[i] = reward;
-    o.done[i] = (uint8_t)done;
-    o.result[i] = (uint8_t)res;
-    o.action_dir[i] = dir;
-    o.action_cmd[i] = (uint8_t)cmd;
   }
   int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
   store_obs_tile(lds[wv], ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, (int)rows * S2D_OBS_DIM);
@@ -1410,6 +1420,9 @@ static int check_action_kind(const S2DEngine* h, const void* actions, int kind) 
       break;
     case S2D_ACT_RANDOM:
       return S2D_OK;
+    case S2D_ACT_COMMAND:
+      if (reinterpret_cast<uintptr_t>(actions) & 15u) return fail(S2D_EINVAL, "float[N][4] commands must be 16-byte aligned");
+      break;
     default:
       return fail(S2D_EINVAL, "unknown action_kind");
   }
@@ -1453,6 +1466,7 @@ S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int a
                         void* stream) {
   if (!h) return fail(S2D_EINVAL, "NULL handle");
   if (n_steps < 0) return fail(S2D_EINVAL, "n_steps must be >= 0");
+  if (action_kind == S2D_ACT_COMMAND) return fail(S2D_EINVAL, "S2D_ACT_COMMAND is a per-step action kind (s2d_step)");
   int rc = check_action_kind(h, actions_dev, action_kind);
   if (rc != S2D_OK) return rc;
   if (n_steps == 0) return S2D_OK;

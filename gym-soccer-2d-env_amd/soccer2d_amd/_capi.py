@@ -21,8 +21,8 @@ MODE_BEFORE_KICK_OFF, MODE_TIME_OVER, MODE_PLAY_ON = 0, 1, 2
 SIDE_UNKNOWN, SIDE_LEFT, SIDE_RIGHT = 0, 1, 2
 RESULT_NONE, RESULT_GOAL, RESULT_OUT, RESULT_TIMEOUT = 0, 1, 2, 3
 RESULT_NAMES = (None, 'Goal', 'Out', 'Timeout')   # info['result'], reach_ball_env.py:126-150
-CMD_NONE, CMD_DASH, CMD_TURN = 0, 1, 2
-ACT_DISCRETE_I32, ACT_DISCRETE_I64, ACT_CONTINUOUS, ACT_TURNING, ACT_RANDOM = 0, 1, 2, 3, 4
+CMD_NONE, CMD_DASH, CMD_TURN, CMD_FREEZE = 0, 1, 2, -1
+ACT_DISCRETE_I32, ACT_DISCRETE_I64, ACT_CONTINUOUS, ACT_TURNING, ACT_RANDOM, ACT_COMMAND = 0, 1, 2, 3, 4, 5
 
 
 class S2DLibraryError(RuntimeError):

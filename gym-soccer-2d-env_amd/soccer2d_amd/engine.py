@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _capi
-from ._capi import (ACT_CONTINUOUS, ACT_DISCRETE_I32, ACT_DISCRETE_I64, ACT_RANDOM, ACT_TURNING,
+from ._capi import (ACT_COMMAND, ACT_CONTINUOUS, ACT_DISCRETE_I32, ACT_DISCRETE_I64, ACT_RANDOM, ACT_TURNING,
                     BUFFER_FIELDS, S2D_OBS_DIM, WORLD_MODEL_FIELDS)
 
 _TORCH_DTYPES = {'float32': torch.float32, 'int32': torch.int32, 'uint8': torch.uint8, 'int64': torch.int64}
@@ -163,6 +163,16 @@ class Engine:
         keep, ptr, kind = self._action_arg(actions)
         _capi.check(self.lib, self.lib.s2d_step(self._h, ptr, kind, self._stream()), 's2d_step')
         self._keep = keep
+        return self.obs, self.reward, self.done, self.result
+
+    def step_commands(self, commands):
+        """One cycle with a decoded body command per env: float32 [N, 4] = (S2D_CMD_* 0 none / 1 dash / 2 turn, power, relative
+        direction, 0), executed as it is (S2D_ACT_COMMAND) -- the boundary of the reference's `action_to_rpc_actions` hook."""
+        c = torch.as_tensor(commands, device=self.device).to(torch.float32).contiguous()
+        if tuple(c.shape) != (self.num_envs, 4):
+            raise ValueError(f"commands must have shape ({self.num_envs}, 4), got {tuple(c.shape)}")
+        _capi.check(self.lib, self.lib.s2d_step(self._h, C.c_void_p(c.data_ptr()), ACT_COMMAND, self._stream()), 's2d_step')
+        self._keep = c
         return self.obs, self.reward, self.done, self.result
 
     def rollout(self, n_steps, actions=None, out=None, with_obs=True):

@@ -88,6 +88,6 @@ class StateView(_Node):
                     continue
                 node = node._kids.setdefault(p, _Node())
             v = t[index]
-            if v.dim() > 0:
+            if getattr(v, 'ndim', 0) > 0:                  # player tables [N, 11, ...]: the one filled row
                 v = v[0]
             node._kids[parts[-1]] = v.item()

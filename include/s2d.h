@@ -54,7 +54,9 @@ enum { S2D_SIDE_UNKNOWN = 0, S2D_SIDE_LEFT = 1, S2D_SIDE_RIGHT = 2 };
 /* info['result'] labels, reach_ball_env.py:126-150 (None / 'Goal' / 'Out' / 'Timeout') */
 enum { S2D_RESULT_NONE = 0, S2D_RESULT_GOAL = 1, S2D_RESULT_OUT = 2, S2D_RESULT_TIMEOUT = 3 };
 /* low-level body commands = PlayerAction oneof members, idl/service.proto:380-397 */
-enum { S2D_CMD_NONE = 0, S2D_CMD_DASH = 1, S2D_CMD_TURN = 2 };
+enum { S2D_CMD_NONE = 0, S2D_CMD_DASH = 1, S2D_CMD_TURN = 2,
+       S2D_CMD_FREEZE = -1 /* S2D_ACT_COMMAND only: this env does not take part in the cycle (state and outputs stay as they are) --
+                            * how a host mirror lets ONE env of a batch consume its reset cycle (soccer_2d_env.py:187-197) */ };
 
 /* how `actions_dev` of s2d_step / s2d_rollout is laid out (reach_ball_env.py:39-47, 53-85) */
 enum {
@@ -62,7 +64,13 @@ enum {
   S2D_ACT_DISCRETE_I64 = 1, /* int64[N]    same, torch's default integer dtype           */
   S2D_ACT_CONTINUOUS = 2,   /* float[N][1] Box(-1,1,(1,))  rel_dir = a*180 (not clipped) */
   S2D_ACT_TURNING = 3,      /* float[N][4] Box(-1,1,(4,))  [turn_p, turn_a, dash_p, dash_a] */
-  S2D_ACT_RANDOM = 4        /* NULL: uniform random policy drawn in-kernel (Philox)      */
+  S2D_ACT_RANDOM = 4,       /* NULL: uniform random policy drawn in-kernel (Philox)      */
+  /* float[N][4] = {S2D_CMD_*, power, relative direction, 0}: one decoded PlayerAction body command per env, executed as it is
+   * (what the proxy does with `ignore_preprocess=True`, server.py:64) -- the boundary of the reference's task HOOK
+   * `action_to_rpc_actions` (soccer_2d_env.py:317-325): a user-defined task env builds pb2.PlayerAction objects in Python and the
+   * host mirror turns them into this array.  Accepted by s2d_step in every task mode (16-byte aligned); not by s2d_rollout.
+   * (The env-step counter of the episode statistics counts every env of the launch, frozen ones included.) */
+  S2D_ACT_COMMAND = 5
 };
 
 /* ---- configuration -------------------------------------------------------------------- */

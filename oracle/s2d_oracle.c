@@ -528,6 +528,7 @@ static void fetch_action(const S2DOEngine *h, int64_t i, const void *actions, in
     case S2D_ACT_DISCRETE_I64: a[0] = (REAL)((const int64_t *)actions)[i]; break;
     case S2D_ACT_CONTINUOUS: a[0] = (REAL)((const float *)actions)[i]; break;
     case S2D_ACT_TURNING: for (int j = 0; j < 4; ++j) a[j] = (REAL)((const float *)actions)[i * 4 + j]; break;
+    case S2D_ACT_COMMAND: break;                         /* decoded by step_one */
     default: {
       if (!p->use_continuous) a[0] = (REAL)rnd_below(quad_word(p->seed, gid, k, ST_POLICY), (uint32_t)p->n_actions);
       else if (!p->use_turning) a[0] = rnd_u01(quad_word(p->seed, gid, k, ST_POLICY)) * R(2.0) - R(1.0);
@@ -553,6 +554,7 @@ static void step_one(S2DOEngine *h, int64_t i, const void *actions, int kind, vo
   uint64_t gid = (uint64_t)(p->env_id_offset + i);
   REAL a[4];
   const int turning = p->use_continuous && p->use_turning;
+  if (kind == S2D_ACT_COMMAND && ((const float *)actions)[4 * i] < 0.0f) return;   /* S2D_CMD_FREEZE: not part of this cycle */
   fetch_action(h, i, actions, kind, e->policy_step, a, rollout_action_out);
   e->step_number += 1;                                   /* reach_ball_env.py:55 */
   const uint32_t k = e->policy_step;
@@ -560,6 +562,10 @@ static void step_one(S2DOEngine *h, int64_t i, const void *actions, int kind, vo
   if (turning) u = rnd_u01(quad_word(p->seed, gid, k, ST_SELECT));
   if (turning || kind == S2D_ACT_RANDOM || p->noise) e->policy_step += 1u;
   int cmd; REAL power, dir;
+  if (kind == S2D_ACT_COMMAND) {                         /* a decoded PlayerAction body command, executed as it is (server.py:64) */
+    const float *c4 = (const float *)actions + 4 * i;
+    cmd = (int)c4[0]; power = (REAL)c4[1]; dir = (REAL)c4[2];
+  } else
   action_map(p, a, u, &cmd, &power, &dir);               /* :238 */
   h->action_cmd[i] = (uint8_t)cmd; h->action_dir[i] = dir;
   sim_cycle(p, e, gid, cmd, power, dir, k, ST_NOISE);    /* rcssserver cycle; trainer forces PlayOn :242 */

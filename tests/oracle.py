@@ -248,6 +248,12 @@ class OracleEngine:
         self.L.s2do_step(self.h, a.ctypes.data if a is not None else None, kind)
         return self.obs(), self.reward(), self.done(), self.result()
 
+    def step_commands(self, commands):
+        a = np.ascontiguousarray(commands, dtype=np.float32)
+        assert a.shape == (self.n, 4)
+        self.L.s2do_step(self.h, a.ctypes.data, _capi.ACT_COMMAND)
+        return self.obs(), self.reward(), self.done(), self.result()
+
     def rollout(self, T, actions=None):
         kind, a = self._kind_and_array(actions, self.cfg)
         n, real = self.n, self.L._np_real

@@ -533,3 +533,133 @@ def test_bench_self_launches_its_ranks(tmp_path):
         assert le['backend'] == 'nccl' and le['rccl_ranks'] == 2 and 'rehearsal' not in d['config']
     else:
         assert le['backend'] == 'gloo' and le['rccl_ranks'] == 0 and 'NOT a multi-GPU measurement' in d['config']['rehearsal']
+
+
+def test_command_action_kind_equals_the_oracle():
+    """S2D_ACT_COMMAND (the boundary of the reference's action_to_rpc_actions hook): a decoded body command per env -- dash with any
+    power / direction, turn, none, and S2D_CMD_FREEZE (the env sits the cycle out) -- executed as it is; GPU == oracle bit for bit,
+    noise off and on, in a dash-only and in the turning task mode."""
+    from soccer2d_amd.engine import Engine, make_config
+    rs = np.random.RandomState(3)
+    for kw in (dict(use_continuous_action=False, noise=False), dict(use_continuous_action=True, use_turning=True, noise=True)):
+        n = 777
+        eng = Engine(n, 'cuda:0', cfg=make_config(auto_reset=False, **kw))
+        orc = O.OracleEngine(O.make_config(auto_reset=0, **{k: (int(v) if k == 'noise' else v) for k, v in kw.items()}), n, 'f32')
+        eng.reset(); orc.reset()
+        for t in range(40):
+            c = np.zeros((n, 4), np.float32)
+            c[:, 0] = rs.choice([-1, 0, 1, 1, 1, 2], n)
+            c[:, 1] = rs.uniform(-120, 120, n)
+            c[:, 2] = rs.uniform(-200, 200, n)
+            obs, rew, done, res = eng.step_commands(c)
+            o_obs, o_rew, o_done, o_res = orc.step_commands(c)
+            torch.cuda.synchronize()
+            assert np.array_equal(obs.cpu().numpy().view(np.int32), o_obs.view(np.int32)), (kw, t)
+            assert np.array_equal(rew.cpu().numpy().view(np.int32), o_rew.view(np.int32)), (kw, t)
+        for f in O.STATE_FIELDS:
+            g, r = getattr(eng, f).cpu().numpy(), orc.state(f)
+            assert np.array_equal(g.view(np.int32) if g.dtype == np.float32 else g, r.view(np.int32) if r.dtype == np.float32 else r), (kw, f)
+        frozen = eng.cycle.cpu().numpy()
+        assert frozen.min() < frozen.max()                 # frozen envs really sat cycles out
+        import ctypes as C
+        from soccer2d_amd import _capi
+        c4 = torch.zeros((4, n, 4), device='cuda:0')
+        assert eng.lib.s2d_rollout(eng._h, 4, C.c_void_p(c4.data_ptr()), _capi.ACT_COMMAND, None, None) == _capi.S2D_EINVAL   # per-step kind only
+
+
+def _copy_state(src, dst, env):
+    """post-reset state of a hook env's engine (index 0) -> a fused one-env engine, reward carry from the hook env's Python fields"""
+    for f in ('player_x', 'player_y', 'player_vx', 'player_vy', 'player_body', 'stamina', 'effort', 'recovery', 'stamina_capacity',
+              'ball_x', 'ball_y', 'ball_vx', 'ball_vy'):
+        getattr(dst, f)[0] = getattr(src, f)[0]
+    dst.step_number[0] = 0
+    dst.prev_dist[0] = float(np.float32(env.last_dist))
+    dst.prev_angle[0] = float(np.float32(env.last_rel))
+
+
+def test_reference_style_hook_env_equals_the_fused_task():
+    """A task env written against the REFERENCE's plugin protocol (tests/hook_reach_ball.py: the four hooks of
+    soccer_2d_env.py:317-354, service_pb2 messages out, pb2.State attribute paths in) runs on the mirror's hook path; started
+    from the same post-reset state and driven with the same actions, the fused reach_ball kernels return the same observations
+    (2e-6), rewards (1e-4 relative to their size), done flags and result labels, episode after episode."""
+    from hook_reach_ball import HookReachBall
+    from soccer2d_amd.engine import Engine, make_config
+    HookReachBall.rng_seed = 11
+    env = HookReachBall(noise=False)
+    assert type(env).overrides_task_hooks() and env.vec is None
+    fused = Engine(1, 'cuda:0', cfg=make_config(auto_reset=False, noise=False, **KW))
+    fused.reset()
+    rs = np.random.RandomState(2)
+    labels = {None: 0, 'Goal': 1, 'Out': 2, 'Timeout': 3}
+    seen = set()
+    for ep in range(6):
+        obs = env.reset()
+        assert obs.shape == (10,) and obs.dtype == np.float64
+        _copy_state(env._hooks.engine, fused, env)
+        steer = ep % 2 == 0
+        for t in range(230):
+            a = int(round(((obs[0] * 180.0 + 180.0) % 360.0) / 22.5)) % 16 if steer else int(rs.randint(16))
+            obs, rew, done, info = env.step(a)
+            f_obs, f_rew, f_done, f_res = fused.step(torch.tensor([a], dtype=torch.int32, device='cuda:0'))
+            torch.cuda.synchronize()
+            assert np.allclose(obs, f_obs[0].cpu().numpy().astype(np.float64), atol=2e-6), (ep, t)
+            assert abs(rew - float(f_rew[0])) <= 1e-4 * max(1.0, abs(rew)), (ep, t, rew, float(f_rew[0]))
+            assert bool(done) == bool(f_done[0]) and labels[info['result']] == int(f_res[0]), (ep, t, info)
+            if done:
+                seen.add(info['result'])
+                break
+        assert done
+    assert 'Goal' in seen and ('Timeout' in seen or 'Out' in seen)
+    env.close()
+
+
+def test_hook_vec_env_instances_keep_their_own_clocks():
+    """HookVecEnv: several instances of a hook-based env on ONE engine.  An instance that resets consumes its command-less cycle
+    while the others are frozen, so every instance sees exactly what it sees when it runs alone (same reset draws, same actions)."""
+    from hook_reach_ball import HookReachBall
+    from soccer2d_amd.hook_env import HookVecEnv
+
+    class Short(HookReachBall):
+        step_limit = 9
+
+    n, T = 4, 45
+    acts = np.random.RandomState(5).randint(0, 16, (T, n))
+
+    def seeded(i):
+        return type(f'Short{i}', (Short,), {'rng_seed': 100 + i})
+    alone = []
+    for i in range(n):
+        e = seeded(i)(noise=False)
+        o = e.reset()
+        tr = [o]
+        for t in range(T):
+            o, r, d, inf = e.step(int(acts[t, i]))
+            tr.append((o, r, d, inf['result']))
+            if d:
+                o = e.reset()
+                tr.append(o)
+        alone.append(tr)
+        e.close()
+    Short.rng_seed = None
+    vec = HookVecEnv(Short, n, noise=False)
+    for i, e in enumerate(vec.envs):
+        import random
+        e.rng = random.Random(100 + i)
+    together = [[o] for o in vec.reset()]
+    for t in range(T):
+        obs, rew, done, info = vec.step([int(a) for a in acts[t]])
+        for i in range(n):
+            if done[i]:
+                together[i].append((info[i]['terminal_observation'], rew[i], True, info[i]['result']))
+                together[i].append(obs[i])
+            else:
+                together[i].append((obs[i], rew[i], False, info[i]['result']))
+    for i in range(n):
+        assert len(alone[i]) == len(together[i]), i
+        for x, y in zip(alone[i], together[i]):
+            if isinstance(x, tuple):
+                assert np.array_equal(x[0], y[0]) and x[1] == y[1] and x[2] == y[2] and x[3] == y[3], i
+            else:
+                assert np.array_equal(x, y), i
+    assert sum(1 for x in together[0] if isinstance(x, tuple) and x[2]) >= 3      # several episodes each
+    vec.close()

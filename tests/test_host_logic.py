@@ -216,9 +216,9 @@ def test_bench_step_units(monkeypatch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.syspath_prepend(root)
     bench = importlib.import_module('bench')
-    for argv, want in ((['bench.py'], (64, 4, 64)), (['bench.py', '--mode', 'step'], (4096, 256, 1)),
+    for argv, want in ((['bench.py'], (32, 4, 256)), (['bench.py', '--mode', 'step'], (4096, 256, 1)),
                        (['bench.py', '--steps', '5', '--warmup', '1', '--fuse', '32'], (5, 1, 32)),
-                       (['bench.py', '--mode', 'graph', '--steps', '7'], (7, 4, 64))):
+                       (['bench.py', '--mode', 'graph', '--steps', '7'], (7, 4, 256))):
         monkeypatch.setattr(_sys, 'argv', argv)
         a = bench.parse()
         assert (a.steps, a.warmup, a.cycles_per_step) == want
@@ -312,3 +312,36 @@ def test_logger_utils_mirror(tmp_path, monkeypatch):
     for name in ('S2DTestLogger', 'S2DTestLogger2'):
         for h in list(logging.getLogger(name).handlers):
             h.close(); logging.getLogger(name).removeHandler(h)
+
+
+def test_service_pb2_messages_and_command_translation():
+    """The light service_pb2 the hook path ships: keyword constructors, proto3 defaults, oneof bookkeeping, enum values of
+    idl/service.proto:267-301; and what the mirror makes of a hook's PlayerAction (one body command per cycle)."""
+    sys.path.insert(0, os.path.join(ROOT, 'gym-soccer-2d-env_amd'))
+    import service_pb2 as pb2
+    from soccer2d_amd import _capi
+    from soccer2d_amd.hook_env import command_of
+    a = pb2.PlayerAction(dash=pb2.Dash(power=100, relative_direction=22.5))
+    assert a.WhichOneof('action') == 'dash' and a.HasField('dash') and not a.HasField('turn') and a.turn.relative_direction == 0.0
+    a.turn = pb2.Turn(relative_direction=-30.0)                          # a oneof keeps one member
+    assert a.WhichOneof('action') == 'turn' and not a.HasField('dash')
+    assert command_of(a) == (_capi.CMD_TURN, 0.0, -30.0)
+    assert command_of(pb2.PlayerAction(dash=pb2.Dash(power=55, relative_direction=90))) == (_capi.CMD_DASH, 55.0, 90.0)
+    assert command_of(pb2.PlayerAction(body_hold_ball=pb2.Body_HoldBall())) == (_capi.CMD_NONE, 0.0, 0.0)
+    assert command_of(pb2.PlayerAction()) == (_capi.CMD_NONE, 0.0, 0.0) and command_of(None)[0] == _capi.CMD_NONE
+    assert command_of([pb2.PlayerAction(turn_neck=pb2.TurnNeck(moment=10)), a]) == (_capi.CMD_TURN, 0.0, -30.0)
+    with pytest.raises(NotImplementedError):
+        command_of(pb2.PlayerAction(kick=pb2.Kick(power=100, relative_direction=0)))
+    with pytest.raises(NotImplementedError):
+        command_of(pb2.PlayerAction(body_go_to_point={}))                # a helios behaviour: accepted as a message, not executable
+    with pytest.raises(AttributeError):
+        pb2.Dash(powr=1)
+    t = pb2.TrainerAction(do_move_player=pb2.DoMovePlayer(our_side=True, uniform_number=1, position=pb2.RpcVector2D(x=3, y=-4), body_direction=270))
+    assert t.WhichOneof('action') == 'do_move_player' and t.do_move_player.position.y == -4 and t.do_move_ball.velocity.x == 0.0
+    g = pb2.GameModeType
+    assert (g.BeforeKickOff, g.PlayOn, g.KickOff_, g.OffSide_, g.FirstHalfOver, g.BackPass_, g.FreeKickFault_, g.CatchFault_, g.IndFreeKick_,
+            g.PenaltySetup_, g.GoalieCatch_, g.MODE_MAX) == (0, 2, 3, 9, 11, 18, 19, 20, 21, 22, 30, 32)
+    assert (pb2.Side.UNKNOWN, pb2.Side.LEFT, pb2.Side.RIGHT) == (0, 1, 2)
+    import soccer_2d_env
+    from sample_environments.reach_ball_env import ReachBallEnv
+    assert not soccer_2d_env.Soccer2DEnv.overrides_task_hooks() and not ReachBallEnv.overrides_task_hooks()   # the fused tasks
