@@ -435,7 +435,8 @@ def measure_match(n, dev, rank, T, launches, repeats, stream, settle_ms, noise=F
     """11v11 engine: `launches` rollout launches of T cycles (or single-cycle launches in step mode) per region."""
     import torch
     from soccer2d_amd.match import MatchEngine, make_match_config
-    eng = MatchEngine(n, dev, cfg=make_match_config(env_id_offset=rank * n, noise=noise))
+    extra = json.loads(os.environ.get('S2D_MATCH_KW', '{}'))            # experiments: match parameter overrides
+    eng = MatchEngine(n, dev, cfg=make_match_config(env_id_offset=rank * n, noise=noise, **extra))
     eng.reset()
     if phase == 'spread':
         # every match at its own (even) match time in the first half: half-time and time-over restarts -- and the ~120 expensive

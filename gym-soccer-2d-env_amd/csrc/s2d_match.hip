@@ -40,14 +40,14 @@ static constexpr int SLOTS = S2D_MATCH_SLOTS;
 
 enum { S2D_ST_TACKLE = 4, S2D_ST_CATCH = 5, S2D_ST_TYPES = 6 };
 enum { SIDE_NONE = 0, SIDE_LEFT = 1, SIDE_RIGHT = 2 };
-enum { MF_X, MF_Y, MF_VX, MF_VY, MF_BODY, MF_STAMINA, MF_EFFORT, MF_RECOVERY, MF_CAPACITY, MF_TACKLE, MF_CATCH_BAN, MF_OBJ_PLANES };
+enum { MF_X, MF_Y, MF_VX, MF_VY, MF_BODY, MF_STAMINA, MF_EFFORT, MF_RECOVERY, MF_CAPACITY, MF_TACKLE, MF_CATCH_BAN, MF_CARD, MF_OBJ_PLANES };
 // Per-slot parameters (heterogeneous PlayerTypes, idl/service.proto:1697-1732): a [PT_WORDS][32] table,
 // one column per lane of the half-wave.  Column 22 (the ball) holds ball_size / ball_decay in the
 // size / decay rows, so the collision scan and the decay treat players and ball alike.
 enum { PT_SPEED_MAX, PT_SPEED_MAX2, PT_STAMINA_INC, PT_DECAY, PT_INERTIA, PT_DASH_RATE, PT_SIZE, PT_INV_KICK_MARGIN,
        PT_KICKABLE_AREA2, PT_KICK_RAND, PT_EXTRA_STAMINA, PT_EFFORT_MAX, PT_EFFORT_MIN, PT_KICK_RATE, PT_CATCH_LEN, PT_WORDS };
 enum { ME_CYCLE, ME_MODE, ME_MODE_SIDE, ME_SCORE_L, ME_SCORE_R, ME_LAST_TOUCH, ME_TIMER, ME_OFFSIDE, ME_REWARD, ME_NEAREST_L,
-       ME_NEAREST_R, ME_HOLDER, ME_MOVES, ME_TAKER, ME_LAST_KICKER, ME_ENV_PLANES };
+       ME_NEAREST_R, ME_HOLDER, ME_MOVES, ME_TAKER, ME_LAST_KICKER, ME_STOPPED, ME_TICK, ME_ENV_PLANES };
 
 struct MParams {   // every field rounded once on the host (double -> float); per-PlayerType values live in the PT table
   float half_l, half_w, ball_size, player_rand, ball_rand;
@@ -66,15 +66,23 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
   float catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle, goalie_max_moves;
   int after_goal_wait, kick_off_wait, back_passes, free_kick_faults;
+  int stopped_clock, announce_wait, foul_cycles; float foul_detect_probability;
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
 };
 typedef float PTab[kHalf];   // one row of the per-slot table
 
-struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int tackle, catch_ban; };
-struct MGame { int cycle, mode, mode_side, score_l, score_r, last_touch, timer, offside; float reward; int done, nearest_l, nearest_r;
+struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int tackle, catch_ban, card; };
+// Per-match words every cycle reads (registers; the same value in the 32 lanes of the match's half-wave) ...
+struct MGame { int cycle, mode, mode_side, last_touch, offside; float reward; int done, nearest_l, nearest_r;
+               int tick;               /* cycles since the reset, stopped ones included (the Philox counter) */ };
+// ... and the ones only events touch (goals, set plays, catches, kicks by the taker, a standing clock): they live in LDS, one row
+// per match, so that they do not occupy registers in a kernel that sits on its 128-VGPR cap (4 resident waves per SIMD).  All
+// 32 lanes of a half read and write the same word with the same value; LDS operations of one wave execute in order.
+struct MRare { int score_l, score_r, timer;
                int holder, moves; /* 1 + index of the goalie holding a caught ball (0 = nobody), his remaining moves */
-               int taker, last_kicker; /* 1 + index (0 = nobody): set-play taker not yet followed by another touch; last Kick-command kicker */ };
+               int taker, last_kicker; /* 1 + index (0 = nobody): set-play taker not yet followed by another touch; last Kick-command kicker */
+               int stopped;            /* WorldModel.stoped_cycle */ };
 
 __constant__ float kFormX[11] = {-50.0f, -35.0f, -35.0f, -35.0f, -35.0f, -20.0f, -20.0f, -20.0f, -20.0f, -10.5f, -10.5f};
 __constant__ float kFormY[11] = {0.0f, -20.0f, -7.0f, 7.0f, 20.0f, -22.0f, -8.0f, 8.0f, 22.0f, -6.0f, 6.0f};
@@ -85,12 +93,28 @@ S2D_DEV U4 m_draw(const MParams& p, uint32_t gl, uint32_t gh, uint32_t cyc, uint
 S2D_DEV int side_of(int i) { return i < 11 ? SIDE_LEFT : SIDE_RIGHT; }
 S2D_DEV int other_side(int s) { return s == SIDE_LEFT ? SIDE_RIGHT : SIDE_LEFT; }
 S2D_DEV bool is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D_GM_TIME_OVER; }
+// announcements: a dead ball named after the offending side; after announce_wait cycles the referee awards the restart
+S2D_DEV bool is_announcement(int mode) {
+  return mode == S2D_GM_OFF_SIDE || mode == S2D_GM_BACK_PASS || mode == S2D_GM_FREE_KICK_FAULT || mode == S2D_GM_CATCH_FAULT ||
+         mode == S2D_GM_FOUL_CHARGE;
+}
+// modes in which nobody may play the ball
+S2D_DEV bool ball_dead(int mode) {
+  return mode == S2D_GM_AFTER_GOAL || mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_GOALIE_CATCH ||
+         is_announcement(mode);
+}
+// modes in which the clock stands still (with stopped_clock): WorldModel.cycle keeps its value, stoped_cycle counts
+S2D_DEV bool clock_stands(int mode) {
+  return mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_AFTER_GOAL || mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_TIME_OVER ||
+         is_announcement(mode);
+}
 S2D_DEV float hbcast(float v, int src) { return __shfl(v, src, kHalf); }
 S2D_DEV int hbcasti(int v, int src) { return __shfl(v, src, kHalf); }
 // 32-bit ballot of this lane's half
 S2D_DEV uint32_t hballot(bool pred, int half) { return (uint32_t)(__ballot(pred) >> (half * kHalf)); }
 
 S2D_DEV void m_place(MObj& o, int l, int kickoff_side) {   // place_formation() for lane l
+  if (l < NP && o.card >= S2D_CARD_RED) return;            // sent off: stays where he was parked
   if (l < NP) {
     int k = l % 11; bool left = l < 11;
     o.x = left ? kFormX[k] : -kFormX[k]; o.y = kFormY[k];
@@ -105,9 +129,10 @@ S2D_DEV void m_recover(const MParams& p, float effort_max, MObj& o, bool with_ca
   o.stamina = p.stamina_max; o.effort = effort_max; o.recovery = p.recover_init;
   if (with_capacity) o.capacity = p.stamina_capacity;
 }
-S2D_DEV void m_reset(const MParams& p, float effort_max, MObj& o, MGame& g, int l) {
-  o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  g = MGame{0, p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0, 0, 0, 0.0f, 0, 10, 20, 0, 0, 0, 0};
+S2D_DEV void m_reset(const MParams& p, float effort_max, MObj& o, MGame& g, MRare& r, int l) {
+  o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  g = MGame{0, p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0.0f, 0, 10, 20, 0};
+  r = MRare{0, 0, 0, 0, 0, 0, 0, 0};
   if (l < NP) m_recover(p, effort_max, o, true);
   m_place(o, l, SIDE_LEFT);
 }
@@ -176,7 +201,7 @@ S2D_DEV bool m_kick(const MParams& p, const PTab* pt, int l, const MObj& o, floa
 S2D_DEV bool m_tackle_in_reach(const MParams& p, const MObj& o, float bx, float by) {
   return sq2(bx - o.x, by - o.y) <= p.tackle_reach2;
 }
-S2D_DEV bool m_tackle(const MParams& p, const MObj& o, float bx, float by, float dir, float u, float& kx, float& ky) {
+S2D_DEV bool m_tackle(const MParams& p, const MObj& o, float bx, float by, float dir, float u, bool foul, float& kx, float& ky) {
   float dx = bx - o.x, dy = by - o.y;
   float sn, cs;
   sincos_deg(o.body, sn, cs);
@@ -186,7 +211,8 @@ S2D_DEV bool m_tackle(const MParams& p, const MObj& o, float bx, float by, float
   float tx = d > 0.0f ? fabsf(rx) / d : (rx == 0.0f ? 0.0f : 1.0e9f);
   float ty = fabsf(ry) / p.tackle_width;
   float tx2 = tx * tx, ty2 = ty * ty;
-  float fail = tx2 * tx2 * tx2 + ty2 * ty2 * ty2;
+  float fail = tx2 * tx2 * tx2 + ty2 * ty2 * ty2;                        // tackle_exponent 6
+  if (foul) { const float tx4 = tx2 * tx2, ty4 = ty2 * ty2; fail = tx4 * tx4 * tx2 + ty4 * ty4 * ty2; }   // Tackle.foul: foul_exponent 10
   if (!(u >= fail)) return false;
   dir = clampf(dir, -180.0f, 180.0f);
   float ang_ball = fabsf(norm_deg_any(atan2_deg(dy, dx) - o.body));
@@ -235,7 +261,22 @@ S2D_DEV void m_noise(float& vx, float& vy, float rnd, float u_mag, float u_ang) 
   vx += mag * cs; vy += mag * sn;
 }
 
-struct MCounts { unsigned int goals_l, goals_r, finished, kicks, tackles, offsides, outs; };
+// Event counters (stats[1..7]: goals left / right, matches finished, kicks + catches, tackles, offsides, ball-outs).  A lane marks
+// the events of ITS cycle in one word (`ev`); at the end of the cycle the wave adds the bits up (ballot + popcount) into the
+// workgroup's LDS counters -- seven per-lane counters carried through the loop cost seven of the kernel's 128 registers.
+enum { EV_GOAL_L = 1 << 1, EV_GOAL_R = 1 << 2, EV_FINISHED = 1 << 3, EV_KICK = 1 << 4, EV_OFFSIDE = 1 << 6, EV_OUT = 1 << 7 };
+struct MCounts { unsigned int* lds; bool valid; unsigned int tackles; };   // the workgroup's counters; this lane's match exists; tackles
+// are the one frequent event (a quarter of the benchmark policy's commands): they keep a per-lane counter, flushed after the loop
+S2D_DEV void m_count_events(const MCounts& c, int ev) {     // wave-uniform call
+  const unsigned long long any = __ballot(c.valid && ev != 0);
+  if (any == 0ull) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    if (k == 5) continue;                                  // tackles: MCounts::tackles
+    const unsigned long long mk = __ballot(c.valid && ((ev >> k) & 1));
+    if (mk != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&c.lds[k], (unsigned int)__popcll(mk));
+  }
+}
 
 // One cycle of the match held by this half-wave.  l = lane within the half, half = 0/1.
 // cmd/a/b = this lane's command (players).  All 64 lanes execute every shuffle.
@@ -257,26 +298,26 @@ S2D_DEV void tile_init(float4* row, int l, float size) {
   row[tile_slot(l)] = make_float4(0.0f, 0.0f, size, 0.0f);
   row[l + (BALL + 1)] = make_float4(0.0f, 0.0f, size, 0.0f);
 }
-// `last` = this is the final cycle of the launch: nearest_left / nearest_right are outputs only (nothing in
-// the dynamics reads them), so the reduction that produces them runs once per launch.
-S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, int l, int half, uint32_t gl, uint32_t gh,
-                         int cmd, float a, float bb, MCounts& cnt, float4* pos, bool last) {
+S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MRare& gr, int l, int half, uint32_t gl, uint32_t gh,
+                         int cmd, float a, float bb, MCounts& cnt, float4* pos) {
+  int ev = 0;                                              // this lane's events of this cycle (EV_*)
   const bool is_player = l < NP, is_ball = l == BALL;
-  const uint32_t cyc = (uint32_t)g.cycle;
+  const uint32_t cyc = (uint32_t)g.tick;                   // Philox counter: cycles since the reset, stopped ones included
   const int mode0 = g.mode, side0 = g.mode_side;
-  const float x0 = o.x;
+  const float x0 = o.x, y0 = o.y;
   const float bx0 = hbcast(o.x, BALL), by0 = hbcast(o.y, BALL), bvx0 = hbcast(o.vx, BALL), bvy0 = hbcast(o.vy, BALL);
   g.reward = 0.0f; g.done = 0;
 
   // ---- 1. commands + player movement (lane-local)
   float ax = 0.0f, ay = 0.0f, kx = 0.0f, ky = 0.0f;
   bool kicked = false, by_kick = false;                    // by_kick: the impulse came from a Kick command (not a tackle)
-  if (!is_player || o.tackle > 0 || mode0 == S2D_GM_TIME_OVER) cmd = S2D_MCMD_NONE;
+  if (!is_player || o.tackle > 0 || mode0 == S2D_GM_TIME_OVER || o.card >= S2D_CARD_RED) cmd = S2D_MCMD_NONE;
   // one noise block per object and cycle: x, y = movement noise; z, w = the command's own noise (a player sends ONE body
   // command per cycle: Turn uses z, Kick uses z and w)
   U4 nz{0, 0, 0, 0};
   if (p.noise) nz = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, (uint32_t)l);
-  const bool may_touch = !is_setplay(mode0) || (side_of(l) == side0 && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_BEFORE_KICK_OFF);   // after a goal / before the kick-off the ball is dead
+  const bool may_touch = !is_setplay(mode0) || (side_of(l) == side0 && !ball_dead(mode0));   // announcements, after a goal, before the kick-off: the ball is dead
+  bool foul_try = false, foul_seen_l = false;              // this lane's intentional tackle succeeded; the referee would see a foul of his
   bool caught = false, hold_moved = false;
   if (cmd == S2D_MCMD_DASH) m_dash(p, pt, l, o, a, bb, ax, ay);
   else if (cmd == S2D_MCMD_TURN) m_turn(p, pt[PT_INERTIA][l], o, a, rnd_u01(nz.z));
@@ -292,7 +333,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
     // Move(x, y) in the team's own frame (right team mirrored): before a kick-off anywhere in the own half;
     // while holding a caught ball, goalie_max_moves times inside the own penalty area
     const float sgn = side_of(l) == SIDE_LEFT ? 1.0f : -1.0f;
-    const bool holds = mode0 == S2D_GM_FREE_KICK && g.holder == l + 1 && g.moves > 0;
+    const bool holds = mode0 == S2D_GM_FREE_KICK && gr.holder == l + 1 && gr.moves > 0;
     if (mode0 == S2D_GM_KICK_OFF || mode0 == S2D_GM_AFTER_GOAL || mode0 == S2D_GM_BEFORE_KICK_OFF || holds) {
       float tx = clampf(a, -p.half_l, holds ? -p.pen_x : 0.0f);
       float ty = holds ? clampf(bb, -p.pen_half_w, p.pen_half_w) : clampf(bb, -p.half_w, p.half_w);
@@ -301,15 +342,18 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
     }
   } else if (cmd == S2D_MCMD_KICK) {
     bool ok = m_kick(p, pt, l, o, bx0, by0, bvx0, bvy0, a, bb, rnd_u01(nz.z), rnd_u01(nz.w), kx, ky);
-    if (ok && may_touch) { kicked = true; by_kick = true; cnt.kicks++; } else { kx = 0.0f; ky = 0.0f; }
+    if (ok && may_touch) { kicked = true; by_kick = true; ev |= EV_KICK; } else { kx = 0.0f; ky = 0.0f; }
   } else if (cmd == S2D_MCMD_TACKLE) {
     bool ok = false;
+    const bool foul = bb != 0.0f;                          // Tackle.foul
     if (m_tackle_in_reach(p, o, bx0, by0)) {               // rare: most tackles are nowhere near the ball
       U4 w = m_draw(p, gl, gh, cyc, S2D_ST_TACKLE, (uint32_t)l);
-      ok = m_tackle(p, o, bx0, by0, a, rnd_u01(w.x), kx, ky);
+      ok = m_tackle(p, o, bx0, by0, a, rnd_u01(w.x), foul, kx, ky);
+      foul_try = ok && foul && mode0 == S2D_GM_PLAY_ON;
+      foul_seen_l = rnd_u01(w.y) < p.foul_detect_probability;
     }
     o.tackle = p.tackle_cycles + 1;
-    cnt.tackles++;
+    cnt.tackles += 1u;
     if (ok && may_touch) kicked = true; else { kx = 0.0f; ky = 0.0f; }
   }
   if (is_player) {
@@ -329,8 +373,36 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   // ... and so does a move of the goalie who holds the ball (the holder is a goalie: bits 0 / 11)
   const uint32_t hmask = hballot(hold_moved, half) & ((1u << S2D_MATCH_GOALIE_LEFT) | (1u << S2D_MATCH_GOALIE_RIGHT));
   const int hold_move = hmask ? __ffs((int)hmask) - 1 : -1;
-  if (caught_by >= 0 && l == caught_by) cnt.kicks++;
+  if (caught_by >= 0 && l == caught_by) ev |= EV_KICK;
   if (caught_by >= 0 || hold_move >= 0) { kicked = false; by_kick = false; kx = 0.0f; ky = 0.0f; }
+  // FoulCharge_ (idl/service.proto:282): a successful INTENTIONAL tackle through an opponent who has the ball (kickable) inside the
+  // tackler's tackle area brings him down for foul_cycles; the referee sees it with foul_detect_probability.  Positions of the
+  // start of the cycle; the first such tackler (lowest index) counts.  Wave-uniform and rare: only tackles with foul set get here.
+  int foul_call = 0;                                       // 1 + tackler if the referee saw a foul, else 0
+  if (__ballot(foul_try) != 0ull) {
+    const bool has_ball = is_player && o.card < S2D_CARD_RED && sq2(bx0 - x0, by0 - y0) <= pt[PT_KICKABLE_AREA2][l];
+    const uint32_t hb = hballot(has_ball, half) & 0x3FFFFFu;
+    float sn, cs;
+    sincos_deg(o.body, sn, cs);
+    int victim = -1;
+    const int o0 = side_of(l) == SIDE_LEFT ? 11 : 0;
+    for (int j = 0; j < 11; ++j) {
+      const int jj = o0 + j;
+      const float dx = hbcast(x0, jj) - x0, dy = hbcast(y0, jj) - y0;
+      const float rx = dx * cs + dy * sn, ry = dy * cs - dx * sn;
+      if (victim < 0 && ((hb >> jj) & 1u) && rx >= 0.0f && rx <= p.tackle_dist && fabsf(ry) <= p.tackle_width) victim = jj;
+    }
+    const uint32_t fm = hballot(foul_try && victim >= 0, half) & 0x3FFFFFu;
+    const int foul_by = fm ? __ffs((int)fm) - 1 : -1;
+    const int src = foul_by >= 0 ? foul_by : 0;
+    const int foul_victim = hbcasti(victim, src);
+    const bool foul_seen = hbcasti(foul_seen_l ? 1 : 0, src) != 0 && foul_by >= 0;
+    if (foul_by >= 0) {                                    // the victim goes down; a foul the referee saw is a card
+      if (l == foul_victim && o.tackle < p.foul_cycles + 1) o.tackle = p.foul_cycles + 1;
+      if (l == foul_by && foul_seen && o.card < S2D_CARD_RED) o.card += 1;
+    }
+    foul_call = foul_seen ? foul_by + 1 : 0;
+  }
   // ---- 2. ball: impulses summed in player order
   const uint32_t kmask = hballot(kicked, half) & 0x3FFFFFu;
   const bool any_kick = kmask != 0u;
@@ -345,16 +417,16 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   }
   if (any_kick) g.last_touch = side_of(last_kicker);
   // free-kick fault / back-pass bookkeeping (oracle: match_step, same decisions from the same masks)
-  const int taker0 = g.taker;
+  const int taker0 = gr.taker;
   const uint32_t cmask2 = hballot(by_kick, half) & 0x3FFFFFu;                  // Kick-command kickers
   const uint32_t taker_bit = taker0 > 0 ? (1u << (taker0 - 1)) : 0u;
   const bool other_touch = (kmask & ~taker_bit) != 0u;
   const bool fk_fault = p.free_kick_faults && mode0 == S2D_GM_PLAY_ON && taker0 != 0 && any_kick && !other_touch;
   if (any_kick) {
-    if (is_setplay(mode0)) g.taker = last_kicker + 1;        // this kick puts the ball into play
-    else if (other_touch) g.taker = 0;
+    if (is_setplay(mode0)) gr.taker = last_kicker + 1;        // this kick puts the ball into play
+    else if (other_touch) gr.taker = 0;
     const int last_kick_cmd = cmask2 ? 31 - __clz(cmask2) : -1;
-    g.last_kicker = (last_kick_cmd == last_kicker) ? last_kick_cmd + 1 : 0;
+    gr.last_kicker = (last_kick_cmd == last_kicker) ? last_kick_cmd + 1 : 0;
   }
   const bool ball_live = !is_setplay(mode0) || any_kick;
   if (caught_by >= 0) {                                   // held: the ball rests where it was caught
@@ -366,7 +438,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
     float sn, cs;
     sincos_deg(gb, sn, cs);
     if (is_ball) { o.x = gx + r * cs; o.y = gy + r * sn; o.vx = 0.0f; o.vy = 0.0f; }
-    g.moves -= 1;
+    gr.moves -= 1;
   } else if (is_ball && ball_live) {
     if (any_kick) {
       float a2 = sq2(bax, bay);
@@ -433,13 +505,16 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
     coll_touch_side = side_of(touch_player);
     g.last_touch = coll_touch_side;
-    if (touch_player + 1 != g.taker) g.taker = 0;
-    if (touch_player + 1 != g.last_kicker) g.last_kicker = 0;
+    if (touch_player + 1 != gr.taker) gr.taker = 0;
+    if (touch_player + 1 != gr.last_kicker) gr.last_kicker = 0;
   }
   // ---- 4. set play: opponents keep their distance
   {
     float bxn = hbcast(o.x, BALL), byn = hbcast(o.y, BALL);
-    if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && is_player && side_of(l) != side0) {
+    // the side that does not take the set play keeps its distance; during an announcement that is the offending side (side0)
+    const int kept_away = is_announcement(mode0) ? side0 : other_side(side0);
+    if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_FIRST_HALF_OVER && is_player &&
+        side_of(l) == kept_away && o.card < S2D_CARD_RED) {
       float dx = o.x - bxn, dy = o.y - byn, d = hypot2(dx, dy);
       if (d < p.free_kick_distance) {
         float ux, uy;
@@ -448,8 +523,12 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
       }
     }
   }
-  // ---- 5. referee (every lane of the half evaluates the same decisions)
-  g.cycle = (int)((uint32_t)g.cycle + 1u);               // wrap-defined (a finished match without auto-restart keeps counting)
+  // ---- 5. referee (every lane of the half evaluates the same decisions).  The clock: WorldModel.cycle advances unless the mode
+  // of this cycle is one in which it stands still
+  g.tick = (int)((uint32_t)g.tick + 1u);
+  const bool advanced = !(p.stopped_clock && clock_stands(mode0));
+  if (advanced) { g.cycle = (int)((uint32_t)g.cycle + 1u); gr.stopped = 0; }   // wrap-defined
+  else gr.stopped += 1;
   // inputs that need shuffles are gathered unconditionally (uniform control flow)
   const float bx = hbcast(o.x, BALL), by = hbcast(o.y, BALL);
   float first = -1.0e9f, second = -1.0e9f;      // two largest dirS*x0 among the kicker's opponents
@@ -467,19 +546,29 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   bool recover_half = false;
   if (mode0 != S2D_GM_TIME_OVER) {
     if (mode0 == S2D_GM_AFTER_GOAL) {                      // dead ball until the wait is over, then the conceding side kicks off
-      g.timer += 1;
-      if (g.timer >= p.after_goal_wait) {
+      gr.timer += 1;
+      if (gr.timer >= p.after_goal_wait) {
         const int ks = other_side(side0);
         restart_form = true; form_side = ks;
-        g.mode = S2D_GM_KICK_OFF; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
-        g.taker = 0; g.last_kicker = 0;
+        g.mode = S2D_GM_KICK_OFF; g.mode_side = ks; gr.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        gr.taker = 0; gr.last_kicker = 0;
       }
     } else if (mode0 == S2D_GM_BEFORE_KICK_OFF) {          // nobody plays the ball, players may Move
-      g.timer += 1;
-      if (g.timer >= p.kick_off_wait) { g.mode = S2D_GM_KICK_OFF; g.timer = 0; }
+      gr.timer += 1;
+      if (gr.timer >= p.kick_off_wait) { g.mode = S2D_GM_KICK_OFF; gr.timer = 0; }
+    } else if (mode0 == S2D_GM_FIRST_HALF_OVER) {          // one cycle of "half time", then the next half's kick-off
+      g.mode = p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF; gr.timer = 0;
+    } else if (mode0 == S2D_GM_GOALIE_CATCH) {             // one cycle of "goalie_catch_ball", then his free kick
+      g.mode = S2D_GM_FREE_KICK; gr.timer = 0;
+    } else if (is_announcement(mode0)) {                   // offside_l, back_pass_l, ...: after the wait, the restart for the other side
+      gr.timer += 1;
+      if (gr.timer >= p.announce_wait) {
+        g.mode = (mode0 == S2D_GM_BACK_PASS || mode0 == S2D_GM_FREE_KICK_FAULT) ? S2D_GM_IND_FREE_KICK : S2D_GM_FREE_KICK;
+        g.mode_side = other_side(side0); gr.timer = 0;
+      }
     } else if (is_setplay(mode0)) {
-      if (any_kick) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; }
-      else { g.timer += 1; if (g.timer > p.drop_ball_time) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; } }
+      if (any_kick) { g.mode = S2D_GM_PLAY_ON; gr.timer = 0; }
+      else { gr.timer += 1; if (gr.timer > p.drop_ball_time) { g.mode = S2D_GM_PLAY_ON; gr.timer = 0; } }
     }
     // offside candidates: each lane tests itself, the mask is assembled by ballot
     float line = 0.0f;
@@ -504,36 +593,39 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
         // back pass: the goalie catches a ball a team-mate kicked to him -> indirect free kick for the other side from the
         // nearer front corner of the penalty area; otherwise, inside the own penalty area: free kick for the goalie's side;
         // outside: catch fault
-        const int lk = g.last_kicker - 1;
+        const int lk = gr.last_kicker - 1;
         const bool back_pass = p.back_passes && in_area && lk >= 0 && lk != caught_by && side_of(lk) == gs;
-        place_ball = true; g.timer = 0; g.offside = 0; g.taker = 0; g.last_kicker = 0;
-        if (back_pass) {
+        place_ball = true; gr.timer = 0; g.offside = 0; gr.taker = 0; gr.last_kicker = 0;
+        if (back_pass) {                                    // back_pass_l / _r: named after the offending side
           pbx = gs == SIDE_LEFT ? -p.pen_x : p.pen_x; pby = by > 0.0f ? p.pen_half_w : -p.pen_half_w;
-          g.mode = S2D_GM_BACK_PASS; g.mode_side = other_side(gs);
-        } else {
+          g.mode = S2D_GM_BACK_PASS; g.mode_side = gs;
+        } else {                                            // GoalieCatch_, then his free kick -- or CatchFault_ outside the area
           pbx = bx; pby = by;
-          g.mode = S2D_GM_FREE_KICK; g.mode_side = in_area ? gs : other_side(gs);
-          if (in_area) { g.holder = caught_by + 1; g.moves = p.goalie_max_moves; }
+          g.mode = in_area ? S2D_GM_GOALIE_CATCH : S2D_GM_CATCH_FAULT; g.mode_side = gs;
+          if (in_area) { gr.holder = caught_by + 1; gr.moves = p.goalie_max_moves; }
         }
+      } else if (foul_call != 0) {                          // the referee saw the foul: FoulCharge_ where the ball is
+        place_ball = true; pbx = clampf(bx, -p.half_l, p.half_l); pby = clampf(by, -p.half_w, p.half_w);
+        g.mode = S2D_GM_FOUL_CHARGE; g.mode_side = side_of(foul_call - 1); gr.timer = 0; g.offside = 0;
       } else if (fk_fault) {                                // the taker touched the ball twice
         place_ball = true; pbx = clampf(bx, -p.half_l, p.half_l); pby = clampf(by, -p.half_w, p.half_w);
-        g.mode = S2D_GM_FREE_KICK_FAULT; g.mode_side = other_side(side_of(taker0 - 1)); g.timer = 0; g.offside = 0;
-        g.taker = 0; g.last_kicker = 0;
+        g.mode = S2D_GM_FREE_KICK_FAULT; g.mode_side = side_of(taker0 - 1); gr.timer = 0; g.offside = 0;
+        gr.taker = 0; gr.last_kicker = 0;
       } else if (bx > p.half_l && fabsf(by) < p.goal_half_width) {
-        g.score_l += 1; g.reward = 1.0f; if (is_ball) cnt.goals_l++;
-        g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        gr.score_l += 1; g.reward = 1.0f; if (is_ball) ev |= EV_GOAL_L;
+        gr.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
         if (p.after_goal_wait > 0) { place_ball = true; pbx = bx; pby = by; g.mode = S2D_GM_AFTER_GOAL; g.mode_side = SIDE_LEFT; }
         else { restart_form = true; form_side = SIDE_RIGHT; g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_RIGHT; }
       } else if (bx < -p.half_l && fabsf(by) < p.goal_half_width) {
-        g.score_r += 1; g.reward = -1.0f; if (is_ball) cnt.goals_r++;
-        g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        gr.score_r += 1; g.reward = -1.0f; if (is_ball) ev |= EV_GOAL_R;
+        gr.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
         if (p.after_goal_wait > 0) { place_ball = true; pbx = bx; pby = by; g.mode = S2D_GM_AFTER_GOAL; g.mode_side = SIDE_RIGHT; }
         else { restart_form = true; form_side = SIDE_LEFT; g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_LEFT; }
       } else if (fabsf(bx) > p.half_l || fabsf(by) > p.half_w) {
-        if (is_ball) cnt.outs++;
+        if (is_ball) ev |= EV_OUT;
         int toucher = g.last_touch == SIDE_NONE ? SIDE_LEFT : g.last_touch;
         float sy = by < 0.0f ? -1.0f : 1.0f, sxn = bx < 0.0f ? -1.0f : 1.0f;
-        place_ball = true; g.timer = 0; g.offside = 0;
+        place_ball = true; gr.timer = 0; g.offside = 0;
         if (fabsf(bx) <= p.half_l) {
           g.mode = S2D_GM_KICK_IN; g.mode_side = other_side(toucher);
           pbx = clampf(bx, -p.half_l, p.half_l); pby = sy * p.half_w;
@@ -551,24 +643,24 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
         uint32_t hit = (uint32_t)g.offside & near_mask;
         if (hit) {
           int t = __ffs((int)hit) - 1;            // first flagged player in index order
-          if (is_ball) cnt.offsides++;
+          if (is_ball) ev |= EV_OFFSIDE;
           place_ball = true; pbx = 0.0f; pby = 0.0f;   // coordinates fetched below (needs a shuffle)
-          g.mode = S2D_GM_OFF_SIDE; g.mode_side = other_side(side_of(t)); g.timer = 0;
+          g.mode = S2D_GM_OFF_SIDE; g.mode_side = side_of(t); gr.timer = 0;          // offside_l / _r: named after the offender
           g.offside = -1 - t;                       // marker: ball goes to player t (resolved below)
         }
       }
     }
-    int total = p.half_time_cycles * p.nr_normal_halfs;
-    if (g.cycle >= total) {
-      g.mode = S2D_GM_TIME_OVER; g.mode_side = SIDE_NONE; g.done = 1; if (g.offside > 0) g.offside = 0; if (is_ball) cnt.finished++;
-    } else if (p.half_time_cycles > 0 && g.cycle % p.half_time_cycles == 0) {
+    int total = p.half_time_cycles * p.nr_normal_halfs;  // half time / time over: only when the clock has just moved
+    if (advanced && g.cycle >= total) {
+      g.mode = S2D_GM_TIME_OVER; g.mode_side = SIDE_NONE; g.done = 1; if (g.offside > 0) g.offside = 0; if (is_ball) ev |= EV_FINISHED;
+    } else if (advanced && p.half_time_cycles > 0 && g.cycle % p.half_time_cycles == 0) {
       int k = g.cycle / p.half_time_cycles;
       int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
       recover_half = true; restart_form = true; form_side = ks; place_ball = false;
-      g.mode = p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+      g.mode = S2D_GM_FIRST_HALF_OVER; g.mode_side = ks; gr.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
     }
-    if (place_ball || restart_form) { g.taker = 0; g.last_kicker = 0; }   // every restart ends the double-touch / back-pass bookkeeping
-    if (g.mode != S2D_GM_FREE_KICK) { g.holder = 0; g.moves = 0; }   // nobody holds the ball any more
+    if (place_ball || restart_form) { gr.taker = 0; gr.last_kicker = 0; }   // every restart ends the double-touch / back-pass bookkeeping
+    if (g.mode != S2D_GM_FREE_KICK && g.mode != S2D_GM_GOALIE_CATCH) { gr.holder = 0; gr.moves = 0; }   // nobody holds the ball any more
   }
   // resolve the offside spot (uniform shuffle, then apply)
   {
@@ -582,6 +674,11 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
   if (recover_half && is_player) m_recover(p, pt[PT_EFFORT_MAX][l], o, false);
   if (restart_form) m_place(o, l, form_side);
   else if (place_ball && is_ball) { o.x = pbx; o.y = pby; o.vx = 0.0f; o.vy = 0.0f; }
+  // a second card is a red one: the player waits beside the halfway line, outside the pitch, one spot per uniform number
+  if (is_player && o.card >= S2D_CARD_RED) {
+    o.x = 0.0f; o.y = (side_of(l) == SIDE_LEFT ? -1.0f : 1.0f) * (p.half_w + 6.0f + 1.5f * (float)(l % 11));
+    o.vx = 0.0f; o.vy = 0.0f;
+  }
   // ---- 6. decay, tackle timers, stamina
   if (l <= BALL) { const float decay = pt[PT_DECAY][l]; o.vx *= decay; o.vy *= decay; }   // column 22 = ball_decay
   if (is_player) {
@@ -589,27 +686,31 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, in
     if (o.catch_ban > 0) o.catch_ban -= 1;
     m_update_stamina(p, pt, l, o);
   }
-  // ---- 7. nearest player to the ball per team (ties -> lowest index): butterfly min-reduction over
-  // the half-wave on the 64-bit key (bits(d2) << 8 | index); d2 >= 0, so its bit pattern orders like
-  // the value and the key orders like (d2, index) -- the same winner as a scan in index order.
-  if (last) {
-    float bxn = hbcast(o.x, BALL), byn = hbcast(o.y, BALL);
-    float d2 = sq2(o.x - bxn, o.y - byn);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 8) | (unsigned long long)l;
-    unsigned long long kl = (is_player && l < 11) ? key : ~0ull;
-    unsigned long long kr = (is_player && l >= 11) ? key : ~0ull;
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-      unsigned long long ol = __shfl_xor(kl, off, kHalf), orr = __shfl_xor(kr, off, kHalf);
-      kl = ol < kl ? ol : kl; kr = orr < kr ? orr : kr;
-    }
-    g.nearest_l = (int)(kl & 0xFFull); g.nearest_r = (int)(kr & 0xFFull);
-  }
+  m_count_events(cnt, ev);
   if (g.done && p.auto_reset) {
-    int d = g.done; float rw = g.reward;
-    m_reset(p, pt[PT_EFFORT_MAX][l], o, g, l);
-    g.done = d; g.reward = rw;
+    int d = g.done; float rw = g.reward; int tk = g.tick;
+    m_reset(p, pt[PT_EFFORT_MAX][l], o, g, gr, l);
+    g.done = d; g.reward = rw; g.tick = tk;                // the draws of the next match continue the sequence
   }
+}
+
+// Nearest player to the ball per team (ties -> lowest index): butterfly min-reduction over the half-wave on the 64-bit key
+// (bits(d2) << 8 | index); d2 >= 0, so its bit pattern orders like the value and the key orders like (d2, index) -- the same
+// winner as a scan in index order.  Outputs only (nothing in the dynamics reads them): evaluated once per launch, after its
+// last cycle.
+S2D_DEV void match_nearest(const MObj& o, MGame& g, int l) {
+  const bool is_player = l < NP;
+  float bxn = hbcast(o.x, BALL), byn = hbcast(o.y, BALL);
+  float d2 = sq2(o.x - bxn, o.y - byn);
+  const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 8) | (unsigned long long)l;
+  unsigned long long kl = (is_player && l < 11) ? key : ~0ull;
+  unsigned long long kr = (is_player && l >= 11) ? key : ~0ull;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    unsigned long long ol = __shfl_xor(kl, off, kHalf), orr = __shfl_xor(kr, off, kHalf);
+    kl = ol < kl ? ol : kl; kr = orr < kr ? orr : kr;
+  }
+  g.nearest_l = (int)(kl & 0xFFull); g.nearest_r = (int)(kr & 0xFFull);
 }
 
 // benchmark policy: Philox POLICY stream, block = player, counter = cycle / 2 -- one call serves two cycles (words
@@ -634,11 +735,12 @@ S2D_DEV void m_random_action(const MParams& p, uint32_t gl, uint32_t gh, uint32_
 struct MPtrs { float* obj; int32_t* env; float* reward; uint8_t* done; unsigned long long* stats; int64_t obj_stride; int64_t env_stride;
                const float* ptab; /* [PT_WORDS][32] per-slot PlayerType parameters */ };
 
-S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g) {
-  o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g, MRare& r) {
+  o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (l < SLOTS) {
     int64_t k = e * SLOTS + l;
     o.catch_ban = __float_as_int(q.obj[MF_CATCH_BAN * q.obj_stride + k]);
+    o.card = __float_as_int(q.obj[MF_CARD * q.obj_stride + k]);
     o.x = q.obj[MF_X * q.obj_stride + k]; o.y = q.obj[MF_Y * q.obj_stride + k];
     o.vx = q.obj[MF_VX * q.obj_stride + k]; o.vy = q.obj[MF_VY * q.obj_stride + k];
     o.body = q.obj[MF_BODY * q.obj_stride + k];
@@ -647,14 +749,15 @@ S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g) {
     o.tackle = __float_as_int(q.obj[MF_TACKLE * q.obj_stride + k]);
   }
   g.cycle = q.env[ME_CYCLE * q.env_stride + e]; g.mode = q.env[ME_MODE * q.env_stride + e];
-  g.mode_side = q.env[ME_MODE_SIDE * q.env_stride + e]; g.score_l = q.env[ME_SCORE_L * q.env_stride + e];
-  g.score_r = q.env[ME_SCORE_R * q.env_stride + e]; g.last_touch = q.env[ME_LAST_TOUCH * q.env_stride + e];
-  g.timer = q.env[ME_TIMER * q.env_stride + e]; g.offside = q.env[ME_OFFSIDE * q.env_stride + e];
-  g.reward = 0.0f; g.done = 0; g.nearest_l = q.env[ME_NEAREST_L * q.env_stride + e]; g.nearest_r = q.env[ME_NEAREST_R * q.env_stride + e];
-  g.holder = q.env[ME_HOLDER * q.env_stride + e]; g.moves = q.env[ME_MOVES * q.env_stride + e];
-  g.taker = q.env[ME_TAKER * q.env_stride + e]; g.last_kicker = q.env[ME_LAST_KICKER * q.env_stride + e];
+  g.mode_side = q.env[ME_MODE_SIDE * q.env_stride + e]; r.score_l = q.env[ME_SCORE_L * q.env_stride + e];
+  r.score_r = q.env[ME_SCORE_R * q.env_stride + e]; g.last_touch = q.env[ME_LAST_TOUCH * q.env_stride + e];
+  r.timer = q.env[ME_TIMER * q.env_stride + e]; g.offside = q.env[ME_OFFSIDE * q.env_stride + e];
+  g.reward = 0.0f; g.done = 0; g.nearest_l = 0; g.nearest_r = 0;        // outputs: match_nearest() after the launch's last cycle
+  r.holder = q.env[ME_HOLDER * q.env_stride + e]; r.moves = q.env[ME_MOVES * q.env_stride + e];
+  r.taker = q.env[ME_TAKER * q.env_stride + e]; r.last_kicker = q.env[ME_LAST_KICKER * q.env_stride + e];
+  r.stopped = q.env[ME_STOPPED * q.env_stride + e]; g.tick = q.env[ME_TICK * q.env_stride + e];
 }
-S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGame& g) {
+S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGame& g, const MRare& r) {
   if (l < SLOTS) {
     int64_t k = e * SLOTS + l;
     q.obj[MF_X * q.obj_stride + k] = o.x; q.obj[MF_Y * q.obj_stride + k] = o.y;
@@ -664,31 +767,23 @@ S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGam
     q.obj[MF_RECOVERY * q.obj_stride + k] = o.recovery; q.obj[MF_CAPACITY * q.obj_stride + k] = o.capacity;
     q.obj[MF_TACKLE * q.obj_stride + k] = __int_as_float(o.tackle);
     q.obj[MF_CATCH_BAN * q.obj_stride + k] = __int_as_float(o.catch_ban);
+    q.obj[MF_CARD * q.obj_stride + k] = __int_as_float(o.card);
   }
   if (l == BALL) {
     q.env[ME_CYCLE * q.env_stride + e] = g.cycle; q.env[ME_MODE * q.env_stride + e] = g.mode;
-    q.env[ME_MODE_SIDE * q.env_stride + e] = g.mode_side; q.env[ME_SCORE_L * q.env_stride + e] = g.score_l;
-    q.env[ME_SCORE_R * q.env_stride + e] = g.score_r; q.env[ME_LAST_TOUCH * q.env_stride + e] = g.last_touch;
-    q.env[ME_TIMER * q.env_stride + e] = g.timer; q.env[ME_OFFSIDE * q.env_stride + e] = g.offside;
+    q.env[ME_MODE_SIDE * q.env_stride + e] = g.mode_side; q.env[ME_SCORE_L * q.env_stride + e] = r.score_l;
+    q.env[ME_SCORE_R * q.env_stride + e] = r.score_r; q.env[ME_LAST_TOUCH * q.env_stride + e] = g.last_touch;
+    q.env[ME_TIMER * q.env_stride + e] = r.timer; q.env[ME_OFFSIDE * q.env_stride + e] = g.offside;
     q.env[ME_NEAREST_L * q.env_stride + e] = g.nearest_l; q.env[ME_NEAREST_R * q.env_stride + e] = g.nearest_r;
-    q.env[ME_HOLDER * q.env_stride + e] = g.holder; q.env[ME_MOVES * q.env_stride + e] = g.moves;
-    q.env[ME_TAKER * q.env_stride + e] = g.taker; q.env[ME_LAST_KICKER * q.env_stride + e] = g.last_kicker;
+    q.env[ME_HOLDER * q.env_stride + e] = r.holder; q.env[ME_MOVES * q.env_stride + e] = r.moves;
+    q.env[ME_TAKER * q.env_stride + e] = r.taker; q.env[ME_LAST_KICKER * q.env_stride + e] = r.last_kicker;
+    q.env[ME_STOPPED * q.env_stride + e] = r.stopped; q.env[ME_TICK * q.env_stride + e] = g.tick;
     q.reward[e] = g.reward; q.done[e] = (uint8_t)g.done;
   }
 }
-// per-lane counters -> wave sums (shuffle tree) -> workgroup sums (LDS) -> ONE striped atomic per
-// workgroup and counter (thousands of waves adding to one address cost ~12 ns each, serially)
-S2D_DEV void m_flush_counts(const MCounts& c, bool valid, unsigned long long* stats, unsigned int* lds_cnt) {
-  if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0u;
-  __syncthreads();
-  auto flush = [&](unsigned int v, int k) {
-    unsigned int s = valid ? v : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&lds_cnt[k], s);
-  };
-  flush(c.goals_l, 1); flush(c.goals_r, 2); flush(c.finished, 3); flush(c.kicks, 4);
-  flush(c.tackles, 5); flush(c.offsides, 6); flush(c.outs, 7);
+// workgroup sums (LDS, m_count_events) -> ONE striped atomic per workgroup and counter (thousands of waves adding to one
+// address cost ~12 ns each, serially)
+S2D_DEV void m_flush_counts(unsigned long long* stats, const unsigned int* lds_cnt) {
   __syncthreads();
   if (threadIdx.x >= 1 && threadIdx.x < 8 && lds_cnt[threadIdx.x])
     atomicAdd(&stats[(blockIdx.x % S2D_STATS_STRIPES) * 8 + threadIdx.x], (unsigned long long)lds_cnt[threadIdx.x]);
@@ -699,9 +794,9 @@ __global__ __launch_bounds__(kMBlock) void s2d_match_reset_kernel(MParams p, MPt
   const int64_t e = (int64_t)blockIdx.x * kEnvsPerBlock + threadIdx.x / kHalf;
   if (e >= n) return;
   if (mask && !mask[e]) return;
-  MObj o; MGame g;
-  m_reset(p, q.ptab[PT_EFFORT_MAX * kHalf + l], o, g, l);
-  m_store(q, e, l, o, g);
+  MObj o; MGame g; MRare r;
+  m_reset(p, q.ptab[PT_EFFORT_MAX * kHalf + l], o, g, r, l);
+  m_store(q, e, l, o, g, r);
 }
 
 struct MRoll { float* obs; float* reward; int32_t* mode; uint8_t* done; };
@@ -712,6 +807,7 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
   __shared__ float4 pos_tile[kEnvsPerBlock][kTileSlots];
   __shared__ PTab pt[PT_WORDS];                       // per-slot PlayerType parameters, shared by the 8 matches
   __shared__ unsigned int lds_cnt[8];
+  __shared__ MRare rare[kEnvsPerBlock];                // per-match words only events touch (see MRare)
   // The ~60 uniform parameters are read from LDS (broadcast reads) where they are used instead of
   // occupying SGPRs for the whole kernel: as kernargs they cost 142 SGPR spills and 48 B of scratch at
   // the 128-VGPR cap (26 spills / 12 B this way, +14 % throughput).
@@ -721,6 +817,7 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
     reinterpret_cast<uint32_t*>(&p_lds)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&p_arg)[threadIdx.x];
   const MParams& p = p_lds;
   for (int k = threadIdx.x; k < PT_WORDS * kHalf; k += kMBlock) (&pt[0][0])[k] = q.ptab[k];
+  if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0u;
   __syncthreads();
   const int l = threadIdx.x & (kHalf - 1);
   const int half = (threadIdx.x >> 5) & 1;
@@ -728,11 +825,12 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
   const bool valid = e < n;
   const int64_t ec = valid ? e : n - 1;              // lanes of out-of-range matches shadow the last match (no stores)
   MObj o; MGame g;
-  m_load(q, ec, l, o, g);
+  MRare& r = rare[threadIdx.x / kHalf];
+  m_load(q, ec, l, o, g, r);
   tile_init(pos_tile[threadIdx.x / kHalf], l, pt[PT_SIZE][l]);
   const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)ec;
   const uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
-  MCounts cnt{0, 0, 0, 0, 0, 0, 0};
+  MCounts cnt{lds_cnt, valid, 0u};
   U4 pol{0, 0, 0, 0};                                     // the policy block of the current pair of cycles
   for (int t = 0; t < n_steps; ++t) {
     int cmd = S2D_MCMD_NONE; float a = 0.0f, b = 0.0f;
@@ -741,10 +839,10 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
         const float* ap = actions + (((int64_t)t * n + ec) * NP + l) * 3;
         cmd = (int)ap[0]; a = ap[1]; b = ap[2];
       } else {
-        m_random_action(p, gl, gh, (uint32_t)g.cycle, l, t == 0, pol, cmd, a, b);
+        m_random_action(p, gl, gh, (uint32_t)g.tick, l, t == 0, pol, cmd, a, b);
       }
     }
-    match_cycle(p, pt, o, g, l, half, gl, gh, cmd, a, b, cnt, pos_tile[threadIdx.x / kHalf], t == n_steps - 1);
+    match_cycle(p, pt, o, g, r, l, half, gl, gh, cmd, a, b, cnt, pos_tile[threadIdx.x / kHalf]);
     if (valid) {
       const int64_t row = (int64_t)t * n + e;
       if (ro.obs && l < SLOTS) {
@@ -758,8 +856,15 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
       }
     }
   }
-  if (valid) m_store(q, e, l, o, g);
-  m_flush_counts(cnt, valid, q.stats, lds_cnt);
+  match_nearest(o, g, l);
+  if (valid) m_store(q, e, l, o, g, r);
+  {                                                     // tackles: per-lane counters -> wave sum -> LDS
+    unsigned int tk = valid ? cnt.tackles : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tk += __shfl_down(tk, off);
+    if ((threadIdx.x & 63) == 0 && tk) atomicAdd(&lds_cnt[5], tk);
+  }
+  m_flush_counts(q.stats, lds_cnt);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&q.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
 }
 
@@ -923,6 +1028,7 @@ S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
   m.max_catch_angle = 90.0; m.min_catch_angle = -90.0; m.penalty_area_length = 16.5; m.penalty_area_half_width = 20.16;
   m.goalie_max_moves = 2; m.after_goal_wait = 50;
   m.kick_off_wait = 0; m.back_passes = 1; m.free_kick_faults = 1;
+  m.stopped_clock = 1; m.announce_wait = 30; m.foul_cycles = 5; m.foul_detect_probability = 0.5;
   c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
   for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) c->player_types[t] = m_default_type(c->sp, m);   // homogeneous
 }
@@ -941,6 +1047,8 @@ S2D_API int s2d_match_validate_config(const S2DMatchConfig* c) {
     return mfail(S2D_EINVAL, "goalie_max_moves / after_goal_wait / kick_off_wait must be >= 0");
   if (c->mp.catch_ban_cycle < 0 || !(c->mp.catch_area_w > 0) || !(c->mp.catchable_area_l > 0))
     return mfail(S2D_EINVAL, "catch_ban_cycle must be >= 0, catch_area_w and catchable_area_l > 0");
+  if (c->mp.announce_wait < 0 || c->mp.foul_cycles < 0 || !(c->mp.foul_detect_probability >= 0 && c->mp.foul_detect_probability <= 1))
+    return mfail(S2D_EINVAL, "announce_wait / foul_cycles must be >= 0, foul_detect_probability in [0, 1]");
   for (int i = 0; i < S2D_MATCH_PLAYERS; ++i)
     if (c->player_type_id[i] < 0 || c->player_type_id[i] >= S2D_MATCH_PLAYER_TYPES)
       return mfail(S2D_EINVAL, "player_type_id entries must be in [0, 18)");
@@ -994,6 +1102,8 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   p.nr_normal_halfs = m.nr_normal_halfs; p.drop_ball_time = m.drop_ball_time; p.use_offside = m.use_offside;
   p.catch_ban_cycle = m.catch_ban_cycle; p.goalie_max_moves = m.goalie_max_moves; p.after_goal_wait = m.after_goal_wait;
   p.kick_off_wait = m.kick_off_wait; p.back_passes = m.back_passes; p.free_kick_faults = m.free_kick_faults;
+  p.stopped_clock = m.stopped_clock; p.announce_wait = m.announce_wait; p.foul_cycles = m.foul_cycles;
+  p.foul_detect_probability = (float)m.foul_detect_probability;
   p.auto_reset = c.auto_reset; p.noise = c.noise;
   p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
   p.gid_lo = (uint32_t)(uint64_t)c.env_id_offset; p.gid_hi = (uint32_t)((uint64_t)c.env_id_offset >> 32);
@@ -1083,6 +1193,8 @@ S2D_API int s2d_match_create(const S2DMatchConfig* cfg, int64_t n_envs, int devi
   b.setplay_timer = env + ME_TIMER * es; b.offside_mask = env + ME_OFFSIDE * es;
   b.ball_holder = env + ME_HOLDER * es; b.goalie_moves = env + ME_MOVES * es;
   b.set_play_taker = env + ME_TAKER * es; b.last_kicker = env + ME_LAST_KICKER * es;
+  b.stopped_cycle = env + ME_STOPPED * es; b.tick = env + ME_TICK * es;
+  b.card = reinterpret_cast<int32_t*>(obj + MF_CARD * os);
   b.reward_left = reinterpret_cast<float*>(h->arena + L.reward);
   b.done = reinterpret_cast<uint8_t*>(h->arena + L.done);
   b.nearest_left = env + ME_NEAREST_L * es; b.nearest_right = env + ME_NEAREST_R * es;
@@ -1123,10 +1235,10 @@ S2D_API int s2d_match_buffer_offsets(S2DMatchHandle h, int64_t* offsets, int n_o
   const S2DMatchBuffers& b = h->buf;
   const void* ptrs[] = {b.x, b.y, b.vx, b.vy, b.body, b.stamina, b.effort, b.recovery, b.stamina_capacity, b.tackle_cycles,
                         b.catch_ban, b.cycle, b.mode, b.mode_side, b.score_left, b.score_right, b.last_touch_side, b.setplay_timer,
-                        b.offside_mask, b.ball_holder, b.goalie_moves, b.set_play_taker, b.last_kicker, b.reward_left, b.done, b.nearest_left, b.nearest_right,
-                        b.stats};
+                        b.offside_mask, b.ball_holder, b.goalie_moves, b.set_play_taker, b.last_kicker, b.stopped_cycle, b.tick, b.card,
+                        b.reward_left, b.done, b.nearest_left, b.nearest_right, b.stats};
   const int count = 1 + (int)(sizeof ptrs / sizeof ptrs[0]);
-  if (n_offsets < count) return mfail(S2D_EINVAL, "offsets array too small (need 29)");
+  if (n_offsets < count) return mfail(S2D_EINVAL, "offsets array too small (need 32)");
   offsets[0] = (int64_t)h->arena_bytes;
   for (int k = 1; k < count; ++k) offsets[k] = (int64_t)(static_cast<const char*>(ptrs[k - 1]) - h->arena);
   return S2D_OK;

@@ -86,8 +86,8 @@ class MatchEngine:
                                            self._stream(), C.byref(h))
         _capi.check(self.lib, rc, 's2d_match_create')
         self._h = h
-        off = (C.c_int64 * 29)()
-        _capi.check(self.lib, self.lib.s2d_match_buffer_offsets(self._h, off, 29), 's2d_match_buffer_offsets')
+        off = (C.c_int64 * 32)()
+        _capi.check(self.lib, self.lib.s2d_match_buffer_offsets(self._h, off, 32), 's2d_match_buffer_offsets')
         n = self.num_envs
         for k, (name, _ct, dt, trail) in enumerate(M.MATCH_BUFFER_FIELDS):
             o = off[k + 1]
@@ -197,7 +197,8 @@ class MatchEngine:
     def world_model(self):
         """dict proto-path -> device tensor (left team's point of view = absolute coordinates)."""
         P = M.MATCH_PLAYERS
-        wm = {'world_model.cycle': self.cycle, 'world_model.game_mode_type': self.mode, 'world_model.game_mode_side': self.mode_side,
+        wm = {'world_model.cycle': self.cycle, 'world_model.stoped_cycle': self.stopped_cycle,
+              'world_model.game_mode_type': self.mode, 'world_model.game_mode_side': self.mode_side,
               'world_model.left_team_score': self.score_left, 'world_model.right_team_score': self.score_right,
               'world_model.last_kick_side': self.last_touch_side,
               'world_model.ball.position.x': self.x[:, M.MATCH_BALL], 'world_model.ball.position.y': self.y[:, M.MATCH_BALL],

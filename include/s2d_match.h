@@ -35,12 +35,19 @@ extern "C" {
  * ChangeView only steer the vision model, which a full-state engine does not have: send S2D_MCMD_NONE. */
 enum { S2D_MCMD_NONE = 0, S2D_MCMD_DASH = 1, S2D_MCMD_TURN = 2, S2D_MCMD_KICK = 3, S2D_MCMD_TACKLE = 4,
        S2D_MCMD_CATCH = 5, S2D_MCMD_MOVE = 6 };
-/* GameModeType values used (idl/service.proto:267-301); the taking side is in mode_side */
+/* GameModeType values used (idl/service.proto:267-301).  mode_side: for the restarts (KickOff_, KickIn_, FreeKick_, CornerKick_,
+ * GoalKick_, IndFreeKick_, GoalieCatch_) the side that takes it; for the ANNOUNCEMENTS (AfterGoal_, OffSide_, BackPass_,
+ * FreeKickFault_, CatchFault_, FoulCharge_: rcssserver's goal_l, offside_l, back_pass_l, ...) the side the call is named after --
+ * the scorer, the offender.  An announcement is a dead ball with the clock stopped; after announce_wait (after_goal_wait) cycles
+ * the referee turns it into the restart for the other side. */
 enum {
   S2D_GM_BEFORE_KICK_OFF = 0, S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4,
   S2D_GM_FREE_KICK = 5, S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_AFTER_GOAL = 8, S2D_GM_OFF_SIDE = 9,
-  S2D_GM_BACK_PASS = 18, S2D_GM_FREE_KICK_FAULT = 19
+  S2D_GM_FIRST_HALF_OVER = 11, S2D_GM_FOUL_CHARGE = 14, S2D_GM_BACK_PASS = 18, S2D_GM_FREE_KICK_FAULT = 19,
+  S2D_GM_CATCH_FAULT = 20, S2D_GM_IND_FREE_KICK = 21, S2D_GM_GOALIE_CATCH = 30
 };
+/* cards (rcssserver's yellow_card / red_card referee messages; no field of the proto's Player carries them) */
+enum { S2D_CARD_NONE = 0, S2D_CARD_YELLOW = 1, S2D_CARD_RED = 2 /* sent off: parked beside the pitch, commands ignored */ };
 
 /* ServerParam fields the match needs beyond S2DServerParams (same names as idl/service.proto:
  * 1435-1662); defaults = rcssserver stock values. */
@@ -65,7 +72,14 @@ typedef struct S2DMatchParams {
                                              (BackPass_, idl/service.proto:286; ServerParam.back_passes :1579) */
   int32_t free_kick_faults;               /* 1: the taker of a set play may not play the ball twice in a row
                                              (FreeKickFault_, :287; ServerParam.free_kick_faults :1578) */
+  int32_t stopped_clock;                  /* 1: the clock (WorldModel.cycle) stands still in BeforeKickOff, AfterGoal_, the
+                                             announcements, FirstHalfOver and TimeOver; WorldModel.stoped_cycle (:333) counts those
+                                             cycles.  0 = the round-1/2 behaviour: time runs in every mode */
+  int32_t announce_wait;                  /* 30: cycles an announcement (OffSide_, BackPass_, FreeKickFault_, CatchFault_,
+                                             FoulCharge_) lasts before the restart it awards (rcssserver's AFTER_*_WAIT) */
+  int32_t foul_cycles;                    /* 5: cycles a fouled player stays down (ServerParam.foul_cycles, :1633) */
   int32_t reserved_mp;
+  double foul_detect_probability;         /* .5: chance that the referee sees an intentional foul (:1632) */
 } S2DMatchParams;
 
 /* PlayerType (idl/service.proto:1697-1732): the members that enter the dynamics.  Type 0 is the
@@ -118,6 +132,9 @@ typedef struct S2DMatchBuffers {
   int32_t *ball_holder, *goalie_moves;  /* 1 + index of the goalie holding a caught ball (0 = nobody), his remaining moves */
   int32_t *set_play_taker, *last_kicker;   /* 1 + index (0 = nobody): who put the ball into play from the last set play and has
                                             not been followed by another touch; who last moved it with a Kick command */
+  int32_t *stopped_cycle;  /* [N] WorldModel.stoped_cycle (idl/service.proto:333): cycles the clock has been standing still */
+  int32_t *tick;           /* [N] simulator cycles since s2d_match_reset, stopped ones included: the Philox counter of every draw */
+  int32_t *card;           /* [N][24] S2D_CARD_* per player */
   float *reward_left;      /* [N] +1 left goal, -1 right goal this cycle */
   uint8_t *done;           /* [N] 1 when the match reached TimeOver this cycle */
   int32_t *nearest_left, *nearest_right;              /* [N] index of the player closest to the ball, per team */
@@ -152,7 +169,7 @@ int s2d_match_buffer_offsets(S2DMatchHandle h, int64_t *offsets, int n_offsets);
 /* kick-off formation, full stamina, score 0-0, cycle 0, KickOff for the left side */
 int s2d_match_reset(S2DMatchHandle h, const uint8_t *mask_dev, void *stream);
 /* actions_dev: float[N][22][3] = {command, a, b}: Dash(power=a, dir=b) Turn(moment=a)
- * Kick(power=a, dir=b) Tackle(dir=a) Catch(dir=a, goalies only) Move(x=a, y=b in the team's own frame: the
+ * Kick(power=a, dir=b) Tackle(power_or_dir=a, foul = b != 0; idl/service.proto:399-402) Catch(dir=a, goalies only) Move(x=a, y=b in the team's own frame: the
  * right team's coordinates are mirrored; legal before a kick-off into the own half, and for a goalie
  * holding a caught ball inside his penalty area); NULL = uniform random policy drawn in-kernel */
 int s2d_match_step(S2DMatchHandle h, const float *actions_dev, void *stream);

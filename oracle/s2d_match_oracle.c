@@ -40,6 +40,7 @@ typedef struct MP {
   int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle, goalie_max_moves;
   int after_goal_wait;
   int kick_off_wait, back_passes, free_kick_faults;
+  int stopped_clock, announce_wait, foul_cycles; REAL foul_detect_probability;
   REAL catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
   /* heterogeneous players: the parameters of every player slot's PlayerType (idl/service.proto:1697-1732) */
@@ -93,6 +94,8 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   p->catch_ban_cycle = m->catch_ban_cycle; p->goalie_max_moves = m->goalie_max_moves;
   p->after_goal_wait = m->after_goal_wait;
   p->kick_off_wait = m->kick_off_wait; p->back_passes = m->back_passes; p->free_kick_faults = m->free_kick_faults;
+  p->stopped_clock = m->stopped_clock; p->announce_wait = m->announce_wait; p->foul_cycles = m->foul_cycles;
+  p->foul_detect_probability = (REAL)m->foul_detect_probability;
   p->catch_half_w = (REAL)(m->catch_area_w * 0.5); p->catch_probability = (REAL)m->catch_probability;
   p->max_catch_angle = (REAL)m->max_catch_angle; p->min_catch_angle = (REAL)m->min_catch_angle;
   p->pen_x = (REAL)(s->pitch_half_length - m->penalty_area_length); p->pen_half_w = (REAL)m->penalty_area_half_width;
@@ -115,7 +118,7 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   }
 }
 
-typedef struct Obj { REAL x, y, vx, vy, body, stamina, effort, recovery, capacity; int32_t tackle, catch_ban; } Obj;
+typedef struct Obj { REAL x, y, vx, vy, body, stamina, effort, recovery, capacity; int32_t tackle, catch_ban, card; } Obj;
 typedef struct Match {
   Obj o[NOBJ];
   int32_t cycle, mode, mode_side, score_left, score_right, last_touch_side, setplay_timer, offside_mask;
@@ -124,12 +127,34 @@ typedef struct Match {
                                            nobody else has touched the ball after (0 = nobody): a second touch is a free-kick fault */
   int32_t last_kicker;                  /* 1 + index of the last player who moved the ball with a Kick command and whom no other
                                            touch (tackle, collision) followed (0 = nobody): the back-pass rule */
+  int32_t stopped_cycle;                /* WorldModel.stoped_cycle (idl/service.proto:333): cycles the clock has been standing still */
+  int32_t tick;                         /* cycles since the reset, stopped ones included: the Philox counter of every draw */
   REAL reward_left; uint8_t done; int32_t nearest_left, nearest_right;
 } Match;
 
 static int side_of(int i) { return i < 11 ? SIDE_LEFT : SIDE_RIGHT; }
 static int other_side(int s) { return s == SIDE_LEFT ? SIDE_RIGHT : SIDE_LEFT; }
 static int is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D_GM_TIME_OVER; }
+/* announcements: a dead ball named after the offending side; after announce_wait cycles the referee awards the restart */
+static int is_announcement(int mode) {
+  return mode == S2D_GM_OFF_SIDE || mode == S2D_GM_BACK_PASS || mode == S2D_GM_FREE_KICK_FAULT || mode == S2D_GM_CATCH_FAULT ||
+         mode == S2D_GM_FOUL_CHARGE;
+}
+/* modes in which nobody may play the ball */
+static int ball_dead(int mode) {
+  return mode == S2D_GM_AFTER_GOAL || mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_GOALIE_CATCH ||
+         is_announcement(mode);
+}
+/* modes in which the clock stands still (with stopped_clock): WorldModel.cycle keeps its value, stoped_cycle counts */
+static int clock_stands(int mode) {
+  return mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_AFTER_GOAL || mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_TIME_OVER ||
+         is_announcement(mode);
+}
+/* where a sent-off player waits: beside the halfway line, outside the pitch, one spot per uniform number */
+static void park_sent_off(const MP *p, Obj *o, int i) {
+  o->x = R(0.0); o->y = (side_of(i) == SIDE_LEFT ? R(-1.0) : R(1.0)) * (p->half_w + R(6.0) + R(1.5) * (REAL)(i % 11));
+  o->vx = R(0.0); o->vy = R(0.0);
+}
 
 /* kick-off formation of the left team (right team mirrored); DESIGN.md section 10 */
 static const REAL FORM_X[11] = {R(-50.0), R(-35.0), R(-35.0), R(-35.0), R(-35.0), R(-20.0), R(-20.0), R(-20.0), R(-20.0), R(-10.5), R(-10.5)};
@@ -139,12 +164,13 @@ static void place_formation(Match *m, int kickoff_side) {
   for (int i = 0; i < NP; ++i) {
     int k = i % 11; int left = i < 11;
     Obj *o = &m->o[i];
+    if (o->card >= S2D_CARD_RED) continue;               /* sent off: stays where he was parked */
     o->x = left ? FORM_X[k] : -FORM_X[k]; o->y = FORM_Y[k];
     o->vx = R(0.0); o->vy = R(0.0); o->body = left ? R(0.0) : R(180.0); o->tackle = 0; o->catch_ban = 0;
   }
   /* the taker stands at the ball */
-  if (kickoff_side == SIDE_LEFT) { m->o[10].x = R(-0.4); m->o[10].y = R(0.0); }
-  else { m->o[21].x = R(0.4); m->o[21].y = R(0.0); }
+  if (kickoff_side == SIDE_LEFT) { if (m->o[10].card < S2D_CARD_RED) { m->o[10].x = R(-0.4); m->o[10].y = R(0.0); } }
+  else { if (m->o[21].card < S2D_CARD_RED) { m->o[21].x = R(0.4); m->o[21].y = R(0.0); } }
   Obj *b = &m->o[BALL]; b->x = R(0.0); b->y = R(0.0); b->vx = R(0.0); b->vy = R(0.0);
 }
 static void recover_all(const MP *p, Match *m, int with_capacity) {
@@ -220,8 +246,9 @@ static int m_kick(const MP *p, const PT *t, const Obj *o, const Obj *b, REAL pow
   *kx = ax; *ky = ay;
   return 1;
 }
-/* Player::tackle (foul = false) -- appendix A.  `u` = uniform draw.  Returns 1 on success. */
-static int m_tackle(const MP *p, const Obj *o, const Obj *b, REAL dir, REAL u, REAL *kx, REAL *ky) {
+/* Player::tackle -- appendix A.  `u` = uniform draw; foul = Tackle.foul (idl/service.proto:401): exponent foul_exponent = 10
+ * instead of tackle_exponent = 6.  Returns 1 on success. */
+static int m_tackle(const MP *p, const Obj *o, const Obj *b, REAL dir, REAL u, int foul, REAL *kx, REAL *ky) {
   REAL dx = b->x - o->x, dy = b->y - o->y;
   REAL sn, cs;
   sincos_deg(o->body, &sn, &cs);
@@ -232,6 +259,7 @@ static int m_tackle(const MP *p, const Obj *o, const Obj *b, REAL dir, REAL u, R
   REAL ty = R(fabs)(ry) / p->tackle_width;
   REAL tx2 = tx * tx, ty2 = ty * ty;
   REAL fail = tx2 * tx2 * tx2 + ty2 * ty2 * ty2;    /* exponent 6 */
+  if (foul) { REAL tx4 = tx2 * tx2, ty4 = ty2 * ty2; fail = tx4 * tx4 * tx2 + ty4 * ty4 * ty2; }   /* exponent 10 */
   if (!(u >= fail)) return 0;
   dir = clampr(dir, R(-180.0), R(180.0));
   REAL ang_ball = R(fabs)(norm_deg(atan2_deg(dy, dx) - o->body));
@@ -291,12 +319,13 @@ typedef struct MatchStats { unsigned long long v[8]; } MatchStats;
 
 /* one cycle of one match; act = [22][3] {cmd, a, b} */
 static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, MatchStats *st) {
-  const uint32_t cyc = (uint32_t)m->cycle;
+  const uint32_t cyc = (uint32_t)m->tick;                /* Philox counter: cycles since the reset, stopped ones included */
   const int mode0 = m->mode, side0 = m->mode_side;
   Obj *b = &m->o[BALL];
-  REAL x0[NOBJ];
-  for (int i = 0; i < NOBJ; ++i) x0[i] = m->o[i].x;
+  REAL x0[NOBJ], y0[NOBJ];
+  for (int i = 0; i < NOBJ; ++i) { x0[i] = m->o[i].x; y0[i] = m->o[i].y; }
   m->reward_left = R(0.0); m->done = 0;
+  int foul_by = -1, foul_victim = -1, foul_seen = 0;      /* an intentional foul of this cycle: tackler, victim, seen by the referee */
 
   /* 1. commands */
   REAL ax[NP], ay[NP], kx[NP], ky[NP];
@@ -310,11 +339,11 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     ax[i] = ay[i] = kx[i] = ky[i] = R(0.0); kicked[i] = 0; by_kick[i] = 0;
     int cmd = (int)act[i * 3 + 0];
     REAL a = (REAL)act[i * 3 + 1], bb = (REAL)act[i * 3 + 2];
-    if (o->tackle > 0 || mode0 == S2D_GM_TIME_OVER) cmd = S2D_MCMD_NONE;
+    if (o->tackle > 0 || mode0 == S2D_GM_TIME_OVER || o->card >= S2D_CARD_RED) cmd = S2D_MCMD_NONE;
     uint32_t nz[4] = {0, 0, 0, 0};                       /* x, y: movement noise; z, w: the command's noise (Turn: z; Kick: z, w) */
     if (p->noise) draw(p->seed, gid, cyc, ST_NOISE, (uint32_t)i, nz);
     /* set play: only the taking side plays the ball; after a goal nobody does */
-    int may_touch = !is_setplay(mode0) || (side_of(i) == side0 && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_BEFORE_KICK_OFF);
+    int may_touch = !is_setplay(mode0) || (side_of(i) == side0 && !ball_dead(mode0));
     if (cmd == S2D_MCMD_DASH) m_dash(p, t, o, a, bb, &ax[i], &ay[i]);
     else if (cmd == S2D_MCMD_TURN) m_turn(p, t, o, a, rnd_u01(nz[2]));
     else if (cmd == S2D_MCMD_CATCH) {
@@ -341,11 +370,29 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
       if (ok && may_touch) { kicked[i] = 1; by_kick[i] = 1; st->v[4]++; } else { kx[i] = ky[i] = R(0.0); }
     } else if (cmd == S2D_MCMD_TACKLE) {
       uint32_t w[4];
+      const int foul = bb != R(0.0);                      /* Tackle.foul */
       draw(p->seed, gid, cyc, ST_TACKLE, (uint32_t)i, w);
-      int ok = m_tackle(p, o, b, a, rnd_u01(w[0]), &kx[i], &ky[i]);
+      int ok = m_tackle(p, o, b, a, rnd_u01(w[0]), foul, &kx[i], &ky[i]);
       o->tackle = p->tackle_cycles + 1;
       st->v[5]++;
       if (ok && may_touch) kicked[i] = 1; else { kx[i] = ky[i] = R(0.0); }
+      /* FoulCharge_ (idl/service.proto:282): a successful INTENTIONAL tackle that goes through an opponent who has the ball
+       * (kickable) inside the tackler's tackle area brings him down for foul_cycles; the referee sees it with
+       * foul_detect_probability (second word of the tackle block).  Positions of the start of the cycle; the first such
+       * tackler (lowest index) counts. */
+      if (ok && foul && mode0 == S2D_GM_PLAY_ON && foul_by < 0) {
+        REAL sn, cs;
+        sincos_deg(m->o[i].body, &sn, &cs);
+        const int o0 = side_of(i) == SIDE_LEFT ? 11 : 0;
+        for (int j = o0; j < o0 + 11 && foul_victim < 0; ++j) {
+          if (m->o[j].card >= S2D_CARD_RED) continue;
+          if (!(hypot2(x0[BALL] - x0[j], y0[BALL] - y0[j]) <= p->pt[j].kickable_area)) continue;
+          REAL dx = x0[j] - x0[i], dy = y0[j] - y0[i];
+          REAL rx = dx * cs + dy * sn, ry = dy * cs - dx * sn;
+          if (rx >= R(0.0) && rx <= p->tackle_dist && R(fabs)(ry) <= p->tackle_width) foul_victim = j;
+        }
+        if (foul_victim >= 0) { foul_by = i; foul_seen = rnd_u01(w[1]) < p->foul_detect_probability; }
+      }
     }
     /* _inc of player i */
     if (cmd == S2D_MCMD_DASH) {
@@ -361,6 +408,11 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   if (caught_by >= 0) st->v[4]++;
   if (caught_by >= 0 || hold_move >= 0)                    /* a catch / a move with the ball wins the cycle: kicks are dropped */
     for (int i = 0; i < NP; ++i) { kicked[i] = 0; by_kick[i] = 0; kx[i] = ky[i] = R(0.0); }
+  if (foul_by >= 0) {                                      /* the victim goes down; a foul the referee saw is a card */
+    Obj *v = &m->o[foul_victim];
+    if (v->tackle < p->foul_cycles + 1) v->tackle = p->foul_cycles + 1;
+    if (foul_seen && m->o[foul_by].card < S2D_CARD_RED) m->o[foul_by].card += 1;
+  }
   /* 2. ball: accelerations summed in player order */
   REAL bax = R(0.0), bay = R(0.0);
   int any_kick = 0, last_kicker = -1, last_kick_cmd = -1, other_touch = 0;
@@ -435,9 +487,11 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     if (touch_player + 1 != m->set_play_taker) m->set_play_taker = 0;
     if (touch_player + 1 != m->last_kicker) m->last_kicker = 0;
   }
-  /* 4. set play: opponents keep free_kick_distance from the ball (nobody has to after a goal) */
-  if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL) {
-    for (int i = 0; i < NP; ++i) if (side_of(i) != side0) {
+  /* 4. set play: the side that does not take it keeps free_kick_distance from the ball; during an announcement that is the
+   * offending side, the one the mode is named after (the restart will be the other side's) */
+  if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_FIRST_HALF_OVER) {
+    const int kept_away = is_announcement(mode0) ? side0 : other_side(side0);
+    for (int i = 0; i < NP; ++i) if (side_of(i) == kept_away && m->o[i].card < S2D_CARD_RED) {
       Obj *o = &m->o[i];
       REAL dx = o->x - b->x, dy = o->y - b->y, d = hypot2(dx, dy);
       if (d < p->free_kick_distance) {
@@ -447,8 +501,11 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
       }
     }
   }
-  /* 5. referee */
-  m->cycle = (int32_t)((uint32_t)m->cycle + 1u);
+  /* 5. referee.  The clock: WorldModel.cycle advances unless the mode of this cycle is one in which it stands still */
+  m->tick = (int32_t)((uint32_t)m->tick + 1u);
+  const int advanced = !(p->stopped_clock && clock_stands(mode0));
+  if (advanced) { m->cycle = (int32_t)((uint32_t)m->cycle + 1u); m->stopped_cycle = 0; }
+  else m->stopped_cycle += 1;
   if (mode0 != S2D_GM_TIME_OVER) {
     if (mode0 == S2D_GM_AFTER_GOAL) {                   /* the ball is dead until the wait is over, then the conceding side kicks off */
       m->setplay_timer += 1;
@@ -460,6 +517,16 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     } else if (mode0 == S2D_GM_BEFORE_KICK_OFF) {        /* BeforeKickOff (idl/service.proto:268): nobody plays the ball, players may Move */
       m->setplay_timer += 1;
       if (m->setplay_timer >= p->kick_off_wait) { m->mode = S2D_GM_KICK_OFF; m->setplay_timer = 0; }
+    } else if (mode0 == S2D_GM_FIRST_HALF_OVER) {        /* one cycle of "half time" (idl/service.proto:279), then the next half's kick-off */
+      m->mode = p->kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF; m->setplay_timer = 0;
+    } else if (mode0 == S2D_GM_GOALIE_CATCH) {           /* one cycle of "goalie_catch_ball" (:298), then his free kick */
+      m->mode = S2D_GM_FREE_KICK; m->setplay_timer = 0;
+    } else if (is_announcement(mode0)) {                 /* offside_l, back_pass_l, ...: after the wait, the restart for the other side */
+      m->setplay_timer += 1;
+      if (m->setplay_timer >= p->announce_wait) {
+        m->mode = (mode0 == S2D_GM_BACK_PASS || mode0 == S2D_GM_FREE_KICK_FAULT) ? S2D_GM_IND_FREE_KICK : S2D_GM_FREE_KICK;
+        m->mode_side = other_side(side0); m->setplay_timer = 0;
+      }
     } else if (is_setplay(mode0)) {
       if (any_kick) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; }
       else { m->setplay_timer += 1; if (m->setplay_timer > p->drop_ball_time) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; } }
@@ -498,12 +565,14 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
          * kick for the other side from the nearer front corner of the penalty area */
         const int lk = m->last_kicker - 1;
         const int back_pass = p->back_passes && in_area && lk >= 0 && lk != caught_by && side_of(lk) == gs;
-        /* otherwise, inside the own penalty area: free kick for the goalie's side; outside: catch fault */
-        if (back_pass) restart(m, S2D_GM_BACK_PASS, other_side(gs), gs == SIDE_LEFT ? -p->pen_x : p->pen_x, by > R(0.0) ? p->pen_half_w : -p->pen_half_w);
-        else restart(m, S2D_GM_FREE_KICK, in_area ? gs : other_side(gs), bx, by);
+        /* otherwise, inside the own penalty area: GoalieCatch_, then a free kick for the goalie's side; outside: CatchFault_ */
+        if (back_pass) restart(m, S2D_GM_BACK_PASS, gs, gs == SIDE_LEFT ? -p->pen_x : p->pen_x, by > R(0.0) ? p->pen_half_w : -p->pen_half_w);
+        else restart(m, in_area ? S2D_GM_GOALIE_CATCH : S2D_GM_CATCH_FAULT, gs, bx, by);
         if (in_area && !back_pass) { m->ball_holder = caught_by + 1; m->goalie_moves = p->goalie_max_moves; }
+      } else if (foul_by >= 0 && foul_seen) {                                /* the referee saw the foul: FoulCharge_ where the ball is */
+        restart(m, S2D_GM_FOUL_CHARGE, side_of(foul_by), clampr(bx, -p->half_l, p->half_l), clampr(by, -p->half_w, p->half_w));
       } else if (fk_fault) {                                                 /* the taker touched the ball twice */
-        restart(m, S2D_GM_FREE_KICK_FAULT, other_side(side_of(taker0 - 1)), clampr(bx, -p->half_l, p->half_l), clampr(by, -p->half_w, p->half_w));
+        restart(m, S2D_GM_FREE_KICK_FAULT, side_of(taker0 - 1), clampr(bx, -p->half_l, p->half_l), clampr(by, -p->half_w, p->half_w));
       } else if (bx > p->half_l && R(fabs)(by) < p->goal_half_width) {       /* goal for the left team */
         m->score_left += 1; m->reward_left = R(1.0); st->v[1]++;
         if (p->after_goal_wait > 0) restart(m, S2D_GM_AFTER_GOAL, SIDE_LEFT, bx, by);   /* the ball rests in the net */
@@ -530,25 +599,27 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
           REAL dx = m->o[t].x - bx, dy = m->o[t].y - by;
           if (sq2(dx, dy) < p->offside_area2) {
             st->v[6]++;
-            restart(m, S2D_GM_OFF_SIDE, other_side(side_of(t)), m->o[t].x, m->o[t].y);
+            restart(m, S2D_GM_OFF_SIDE, side_of(t), m->o[t].x, m->o[t].y);
             break;
           }
         }
       }
     }
-    /* half time / time over */
+    /* half time / time over: only when the clock has just moved */
     int total = p->half_time_cycles * p->nr_normal_halfs;
-    if (m->cycle >= total) {
+    if (advanced && m->cycle >= total) {
       m->mode = S2D_GM_TIME_OVER; m->mode_side = SIDE_NONE; m->done = 1; m->offside_mask = 0; st->v[3]++;
-    } else if (p->half_time_cycles > 0 && m->cycle % p->half_time_cycles == 0) {
+    } else if (advanced && p->half_time_cycles > 0 && m->cycle % p->half_time_cycles == 0) {
       int k = m->cycle / p->half_time_cycles;
       int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
       recover_all(p, m, 0);
       place_formation(m, ks);
-      restart(m, p->kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, ks, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
+      restart(m, S2D_GM_FIRST_HALF_OVER, ks, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
     }
-    if (m->mode != S2D_GM_FREE_KICK) { m->ball_holder = 0; m->goalie_moves = 0; }   /* nobody holds the ball any more */
+    if (m->mode != S2D_GM_FREE_KICK && m->mode != S2D_GM_GOALIE_CATCH) { m->ball_holder = 0; m->goalie_moves = 0; }   /* nobody holds the ball any more */
   }
+  /* a second card is a red one: the player leaves the pitch (checked every cycle; a parked player does not move) */
+  for (int i = 0; i < NP; ++i) if (m->o[i].card >= S2D_CARD_RED) park_sent_off(p, &m->o[i], i);
   /* 6. decay, tackle timers, stamina */
   for (int i = 0; i < NP; ++i) {
     Obj *o = &m->o[i];
@@ -569,9 +640,9 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   }
   st->v[0]++;
   if (m->done && p->auto_reset) {
-    uint8_t d = m->done; REAL rw = m->reward_left;
+    uint8_t d = m->done; REAL rw = m->reward_left; int32_t tk = m->tick;
     match_reset(p, m);
-    m->done = d; m->reward_left = rw;
+    m->done = d; m->reward_left = rw; m->tick = tk;      /* the draws of the next match continue the sequence */
   }
 }
 
@@ -616,7 +687,7 @@ API void s2dmo_step(S2DMOEngine *h, const float *actions) {
     for (int64_t e = 0; e < h->n; ++e) {
       float buf[NP * 3];
       const float *a = actions ? actions + (size_t)e * NP * 3 : buf;
-      if (!actions) random_actions(&h->p, (uint64_t)(h->p.env_id_offset + e), (uint32_t)h->m[e].cycle, buf);
+      if (!actions) random_actions(&h->p, (uint64_t)(h->p.env_id_offset + e), (uint32_t)h->m[e].tick, buf);
       match_step(&h->p, &h->m[e], (uint64_t)(h->p.env_id_offset + e), a, &loc);
     }
 #pragma omp critical
@@ -630,13 +701,13 @@ API void s2dmo_step(S2DMOEngine *h, const float *actions) {
 API int s2dmo_get(const S2DMOEngine *h, int field, double *out) {
   for (int64_t e = 0; e < h->n; ++e) {
     const Match *m = &h->m[e];
-    if (field <= 9 || field == 22) {                     /* 22 = catch_ban (object plane) */
+    if (field <= 9 || field == 22 || field == 29) {      /* 22 = catch_ban, 29 = card (object planes) */
       for (int s = 0; s < S2D_MATCH_SLOTS; ++s) {
         double v = 0;
         if (s < NOBJ) {
           const Obj *o = &m->o[s];
           switch (field) {
-            case 22: v = o->catch_ban; break;
+            case 22: v = o->catch_ban; break; case 29: v = o->card; break;
             case 0: v = o->x; break; case 1: v = o->y; break; case 2: v = o->vx; break; case 3: v = o->vy; break;
             case 4: v = o->body; break; case 5: v = o->stamina; break; case 6: v = o->effort; break;
             case 7: v = o->recovery; break; case 8: v = o->capacity; break; default: v = o->tackle; break;
@@ -653,6 +724,7 @@ API int s2dmo_get(const S2DMOEngine *h, int field, double *out) {
         case 19: v = m->done; break; case 20: v = m->nearest_left; break; case 21: v = m->nearest_right; break;
         case 23: v = m->ball_holder; break; case 24: v = m->goalie_moves; break;
         case 25: v = m->set_play_taker; break; case 26: v = m->last_kicker; break;
+        case 27: v = m->stopped_cycle; break; case 28: v = m->tick; break;
         default: return -1;
       }
       out[e] = v;
@@ -667,6 +739,11 @@ API int s2dmo_set_obj(S2DMOEngine *h, int64_t e, int slot, const double *v10) {
   o->x = (REAL)v10[0]; o->y = (REAL)v10[1]; o->vx = (REAL)v10[2]; o->vy = (REAL)v10[3]; o->body = (REAL)v10[4];
   o->stamina = (REAL)v10[5]; o->effort = (REAL)v10[6]; o->recovery = (REAL)v10[7]; o->capacity = (REAL)v10[8];
   o->tackle = (int32_t)v10[9]; o->catch_ban = 0;
+  return 0;
+}
+API int s2dmo_set_card(S2DMOEngine *h, int64_t e, int slot, int card) {
+  if (e < 0 || e >= h->n || slot < 0 || slot >= NP) return -1;
+  h->m[e].o[slot].card = card;
   return 0;
 }
 API int s2dmo_set_touch(S2DMOEngine *h, int64_t e, int set_play_taker, int last_kicker) {
@@ -694,5 +771,5 @@ API void s2dmo_relative(const S2DMOEngine *h, float *dist, float *angle) {
 }
 API void s2dmo_random_actions(const S2DMOEngine *h, float *out) {
   for (int64_t e = 0; e < h->n; ++e)
-    random_actions(&h->p, (uint64_t)(h->p.env_id_offset + e), (uint32_t)h->m[e].cycle, out + (size_t)e * NP * 3);
+    random_actions(&h->p, (uint64_t)(h->p.env_id_offset + e), (uint32_t)h->m[e].tick, out + (size_t)e * NP * 3);
 }

@@ -16,7 +16,8 @@ MATCH_DEFAULTS = dict(
     tackle_cycles=10, half_time_cycles=3000, nr_normal_halfs=2, drop_ball_time=100, use_offside=1, catch_ban_cycle=5,
     catchable_area_l=1.2, catch_area_w=1.0, catch_probability=1.0, max_catch_angle=90.0, min_catch_angle=-90.0,
     penalty_area_length=16.5, penalty_area_half_width=20.16, goalie_max_moves=2, after_goal_wait=50,
-    kick_off_wait=0, back_passes=1, free_kick_faults=1)
+    kick_off_wait=0, back_passes=1, free_kick_faults=1, stopped_clock=1, announce_wait=30, foul_cycles=5,
+    foul_detect_probability=0.5)
 
 
 def default_player_type(sp, mp):
@@ -29,8 +30,8 @@ def default_player_type(sp, mp):
                 catchable_area_l_stretch=1.0)
 
 OBJ_FIELDS = ('x', 'y', 'vx', 'vy', 'body', 'stamina', 'effort', 'recovery', 'stamina_capacity', 'tackle_cycles')
-EXTRA_OBJ_FIELDS = {'catch_ban': 22}      # s2dmo_get field ids beyond the contiguous block
-EXTRA_ENV_FIELDS = {'ball_holder': 23, 'goalie_moves': 24, 'set_play_taker': 25, 'last_kicker': 26}
+EXTRA_OBJ_FIELDS = {'catch_ban': 22, 'card': 29}      # s2dmo_get field ids beyond the contiguous block
+EXTRA_ENV_FIELDS = {'ball_holder': 23, 'goalie_moves': 24, 'set_play_taker': 25, 'last_kicker': 26, 'stopped_cycle': 27, 'tick': 28}
 ENV_FIELDS = ('cycle', 'mode', 'mode_side', 'score_left', 'score_right', 'last_touch_side', 'setplay_timer',
               'offside_mask', 'reward_left', 'done', 'nearest_left', 'nearest_right')
 
@@ -85,6 +86,7 @@ def lib():
         L.s2dmo_set_obj.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]; L.s2dmo_set_obj.restype = C.c_int
         L.s2dmo_set_game.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]; L.s2dmo_set_game.restype = C.c_int
         L.s2dmo_set_touch.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]; L.s2dmo_set_touch.restype = C.c_int
+        L.s2dmo_set_card.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]; L.s2dmo_set_card.restype = C.c_int
         L.s2dmo_stats.argtypes = [C.c_void_p]; L.s2dmo_stats.restype = C.POINTER(C.c_ulonglong)
         L.s2dmo_random_actions.argtypes = [C.c_void_p, C.c_void_p]; L.s2dmo_random_actions.restype = None
         L.s2dmo_relative.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; L.s2dmo_relative.restype = None
@@ -131,7 +133,7 @@ class MatchOracle:
             idx = OBJ_FIELDS.index(name) if name in OBJ_FIELDS else EXTRA_OBJ_FIELDS[name]
             out = np.zeros((self.n, 24))
             assert self.L.s2dmo_get(self.h, idx, out.ctypes.data_as(C.POINTER(C.c_double))) == 0
-            return out.astype(np.int32 if name in ('tackle_cycles', 'catch_ban') else np.float32)
+            return out.astype(np.int32 if name in ('tackle_cycles', 'catch_ban', 'card') else np.float32)
         idx = EXTRA_ENV_FIELDS[name] if name in EXTRA_ENV_FIELDS else 10 + ENV_FIELDS.index(name)
         out = np.zeros(self.n)
         assert self.L.s2dmo_get(self.h, idx, out.ctypes.data_as(C.POINTER(C.c_double))) == 0

@@ -32,7 +32,7 @@ def _bits(a):
 
 def assert_match_same(eng, orc, tag):
     torch.cuda.synchronize()
-    for f in MO.OBJ_FIELDS + ('catch_ban',) + MO.ENV_FIELDS + ('ball_holder', 'goalie_moves', 'set_play_taker', 'last_kicker'):
+    for f in MO.OBJ_FIELDS + ('catch_ban', 'card') + MO.ENV_FIELDS + ('ball_holder', 'goalie_moves', 'set_play_taker', 'last_kicker', 'stopped_cycle', 'tick'):
         g = getattr(eng, f).cpu().numpy()
         c = orc.get(f)
         if not np.array_equal(_bits(g), _bits(c)):
@@ -114,7 +114,8 @@ def test_match_full_size_rollout_parity():
     assert list(eng.stats.cpu().numpy()) == list(orc.stats())
     wm = eng.world_model()
     assert wm['world_model.teammates.position.x'].shape == (n, 11) and wm['world_model.opponents.body_direction'].shape == (n, 11)
-    assert int(wm['world_model.cycle'].min()) == T
+    assert int(eng.tick.min()) == T and int(wm['world_model.cycle'].max()) == T            # (the clock of a match that saw a call stood still)
+    assert torch.equal(wm['world_model.cycle'] + 0, eng.cycle) and int(wm['world_model.stoped_cycle'].max()) > 0
 
 
 def test_scripted_policy_beats_idle_and_random_in_league_round():
@@ -155,7 +156,7 @@ def test_match_vec_env_surface():
         assert np.array_equal(rew.cpu().numpy(), orc.get('reward_left')) and np.array_equal(done.cpu().numpy(), orc.get('done'))
         assert np.array_equal(info['game_mode_type'].cpu().numpy(), orc.get('mode'))
         dones += int(done.sum())
-    assert dones == 32
+    assert 16 <= dones <= 32                               # 30 + FirstHalfOver + 30 cycles of play; announcements stop the clock of some
 
 
 def test_relative_tables_parity_and_nearest_k():
@@ -382,6 +383,84 @@ def test_match_round2_rules_on_device():
     both(acts(p0=[MCMD_CATCH, 0, 0]))
     assert (orc.get('mode') == GM_BACK_PASS).all() and (eng.mode.cpu().numpy() == GM_BACK_PASS).all()
     assert {GM_BEFORE_KICK_OFF, GM_FREE_KICK_FAULT, GM_BACK_PASS} <= seen
+
+
+def test_match_round3_rules_on_device():
+    """Round 3: the stopped clock (stoped_cycle), the announcements and the restarts they award (OffSide_ -> FreeKick_, FreeKickFault_ /
+    BackPass_ -> IndFreeKick_, CatchFault_), GoalieCatch_, FirstHalfOver, intentional fouls with cards and a sending-off: scripted
+    sequences on the device, every word equal to the oracle after every cycle, and every new mode does occur."""
+    from soccer2d_amd._capi_match import (CARD_RED, CARD_YELLOW, GM_CATCH_FAULT, GM_FIRST_HALF_OVER, GM_FOUL_CHARGE, GM_FREE_KICK,
+                                          GM_FREE_KICK_FAULT, GM_GOALIE_CATCH, GM_IND_FREE_KICK, MCMD_CATCH, MCMD_DASH, MCMD_KICK,
+                                          MCMD_TACKLE)
+    n = 8
+    eng, orc = _pair(n, half_time_cycles=60, announce_wait=4, foul_detect_probability=1.0, auto_reset=0)
+    seen = set()
+
+    def both(a):
+        eng.step(torch.as_tensor(a, device='cuda:0')); orc.step(a)
+        assert_match_same(eng, orc, 'round-3 rules')
+        seen.update(int(m) for m in orc.get('mode'))
+
+    def acts(**pp):
+        a = np.zeros((n, 22, 3), dtype=np.float32)
+        for k, v in pp.items():
+            a[:, int(k[1:])] = v
+        return a
+
+    def put(slot, **kw):
+        for e in range(n):
+            orc.set_obj(e, slot, **kw)                                   # (the oracle's setter also clears the slot's catch ban)
+            eng.catch_ban[e, slot] = 0
+            for k, v in kw.items():
+                getattr(eng, k)[e, slot] = v
+
+    def play_on():
+        for e in range(n):
+            orc.set_game(e, mode=2, mode_side=0); eng.mode[e] = 2; eng.mode_side[e] = 0
+    # double touch by the kick-off taker -> FreeKickFault_ (4 stopped cycles) -> IndFreeKick_ for the right side
+    both(acts(p10=[MCMD_KICK, 20, 0])); both(acts(p10=[MCMD_DASH, 100, 0])); both(acts(p10=[MCMD_KICK, 50, 0]))
+    assert (orc.get('mode') == GM_FREE_KICK_FAULT).all() and (orc.get('mode_side') == 1).all()
+    c0 = orc.get('cycle').copy()
+    for _ in range(4):
+        both(acts(p10=[MCMD_KICK, 50, 0]))
+    assert (orc.get('mode') == GM_IND_FREE_KICK).all() and (orc.get('mode_side') == 2).all() and (orc.get('cycle') == c0).all()
+    assert (eng.stopped_cycle.cpu().numpy() == 4).all()
+    # an intentional foul: left #6 goes through a right player on the ball; seen by the referee (probability 1): FoulCharge_ + yellow
+    play_on()
+    put(5, x=0.0, y=0.0, body=0.0, tackle_cycles=0); put(15, x=1.0, y=0.2, body=180.0); put(22, x=0.7, y=0.1, vx=0.0, vy=0.0)
+    fouled = 0
+    for k in range(12):
+        both(acts(p5=[MCMD_TACKLE, 0, 1]))
+        if (orc.get('mode') == GM_FOUL_CHARGE).all():
+            fouled += 1
+            cards = eng.card.cpu().numpy()[:, 5]
+            assert (cards == (CARD_YELLOW if fouled == 1 else CARD_RED)).all()
+            for _ in range(4):
+                both(acts())
+            assert (orc.get('mode') == GM_FREE_KICK).all() and (orc.get('mode_side') == 2).all()
+            if fouled == 2:
+                break
+            play_on()
+            put(5, x=0.0, y=0.0, body=0.0, tackle_cycles=0); put(15, x=1.0, y=0.2, body=180.0, tackle_cycles=0); put(22, x=0.7, y=0.1, vx=0.0, vy=0.0)
+    assert fouled == 2 and (eng.x.cpu().numpy()[:, 5] == 0.0).all() and (eng.y.cpu().numpy()[:, 5] < -34.0).all()   # sent off
+    # goalie catch inside the area -> GoalieCatch_ -> FreeKick_; outside -> CatchFault_
+    play_on()
+    put(22, x=-49.2, y=0.3, vx=-1.0, vy=0.0)
+    both(acts(p0=[MCMD_CATCH, 0, 0]))
+    assert (orc.get('mode') == GM_GOALIE_CATCH).all()
+    both(acts()); both(acts(p0=[MCMD_KICK, 100, 0]))
+    play_on()
+    put(0, x=-30.0, y=0.0, body=0.0); put(22, x=-29.2, y=0.0, vx=0.0, vy=0.0)
+    for _ in range(6):
+        both(acts())                                                     # (the catch ban of the first attempt runs out)
+    both(acts(p0=[MCMD_CATCH, 0, 0]))
+    assert (orc.get('mode') == GM_CATCH_FAULT).all()
+    # ... and on through half time
+    while not (orc.get('mode') == GM_FIRST_HALF_OVER).all():
+        both(acts())
+    both(acts())
+    assert (eng.x.cpu().numpy()[:, 5] == 0.0).all()                      # the kick-off formation leaves the sent-off player where he is
+    assert {GM_FREE_KICK_FAULT, GM_IND_FREE_KICK, GM_FOUL_CHARGE, GM_FREE_KICK, GM_GOALIE_CATCH, GM_CATCH_FAULT, GM_FIRST_HALF_OVER} <= seen
 
 
 def test_match_parity_under_scripted_policies():

@@ -186,8 +186,21 @@ def test_offside_is_called():
     assert m.get('offside_mask')[0] == 1 << 10 and m.get('mode')[0] == GM_PLAY_ON
     m.set_obj(0, 22, x=34.0, y=0.5, vx=0.0, vy=0.0)                      # ball arrives at the flagged player
     m.step(acts())
-    assert m.get('mode')[0] == GM_OFF_SIDE and m.get('mode_side')[0] == RIGHT and m.stats()[6] == 1
+    assert m.get('mode')[0] == GM_OFF_SIDE and m.get('mode_side')[0] == LEFT and m.stats()[6] == 1      # offside_l: named after the offender
     assert m.get('x')[0][22] == pytest.approx(m.get('x')[0][10]) and m.get('offside_mask')[0] == 0
+    # the announcement: 30 cycles of dead ball with the clock stopped, then the free kick for the other side
+    from soccer2d_amd._capi_match import GM_FREE_KICK
+    c0 = int(m.get('cycle')[0])
+    for k in range(29):
+        m.step(acts(p12=[MCMD_KICK, 100, 0], p10=[MCMD_KICK, 100, 0]))
+        assert m.get('mode')[0] == GM_OFF_SIDE and m.get('cycle')[0] == c0 and m.get('stopped_cycle')[0] == k + 1
+        # the offending side is cleared from the ball (free_kick_distance), the side that will take the free kick is not
+        bx, by = m.get('x')[0][22], m.get('y')[0][22]
+        assert np.hypot(m.get('x')[0][10] - bx, m.get('y')[0][10] - by) == pytest.approx(9.15, rel=1e-6)
+    m.step(acts())
+    assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == RIGHT and m.get('cycle')[0] == c0 and m.get('stopped_cycle')[0] == 30
+    m.step(acts())
+    assert m.get('cycle')[0] == c0 + 1 and m.get('stopped_cycle')[0] == 0 and m.get('tick')[0] == c0 + 31
     # not offside from a kick-in
     m = fresh(); m.set_game(0, mode=GM_KICK_IN, mode_side=LEFT)
     for i in range(11, 22):
@@ -203,29 +216,40 @@ def test_half_time_and_time_over():
     for _ in range(19):
         m.step(acts(p3=[MCMD_DASH, 100, 0]))
     assert m.get('stamina')[0][3] < 8000 and m.get('cycle')[0] == 19
+    from soccer2d_amd._capi_match import GM_FIRST_HALF_OVER
     m.step(acts())
-    assert m.get('cycle')[0] == 20 and m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == RIGHT
+    # half time: one cycle of FirstHalfOver (clock stopped), then the kick-off of the side that did not start the match
+    assert m.get('cycle')[0] == 20 and m.get('mode')[0] == GM_FIRST_HALF_OVER and m.get('mode_side')[0] == RIGHT
     assert m.get('stamina')[0][3] == 8000 and m.get('stamina_capacity')[0][3] < 130600      # capacity is not restored
+    m.step(acts())
+    assert m.get('cycle')[0] == 20 and m.get('stopped_cycle')[0] == 1 and m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == RIGHT
     for _ in range(20):
         m.step(acts())
     assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1 and m.get('cycle')[0] == 40
     m.step(acts(p3=[MCMD_DASH, 100, 0]))
     assert m.get('done')[0] == 0 and m.get('vx')[0][3] == 0            # time over: commands ignored
+    assert m.get('cycle')[0] == 40 and m.get('stopped_cycle')[0] == 1  # ... and the clock stands
     m = fresh(half_time_cycles=5, auto_reset=1)
-    for _ in range(10):
+    for _ in range(11):                                                 # 5 + FirstHalfOver + 5
         m.step(acts())
     assert m.get('done')[0] == 1 and m.get('cycle')[0] == 0 and m.get('mode')[0] == GM_KICK_OFF and m.stats()[3] == 1
+    assert m.get('tick')[0] == 11                                       # the draws of the next match continue the sequence
+    # stopped_clock = 0: the round-2 behaviour, time runs in every mode
+    m = fresh(half_time_cycles=20, auto_reset=0, stopped_clock=0); play_on(m)
+    for _ in range(22):
+        m.step(acts())
+    assert m.get('cycle')[0] == 22 and m.get('stopped_cycle')[0] == 0 and m.get('mode')[0] == GM_KICK_OFF
 
 
 def test_random_matches_are_deterministic_and_eventful():
     n = 64
     a, b = fresh(n, half_time_cycles=400), fresh(n, half_time_cycles=400)
-    for _ in range(800):
+    for _ in range(1300):                                  # 800 cycles of play + the stopped ones (after goals, offside calls, half time)
         a.step(None); b.step(None)
     for f in MO.OBJ_FIELDS + MO.ENV_FIELDS:
         assert np.array_equal(a.get(f), b.get(f)), f
     st = a.stats()
-    assert st[0] == n * 800 and st[3] == n and st[4] > 0 and st[5] > 0 and st[7] > 0
+    assert st[0] == n * 1300 and st[3] >= n // 2 and st[4] > 0 and st[5] > 0 and st[7] > 0
     assert np.isfinite(a.get('x')).all() and np.abs(a.get('x')[:, :22]).max() < 80
     acts0 = a.random_actions()
     assert set(np.unique(acts0[..., 0])) <= {1.0, 2.0, 3.0, 4.0}
@@ -245,14 +269,17 @@ def test_goalie_catch_gives_free_kick_and_bans_catching():
     from soccer2d_amd._capi_match import GM_FREE_KICK, MCMD_CATCH
     m = fresh(); play_on(m)
     m.set_obj(0, 22, x=-49.2, y=0.3, vx=-1.0, vy=0.0)      # ball 0.8 m in front of the left goalie (-50, 0), moving in
+    from soccer2d_amd._capi_match import GM_GOALIE_CATCH
     m.step(acts(p0=[MCMD_CATCH, 0, 0]))
-    assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == LEFT and m.get('last_touch_side')[0] == LEFT
+    assert m.get('mode')[0] == GM_GOALIE_CATCH and m.get('mode_side')[0] == LEFT and m.get('last_touch_side')[0] == LEFT
     # held: the ball rests where it was caught, no goal is scored, the goalie is banned for 5 cycles
     assert m.get('vx')[0][22] == 0 and m.get('x')[0][22] == pytest.approx(-49.2) and m.get('score_right')[0] == 0
     assert m.get('catch_ban')[0][0] == 5 and m.stats()[4] == 1
-    # opponents are kept 9.15 m away during the free kick; the goalie's kick resumes play
+    # one cycle of GoalieCatch_ (the clock runs), then the goalie's free kick: opponents are kept 9.15 m away; his kick resumes play
     m.set_obj(0, 21, x=-48.0, y=0.3)
-    m.step(acts())
+    c0 = int(m.get('cycle')[0])
+    m.step(acts(p0=[MCMD_KICK, 100, 0]))                    # not yet: the ball is dead for this one cycle
+    assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == LEFT and m.get('cycle')[0] == c0 + 1 and m.get('vx')[0][22] == 0
     assert np.hypot(m.get('x')[0][21] + 49.2, m.get('y')[0][21] - 0.3) == pytest.approx(9.15, rel=1e-6)
     m.step(acts(p0=[MCMD_KICK, 100, 0]))
     assert m.get('mode')[0] == GM_PLAY_ON and m.get('vx')[0][22] > 0
@@ -278,7 +305,8 @@ def test_catch_needs_goalie_rectangle_and_no_ban():
     m = fresh(); play_on(m)
     m.set_obj(0, 22, x=-50.0, y=0.9)
     m.step(acts(p0=[MCMD_CATCH, 90, 0]))                   # dir = +90 deg turns the rectangle towards +y
-    assert m.get('mode')[0] == GM_FREE_KICK
+    from soccer2d_amd._capi_match import GM_GOALIE_CATCH
+    assert m.get('mode')[0] == GM_GOALIE_CATCH
 
 
 def test_catch_outside_the_penalty_area_is_a_fault():
@@ -286,8 +314,12 @@ def test_catch_outside_the_penalty_area_is_a_fault():
     m = fresh(); play_on(m)
     m.set_obj(0, 0, x=-30.0, y=0.0)                        # goalie far out of his area (x > -36)
     m.set_obj(0, 22, x=-29.2, y=0.0)
+    from soccer2d_amd._capi_match import GM_CATCH_FAULT
     m.step(acts(p0=[MCMD_CATCH, 0, 0]))
-    assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == RIGHT
+    assert m.get('mode')[0] == GM_CATCH_FAULT and m.get('mode_side')[0] == LEFT           # catch_fault_l: the left goalie's fault
+    for _ in range(30):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == RIGHT and m.get('ball_holder')[0] == 0
 
 
 # ------------------------------------------------------------------ heterogeneous PlayerTypes
@@ -333,7 +365,9 @@ def test_move_before_kick_off_and_with_a_caught_ball():
     m = fresh(); play_on(m)
     m.set_obj(0, 22, x=-49.3, y=0.0)
     m.step(acts(p0=[MCMD_CATCH, 0, 0]))
-    assert m.get('mode')[0] == GM_FREE_KICK and m.get('ball_holder')[0] == 1 and m.get('goalie_moves')[0] == 2
+    assert m.get('ball_holder')[0] == 1 and m.get('goalie_moves')[0] == 2
+    m.step(acts(p0=[MCMD_MOVE, -40.0, 10.0]))              # GoalieCatch_ cycle: not yet
+    assert m.get('mode')[0] == GM_FREE_KICK and m.get('x')[0][0] == -50.0 and m.get('goalie_moves')[0] == 2
     m.step(acts(p0=[MCMD_MOVE, -40.0, 10.0]))
     assert (m.get('x')[0][0], m.get('y')[0][0]) == (-40.0, 10.0) and m.get('goalie_moves')[0] == 1
     assert m.get('x')[0][22] == pytest.approx(-40.0 + 0.485) and m.get('y')[0][22] == pytest.approx(10.0)   # in front of the body (0 deg)
@@ -362,11 +396,17 @@ def test_before_kick_off_mode_waits_and_lets_players_move():
     assert m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == LEFT and m.get('setplay_timer')[0] == 0
     m.step(acts(p10=[MCMD_KICK, 100, 0]))
     assert m.get('mode')[0] == GM_PLAY_ON
-    # half time goes through BeforeKickOff again, for the side that kicks off the second half
+    # the clock stood still during the wait: WorldModel.cycle 0, stoped_cycle counted the four cycles
+    assert m.get('cycle')[0] == 1 and m.get('tick')[0] == 5
+    # half time goes through FirstHalfOver and BeforeKickOff again, for the side that kicks off the second half
+    from soccer2d_amd._capi_match import GM_FIRST_HALF_OVER
     while m.get('cycle')[0] < 20:
         m.step(acts())
-    assert m.get('mode')[0] == GM_BEFORE_KICK_OFF and m.get('mode_side')[0] == RIGHT
-    for _ in range(4):
+    assert m.get('mode')[0] == GM_FIRST_HALF_OVER and m.get('mode_side')[0] == RIGHT
+    m.step(acts())
+    assert m.get('mode')[0] == GM_BEFORE_KICK_OFF and m.get('mode_side')[0] == RIGHT and m.get('cycle')[0] == 20
+    for k in range(4):
+        assert m.get('stopped_cycle')[0] == k + 1
         m.step(acts())
     assert m.get('mode')[0] == GM_KICK_OFF and m.get('mode_side')[0] == RIGHT
 
@@ -380,12 +420,18 @@ def test_free_kick_fault_on_a_second_touch_by_the_taker():
     assert m.get('set_play_taker')[0] == 11 and m.get('mode')[0] == GM_PLAY_ON
     bx = m.get('x')[0][22]
     m.step(acts(p10=[MCMD_KICK, 50, 0]))           # ... and kicks again before anybody else touched it: fault
-    assert m.get('mode')[0] == GM_FREE_KICK_FAULT and m.get('mode_side')[0] == RIGHT and m.get('set_play_taker')[0] == 0
+    assert m.get('mode')[0] == GM_FREE_KICK_FAULT and m.get('mode_side')[0] == LEFT and m.get('set_play_taker')[0] == 0   # free_kick_fault_l
     assert m.get('vx')[0][22] == 0 and m.get('x')[0][22] > bx          # ball placed where it was after the kick, at rest
-    # the free kick is a set play for the other side: the offender cannot play it, the right team can
+    # the announcement is a dead ball for both sides; after announce_wait cycles: indirect free kick for the other side
+    from soccer2d_amd._capi_match import GM_IND_FREE_KICK
     m.set_obj(0, 15, x=float(m.get('x')[0][22]) + 0.5, y=0.0, body=180.0)
-    m.step(acts(p10=[MCMD_KICK, 50, 0]))
-    assert m.get('mode')[0] == GM_FREE_KICK_FAULT
+    for _ in range(29):
+        m.step(acts(p10=[MCMD_KICK, 50, 0], p15=[MCMD_KICK, 50, 0]))
+        assert m.get('mode')[0] == GM_FREE_KICK_FAULT and m.get('vx')[0][22] == 0
+    m.step(acts())
+    assert m.get('mode')[0] == GM_IND_FREE_KICK and m.get('mode_side')[0] == RIGHT
+    m.step(acts(p10=[MCMD_KICK, 50, 0]))                    # the offender's side cannot play it, the right team can
+    assert m.get('mode')[0] == GM_IND_FREE_KICK
     m.step(acts(p15=[MCMD_KICK, 50, 0]))
     assert m.get('mode')[0] == GM_PLAY_ON and m.get('set_play_taker')[0] == 16
 
@@ -417,18 +463,28 @@ def test_back_pass_to_the_goalie_is_an_indirect_free_kick():
     m.step(acts())
     assert m.get('last_kicker')[0] == 3                    # nobody else touched it on the way
     m.set_obj(0, 22, x=-49.2, y=0.3, vx=-1.0, vy=0.0)      # (the rolling ball, placed in front of the goalie)
-    # ... who catches it inside his penalty area: BackPass_, free kick for the RIGHT side from the nearer front corner
+    # ... who catches it inside his penalty area: BackPass_ (named after the offending side), ball at the nearer front corner,
+    # then an indirect free kick for the RIGHT side
+    from soccer2d_amd._capi_match import GM_GOALIE_CATCH, GM_IND_FREE_KICK
     m.step(acts(p0=[MCMD_CATCH, 0, 0]))
-    assert m.get('mode')[0] == GM_BACK_PASS and m.get('mode_side')[0] == RIGHT
+    assert m.get('mode')[0] == GM_BACK_PASS and m.get('mode_side')[0] == LEFT
     assert m.get('x')[0][22] == pytest.approx(-36.0) and m.get('y')[0][22] == pytest.approx(20.16) and m.get('vx')[0][22] == 0
     assert m.get('ball_holder')[0] == 0 and m.get('last_kicker')[0] == 0
+    w = fresh(announce_wait=3); play_on(w)
+    w.set_game(0, last_kicker=3)
+    w.set_obj(0, 22, x=-49.2, y=0.3, vx=-1.0, vy=0.0)
+    w.step(acts(p0=[MCMD_CATCH, 0, 0]))
+    for _ in range(3):
+        assert w.get('mode')[0] == GM_BACK_PASS
+        w.step(acts())
+    assert w.get('mode')[0] == GM_IND_FREE_KICK and w.get('mode_side')[0] == RIGHT
     # an opponent's kick before the catch is no back pass; nor is the goalie's own kick; nor with back_passes = 0
     for kicker, kw in ((13, {}), (0, {}), (2, dict(back_passes=0))):
         m = fresh(**kw); play_on(m)
         m.set_game(0, last_kicker=kicker + 1)
         m.set_obj(0, 22, x=-49.2, y=0.3, vx=-1.0, vy=0.0)
         m.step(acts(p0=[MCMD_CATCH, 0, 0]))
-        assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == LEFT and m.get('ball_holder')[0] == 1
+        assert m.get('mode')[0] == GM_GOALIE_CATCH and m.get('mode_side')[0] == LEFT and m.get('ball_holder')[0] == 1
     # a tackle or a collision with another player in between ends the back pass
     m = fresh(); play_on(m)
     m.set_game(0, last_kicker=3)
@@ -436,3 +492,51 @@ def test_back_pass_to_the_goalie_is_an_indirect_free_kick():
     m.set_obj(0, 15, x=-30.2, y=0.0)                # an opponent standing on the ball: collision touch
     m.step(acts())
     assert m.get('last_kicker')[0] == 0
+
+
+# ---- round 3: fouls and cards (Tackle.foul, idl/service.proto:399-402; FoulCharge_ :282) -- rcssserver's rule restated, parity unpinned
+def _foul_scene(**kw):
+    from soccer2d_amd._capi_match import GM_PLAY_ON
+    m = fresh(**kw); play_on(m)
+    m.set_obj(0, 5, x=0.0, y=0.0, body=0.0)                 # left #6 faces +x ...
+    m.set_obj(0, 15, x=1.0, y=0.2, body=180.0)              # ... a right player stands 1 m in front of him with the ball at his feet
+    m.set_obj(0, 22, x=0.7, y=0.1, vx=0.0, vy=0.0)
+    return m
+
+
+def test_intentional_foul_brings_the_victim_down_and_may_be_carded():
+    from soccer2d_amd._capi_match import CARD_RED, CARD_YELLOW, GM_FOUL_CHARGE, GM_FREE_KICK
+    seen = {True: 0, False: 0}
+    for seed in range(40):
+        m = _foul_scene(seed=seed)
+        m.step(acts(p5=[MCMD_TACKLE, 0, 1]))                # Tackle(power_or_dir = 0, foul = true)
+        if m.get('tackle_cycles')[0][15] == 0:              # the tackle itself failed (exponent 10: rarely): no foul
+            assert m.get('mode')[0] == GM_PLAY_ON and m.get('card')[0][5] == 0
+            continue
+        assert m.get('tackle_cycles')[0][15] == 5            # the victim stays down for foul_cycles (this cycle's tick included)
+        called = m.get('mode')[0] == GM_FOUL_CHARGE
+        seen[bool(called)] += 1
+        if called:                                          # foul_charge_l + a yellow card; 30 stopped cycles; free kick for the victim's side
+            assert m.get('mode_side')[0] == LEFT and m.get('card')[0][5] == CARD_YELLOW and m.get('vx')[0][22] == 0
+            c0 = int(m.get('cycle')[0])
+            for _ in range(30):
+                m.step(acts())
+            assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == RIGHT and m.get('cycle')[0] == c0
+        else:                                               # the referee did not see it: play goes on, no card
+            assert m.get('mode')[0] == GM_PLAY_ON and m.get('card')[0][5] == 0
+    assert seen[True] >= 8 and seen[False] >= 8             # foul_detect_probability = 0.5
+    # a clean tackle (foul = false) through the same opponent is no foul; nor is an intentional one with nobody on the ball
+    m = _foul_scene(); m.step(acts(p5=[MCMD_TACKLE, 0, 0]))
+    assert m.get('card')[0][5] == 0 and m.get('tackle_cycles')[0][15] == 0 and m.get('mode')[0] == GM_PLAY_ON
+    m = _foul_scene(); m.set_obj(0, 15, x=20.0, y=20.0)
+    m.step(acts(p5=[MCMD_TACKLE, 0, 1]))
+    assert m.get('card')[0][5] == 0 and m.get('mode')[0] == GM_PLAY_ON
+    # the second card is a red one: the player is parked beside the pitch, his commands are ignored, formations leave him there
+    m = _foul_scene(foul_detect_probability=1.0, half_time_cycles=50, auto_reset=0)
+    m.L.s2dmo_set_card(m.h, 0, 5, CARD_YELLOW)
+    m.step(acts(p5=[MCMD_TACKLE, 0, 1]))
+    assert m.get('card')[0][5] == CARD_RED and m.get('mode')[0] == GM_FOUL_CHARGE
+    assert m.get('x')[0][5] == 0.0 and m.get('y')[0][5] == pytest.approx(-(34.0 + 6.0 + 1.5 * 5))
+    for _ in range(100):
+        m.step(acts(p5=[MCMD_DASH, 100, 0]))
+    assert m.get('x')[0][5] == 0.0 and m.get('y')[0][5] == pytest.approx(-(34.0 + 6.0 + 1.5 * 5)) and m.get('cycle')[0] >= 50   # through half time
