@@ -82,7 +82,14 @@ struct MGame { int cycle, mode, mode_side, last_touch, offside; float reward; in
 struct MRare { int score_l, score_r, timer;
                int holder, moves; /* 1 + index of the goalie holding a caught ball (0 = nobody), his remaining moves */
                int taker, last_kicker; /* 1 + index (0 = nobody): set-play taker not yet followed by another touch; last Kick-command kicker */
-               int stopped;            /* WorldModel.stoped_cycle */ };
+               int stopped;            /* WorldModel.stoped_cycle */
+               int to_half;            /* cycles until the clock reaches the next multiple of half_time_cycles (derived at load: not a
+                                          state word) -- a countdown instead of an integer modulo by a run-time divisor every cycle */ };
+// cycles until `cycle` is the next multiple of h (> 0): the value of the countdown for a clock that reads `cycle`
+S2D_DEV int cycles_to_half(int cycle, int h) {
+  const int rem = cycle % h;                             // C remainder: negative for a clock that has wrapped
+  return rem < 0 ? -rem : h - rem;
+}
 
 __constant__ float kFormX[11] = {-50.0f, -35.0f, -35.0f, -35.0f, -35.0f, -20.0f, -20.0f, -20.0f, -20.0f, -10.5f, -10.5f};
 __constant__ float kFormY[11] = {0.0f, -20.0f, -7.0f, 7.0f, 20.0f, -22.0f, -8.0f, 8.0f, 22.0f, -6.0f, 6.0f};
@@ -93,21 +100,21 @@ S2D_DEV U4 m_draw(const MParams& p, uint32_t gl, uint32_t gh, uint32_t cyc, uint
 S2D_DEV int side_of(int i) { return i < 11 ? SIDE_LEFT : SIDE_RIGHT; }
 S2D_DEV int other_side(int s) { return s == SIDE_LEFT ? SIDE_RIGHT : SIDE_LEFT; }
 S2D_DEV bool is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D_GM_TIME_OVER; }
+// Mode classes as bit masks over GameModeType (every value used is < 32): one shift + and instead of a chain of compares.
 // announcements: a dead ball named after the offending side; after announce_wait cycles the referee awards the restart
-S2D_DEV bool is_announcement(int mode) {
-  return mode == S2D_GM_OFF_SIDE || mode == S2D_GM_BACK_PASS || mode == S2D_GM_FREE_KICK_FAULT || mode == S2D_GM_CATCH_FAULT ||
-         mode == S2D_GM_FOUL_CHARGE;
-}
+constexpr uint32_t kAnnounceModes = (1u << S2D_GM_OFF_SIDE) | (1u << S2D_GM_BACK_PASS) | (1u << S2D_GM_FREE_KICK_FAULT) |
+                                    (1u << S2D_GM_CATCH_FAULT) | (1u << S2D_GM_FOUL_CHARGE);
 // modes in which nobody may play the ball
-S2D_DEV bool ball_dead(int mode) {
-  return mode == S2D_GM_AFTER_GOAL || mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_GOALIE_CATCH ||
-         is_announcement(mode);
-}
+constexpr uint32_t kDeadBallModes = kAnnounceModes | (1u << S2D_GM_AFTER_GOAL) | (1u << S2D_GM_BEFORE_KICK_OFF) |
+                                    (1u << S2D_GM_FIRST_HALF_OVER) | (1u << S2D_GM_GOALIE_CATCH);
 // modes in which the clock stands still (with stopped_clock): WorldModel.cycle keeps its value, stoped_cycle counts
-S2D_DEV bool clock_stands(int mode) {
-  return mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_AFTER_GOAL || mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_TIME_OVER ||
-         is_announcement(mode);
-}
+constexpr uint32_t kClockStandsModes = kAnnounceModes | (1u << S2D_GM_BEFORE_KICK_OFF) | (1u << S2D_GM_AFTER_GOAL) |
+                                       (1u << S2D_GM_FIRST_HALF_OVER) | (1u << S2D_GM_TIME_OVER);
+static_assert(S2D_GM_GOALIE_CATCH < 32, "mode masks are 32 bits wide");
+S2D_DEV bool in_modes(int mode, uint32_t mask) { return ((mask >> (mode & 31)) & 1u) != 0u; }
+S2D_DEV bool is_announcement(int mode) { return in_modes(mode, kAnnounceModes); }
+S2D_DEV bool ball_dead(int mode) { return in_modes(mode, kDeadBallModes); }
+S2D_DEV bool clock_stands(int mode) { return in_modes(mode, kClockStandsModes); }
 S2D_DEV float hbcast(float v, int src) { return __shfl(v, src, kHalf); }
 S2D_DEV int hbcasti(int v, int src) { return __shfl(v, src, kHalf); }
 // 32-bit ballot of this lane's half
@@ -132,7 +139,7 @@ S2D_DEV void m_recover(const MParams& p, float effort_max, MObj& o, bool with_ca
 S2D_DEV void m_reset(const MParams& p, float effort_max, MObj& o, MGame& g, MRare& r, int l) {
   o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   g = MGame{0, p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0.0f, 0, 10, 20, 0};
-  r = MRare{0, 0, 0, 0, 0, 0, 0, 0};
+  r = MRare{0, 0, 0, 0, 0, 0, 0, 0, p.half_time_cycles};
   if (l < NP) m_recover(p, effort_max, o, true);
   m_place(o, l, SIDE_LEFT);
 }
@@ -653,7 +660,11 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MR
     int total = p.half_time_cycles * p.nr_normal_halfs;  // half time / time over: only when the clock has just moved
     if (advanced && g.cycle >= total) {
       g.mode = S2D_GM_TIME_OVER; g.mode_side = SIDE_NONE; g.done = 1; if (g.offside > 0) g.offside = 0; if (is_ball) ev |= EV_FINISHED;
-    } else if (advanced && p.half_time_cycles > 0 && g.cycle % p.half_time_cycles == 0) {
+    }
+    bool at_half = false;                                  // the clock has just reached a multiple of half_time_cycles
+    if (advanced) { const int left = gr.to_half - 1; at_half = left == 0; gr.to_half = at_half ? p.half_time_cycles : left; }
+    if (g.mode == S2D_GM_TIME_OVER && g.done) {
+    } else if (at_half) {
       int k = g.cycle / p.half_time_cycles;
       int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
       recover_half = true; restart_form = true; form_side = ks; place_ball = false;
@@ -757,6 +768,7 @@ S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g, MRare& 
   r.taker = q.env[ME_TAKER * q.env_stride + e]; r.last_kicker = q.env[ME_LAST_KICKER * q.env_stride + e];
   r.stopped = q.env[ME_STOPPED * q.env_stride + e]; g.tick = q.env[ME_TICK * q.env_stride + e];
 }
+S2D_DEV void m_derive(const MParams& p, const MGame& g, MRare& r) { r.to_half = cycles_to_half(g.cycle, p.half_time_cycles); }
 S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGame& g, const MRare& r) {
   if (l < SLOTS) {
     int64_t k = e * SLOTS + l;
@@ -808,6 +820,10 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
   __shared__ PTab pt[PT_WORDS];                       // per-slot PlayerType parameters, shared by the 8 matches
   __shared__ unsigned int lds_cnt[8];
   __shared__ MRare rare[kEnvsPerBlock];                // per-match words only events touch (see MRare)
+  // rollout observations: the two matches of a wave are neighbours in [T][N][24][5], i.e. 960 contiguous bytes per cycle.  Each lane
+  // puts its five words into a wave-private tile (stride 5: no bank conflicts) and the wave stores the block as 60 x 16 bytes --
+  // instead of five 20-byte-strided dword stores per lane (partial lines: what the reach kernels' store-pattern study priced)
+  __shared__ __attribute__((aligned(16))) float obs_tile[kMBlock / 64][2 * SLOTS * S2D_MATCH_OBJ_WORDS];
   // The ~60 uniform parameters are read from LDS (broadcast reads) where they are used instead of
   // occupying SGPRs for the whole kernel: as kernargs they cost 142 SGPR spills and 48 B of scratch at
   // the 128-VGPR cap (26 spills / 12 B this way, +14 % throughput).
@@ -827,6 +843,7 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
   MObj o; MGame g;
   MRare& r = rare[threadIdx.x / kHalf];
   m_load(q, ec, l, o, g, r);
+  m_derive(p, g, r);
   tile_init(pos_tile[threadIdx.x / kHalf], l, pt[PT_SIZE][l]);
   const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)ec;
   const uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
@@ -843,12 +860,23 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
       }
     }
     match_cycle(p, pt, o, g, r, l, half, gl, gh, cmd, a, b, cnt, pos_tile[threadIdx.x / kHalf]);
+    if (ro.obs) {                                          // wave-uniform
+      float* const tile = obs_tile[threadIdx.x >> 6];
+      if (l < SLOTS) {
+        float* tw = tile + (half * SLOTS + l) * S2D_MATCH_OBJ_WORDS;
+        tw[0] = o.x; tw[1] = o.y; tw[2] = o.vx; tw[3] = o.vy; tw[4] = o.body;
+      }
+      wave_fence();
+      const int lane = threadIdx.x & 63;
+      const int64_t e0 = e - half;                         // first match of this wave (matches of a wave: e0, e0 + 1)
+      constexpr int kVecPerMatch = SLOTS * S2D_MATCH_OBJ_WORDS / 4;   // 30 float4 per match
+      const int n_vec = e0 + 1 < n ? 2 * kVecPerMatch : (e0 < n ? kVecPerMatch : 0);
+      if (lane < n_vec)
+        reinterpret_cast<float4*>(ro.obs + ((int64_t)t * n + e0) * (SLOTS * S2D_MATCH_OBJ_WORDS))[lane] = reinterpret_cast<const float4*>(tile)[lane];
+      wave_fence();
+    }
     if (valid) {
       const int64_t row = (int64_t)t * n + e;
-      if (ro.obs && l < SLOTS) {
-        float* d = ro.obs + (row * SLOTS + l) * S2D_MATCH_OBJ_WORDS;
-        d[0] = o.x; d[1] = o.y; d[2] = o.vx; d[3] = o.vy; d[4] = o.body;
-      }
       if (l == BALL) {
         if (ro.reward) ro.reward[row] = g.reward;
         if (ro.mode) ro.mode[row] = g.mode;
@@ -1268,6 +1296,7 @@ S2D_API int s2d_match_step(S2DMatchHandle h, const float* actions_dev, void* str
 S2D_API int s2d_match_rollout(S2DMatchHandle h, int n_steps, const float* actions_dev, const S2DMatchRollout* out, void* stream) {
   if (!h) return mfail(S2D_EINVAL, "NULL handle");
   if (n_steps < 0) return mfail(S2D_EINVAL, "n_steps must be >= 0");
+  if (out && out->obs && (reinterpret_cast<uintptr_t>(out->obs) & 15u)) return mfail(S2D_EINVAL, "rollout obs buffer must be 16-byte aligned");
   if (n_steps == 0) return S2D_OK;
   return m_launch(h, n_steps, actions_dev, out, stream);
 }

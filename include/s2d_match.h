@@ -144,7 +144,7 @@ typedef struct S2DMatchBuffers {
 } S2DMatchBuffers;
 
 typedef struct S2DMatchRollout {
-  float *obs;        /* [T][N][24][5] x,y,vx,vy,body after each cycle (slot 22 = ball) or NULL */
+  float *obs;        /* [T][N][24][5] x,y,vx,vy,body after each cycle (slot 22 = ball) or NULL; 16-byte aligned */
   float *reward;     /* [T][N] or NULL */
   int32_t *mode;     /* [T][N] or NULL */
   uint8_t *done;     /* [T][N] or NULL */
