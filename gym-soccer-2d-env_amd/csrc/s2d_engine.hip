@@ -897,7 +897,8 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   } else if (role == 2) {
     __builtin_amdgcn_s_setprio(S2D_PRIO_A);
     // ------------------------------------------------------------------ A-wave (player half, reward, labels)
-    const S2DHot& p = p_sgpr;
+    const S2DHot p = hot_in_vgprs(p_sgpr);                 // no kernarg re-loads (s_load + s_waitcnt) inside the loop
+    const bool auto_reset = p_sgpr.auto_reset != 0;
     float prev_dist = 0.0f, prev_angle = 0.0f;
     if (active) {
       prev_dist = S[F_PREV_DIST * stride + i]; prev_angle = S[F_PREV_ANGLE * stride + i];
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           reward = reward_of(prev_dist, prev_angle, dist, rel, flags, res);
           prev_dist = dist; prev_angle = rel;
           done = flags ? 1 : 0;
-          if (flags && p.auto_reset) {                     // rare: terminal row, then the new episode's first obs
+          if (flags && auto_reset) {                       // rare: terminal row, then the new episode's first obs
             const float (*sl)[kWave] = slots[fw >> 8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) term_row[k] = oa[k];
@@ -961,7 +962,8 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   } else {
     // ------------------------------------------------------------------ B-wave (ball half, observation stream)
     __builtin_amdgcn_s_setprio(S2D_PRIO_B);
-    const S2DHot& p = p_sgpr;
+    const S2DHot p = hot_in_vgprs(p_sgpr);                 // no kernarg re-loads inside the loop
+    const bool auto_reset = p_sgpr.auto_reset != 0;
     float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
     __syncthreads();                                       // prepared episodes published
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         float bvx = snap[b][WS_BVX][lane], bvy = snap[b][WS_BVY][lane];
         const int fw = __float_as_int(snap[b][WS_FLAGS][lane]);
         observe_ball(p, bx, by, bvx, bvy, ob6);
-        if ((fw & 0xff) && p.auto_reset) {                 // rare: terminal row, then the new episode's first obs
+        if ((fw & 0xff) && auto_reset) {                   // rare: terminal row, then the new episode's first obs
           const float (*sl)[kWave] = slots[fw >> 8];
 #pragma unroll
           for (int k = 4; k < S2D_OBS_DIM; ++k) term_row[k] = ob6[k];
