@@ -117,6 +117,14 @@ S2D_DEV bool ball_dead(int mode) { return in_modes(mode, kDeadBallModes); }
 S2D_DEV bool clock_stands(int mode) { return in_modes(mode, kClockStandsModes); }
 S2D_DEV float hbcast(float v, int src) { return __shfl(v, src, kHalf); }
 S2D_DEV int hbcasti(int v, int src) { return __shfl(v, src, kHalf); }
+// The same broadcast from a lane known at compile time (the ball's): two v_readlane and a select -- a few cycles -- where the
+// general shuffle is a ds_bpermute through the LDS pipeline (~100 cycles of latency a wave of this kernel cannot hide).  Called
+// in uniform control flow only.
+template <int SRC> S2D_DEV int hbcasti_c(int v, int half) {
+  const int lo = __builtin_amdgcn_readlane(v, SRC), hi = __builtin_amdgcn_readlane(v, SRC + kHalf);
+  return half ? hi : lo;
+}
+template <int SRC> S2D_DEV float hbcast_c(float v, int half) { return __int_as_float(hbcasti_c<SRC>(__float_as_int(v), half)); }
 // 32-bit ballot of this lane's half
 S2D_DEV uint32_t hballot(bool pred, int half) { return (uint32_t)(__ballot(pred) >> (half * kHalf)); }
 
@@ -312,7 +320,9 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MR
   const uint32_t cyc = (uint32_t)g.tick;                   // Philox counter: cycles since the reset, stopped ones included
   const int mode0 = g.mode, side0 = g.mode_side;
   const float x0 = o.x, y0 = o.y;
-  const float bx0 = hbcast(o.x, BALL), by0 = hbcast(o.y, BALL), bvx0 = hbcast(o.vx, BALL), bvy0 = hbcast(o.vy, BALL);
+  const float bx0 = hbcast_c<BALL>(o.x, half), by0 = hbcast_c<BALL>(o.y, half);
+  float bvx0 = 0.0f, bvy0 = 0.0f;                         // the ball's velocity: read by the kick noise only
+  if (p.noise) { bvx0 = hbcast_c<BALL>(o.vx, half); bvy0 = hbcast_c<BALL>(o.vy, half); }
   g.reward = 0.0f; g.done = 0;
 
   // ---- 1. commands + player movement (lane-local)
@@ -375,13 +385,16 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MR
     o.x += o.vx; o.y += o.vy;
   }
   // a successful catch wins the cycle: every kick / tackle impulse of this cycle is dropped
-  const uint32_t cmask = hballot(caught, half) & ((1u << S2D_MATCH_GOALIE_LEFT) | (1u << S2D_MATCH_GOALIE_RIGHT));
-  const int caught_by = cmask ? __ffs((int)cmask) - 1 : -1;
   // ... and so does a move of the goalie who holds the ball (the holder is a goalie: bits 0 / 11)
-  const uint32_t hmask = hballot(hold_moved, half) & ((1u << S2D_MATCH_GOALIE_LEFT) | (1u << S2D_MATCH_GOALIE_RIGHT));
-  const int hold_move = hmask ? __ffs((int)hmask) - 1 : -1;
-  if (caught_by >= 0 && l == caught_by) ev |= EV_KICK;
-  if (caught_by >= 0 || hold_move >= 0) { kicked = false; by_kick = false; kx = 0.0f; ky = 0.0f; }
+  int caught_by = -1, hold_move = -1;
+  if (__ballot(caught || hold_moved) != 0ull) {            // wave-uniform, rare
+    const uint32_t goalies = (1u << S2D_MATCH_GOALIE_LEFT) | (1u << S2D_MATCH_GOALIE_RIGHT);
+    const uint32_t cmask = hballot(caught, half) & goalies, hmask = hballot(hold_moved, half) & goalies;
+    caught_by = cmask ? __ffs((int)cmask) - 1 : -1;
+    hold_move = hmask ? __ffs((int)hmask) - 1 : -1;
+    if (caught_by >= 0 && l == caught_by) ev |= EV_KICK;
+    if (caught_by >= 0 || hold_move >= 0) { kicked = false; by_kick = false; kx = 0.0f; ky = 0.0f; }
+  }
   // FoulCharge_ (idl/service.proto:282): a successful INTENTIONAL tackle through an opponent who has the ball (kickable) inside the
   // tackler's tackle area brings him down for foul_cycles; the referee sees it with foul_detect_probability.  Positions of the
   // start of the cycle; the first such tackler (lowest index) counts.  Wave-uniform and rare: only tackles with foul set get here.
@@ -411,29 +424,31 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MR
     foul_call = foul_seen ? foul_by + 1 : 0;
   }
   // ---- 2. ball: impulses summed in player order
-  const uint32_t kmask = hballot(kicked, half) & 0x3FFFFFu;
-  const bool any_kick = kmask != 0u;
-  const int last_kicker = any_kick ? 31 - __clz(kmask) : -1;
   float bax = 0.0f, bay = 0.0f;
+  bool any_kick = false, fk_fault = false;
+  int last_kicker = -1, taker0 = 0;
   const bool wave_kick = __ballot(kicked) != 0ull;          // wave-uniform: kicks are rare events
   if (wave_kick) {
+    const uint32_t kmask = hballot(kicked, half) & 0x3FFFFFu;
+    any_kick = kmask != 0u;
+    last_kicker = any_kick ? 31 - __clz(kmask) : -1;
     for (int j = 0; j < NP; ++j) {
       float kxj = hbcast(kx, j), kyj = hbcast(ky, j);
       if ((kmask >> j) & 1u) { bax += kxj; bay += kyj; }
     }
-  }
-  if (any_kick) g.last_touch = side_of(last_kicker);
-  // free-kick fault / back-pass bookkeeping (oracle: match_step, same decisions from the same masks)
-  const int taker0 = gr.taker;
-  const uint32_t cmask2 = hballot(by_kick, half) & 0x3FFFFFu;                  // Kick-command kickers
-  const uint32_t taker_bit = taker0 > 0 ? (1u << (taker0 - 1)) : 0u;
-  const bool other_touch = (kmask & ~taker_bit) != 0u;
-  const bool fk_fault = p.free_kick_faults && mode0 == S2D_GM_PLAY_ON && taker0 != 0 && any_kick && !other_touch;
-  if (any_kick) {
-    if (is_setplay(mode0)) gr.taker = last_kicker + 1;        // this kick puts the ball into play
-    else if (other_touch) gr.taker = 0;
-    const int last_kick_cmd = cmask2 ? 31 - __clz(cmask2) : -1;
-    gr.last_kicker = (last_kick_cmd == last_kicker) ? last_kick_cmd + 1 : 0;
+    if (any_kick) g.last_touch = side_of(last_kicker);
+    // free-kick fault / back-pass bookkeeping (oracle: match_step, same decisions from the same masks)
+    taker0 = gr.taker;
+    const uint32_t cmask2 = hballot(by_kick, half) & 0x3FFFFFu;                  // Kick-command kickers
+    const uint32_t taker_bit = taker0 > 0 ? (1u << (taker0 - 1)) : 0u;
+    const bool other_touch = (kmask & ~taker_bit) != 0u;
+    fk_fault = p.free_kick_faults && mode0 == S2D_GM_PLAY_ON && taker0 != 0 && any_kick && !other_touch;
+    if (any_kick) {
+      if (is_setplay(mode0)) gr.taker = last_kicker + 1;        // this kick puts the ball into play
+      else if (other_touch) gr.taker = 0;
+      const int last_kick_cmd = cmask2 ? 31 - __clz(cmask2) : -1;
+      gr.last_kicker = (last_kick_cmd == last_kicker) ? last_kick_cmd + 1 : 0;
+    }
   }
   const bool ball_live = !is_setplay(mode0) || any_kick;
   if (caught_by >= 0) {                                   // held: the ball rests where it was caught
@@ -484,7 +499,8 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MR
     overlap &= l <= BALL;
   }
   wave_fence();
-  for (int pass = 0; pass < 10 && __ballot(overlap) != 0ull; ++pass) {
+  const bool wave_overlap = __ballot(overlap) != 0ull;     // wave-uniform: everything about collisions hangs on it
+  for (int pass = 0; pass < 10 && wave_overlap; ++pass) {
     float sx = 0.0f, sy = 0.0f; int c = 0; int tp = -1;
     tile_put(pos, l, o.x, o.y);                           // wave-private tile: LDS ops of a wave are in order
     wave_fence();
@@ -506,18 +522,22 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MR
     if (__ballot(c > 0) == 0ull) break;
     if (c > 0) { o.x = sx / (float)c; o.y = sy / (float)c; collided = true; if (is_ball) touch_player = tp; }
   }
-  if (collided) { o.vx *= p.collision_vel_rate; o.vy *= p.collision_vel_rate; }
-  touch_player = hbcasti(touch_player, BALL);
   int coll_touch_side = SIDE_NONE;
-  if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
-    coll_touch_side = side_of(touch_player);
-    g.last_touch = coll_touch_side;
-    if (touch_player + 1 != gr.taker) gr.taker = 0;
-    if (touch_player + 1 != gr.last_kicker) gr.last_kicker = 0;
+  if (wave_overlap) {
+    if (collided) { o.vx *= p.collision_vel_rate; o.vy *= p.collision_vel_rate; }
+    touch_player = hbcasti_c<BALL>(touch_player, half);
+    if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
+      coll_touch_side = side_of(touch_player);
+      g.last_touch = coll_touch_side;
+      if (touch_player + 1 != gr.taker) gr.taker = 0;
+      if (touch_player + 1 != gr.last_kicker) gr.last_kicker = 0;
+    }
   }
+  // the ball after its move and the collisions (nothing below moves it before the referee has looked)
+  const float bx = hbcast_c<BALL>(o.x, half), by = hbcast_c<BALL>(o.y, half);
   // ---- 4. set play: opponents keep their distance
-  {
-    float bxn = hbcast(o.x, BALL), byn = hbcast(o.y, BALL);
+  if (__ballot(mode0 != S2D_GM_PLAY_ON) != 0ull) {         // wave-uniform
+    const float bxn = bx, byn = by;
     // the side that does not take the set play keeps its distance; during an announcement that is the offending side (side0)
     const int kept_away = is_announcement(mode0) ? side0 : other_side(side0);
     if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_FIRST_HALF_OVER && is_player &&
@@ -536,8 +556,16 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MR
   const bool advanced = !(p.stopped_clock && clock_stands(mode0));
   if (advanced) { g.cycle = (int)((uint32_t)g.cycle + 1u); gr.stopped = 0; }   // wrap-defined
   else gr.stopped += 1;
-  // inputs that need shuffles are gathered unconditionally (uniform control flow)
-  const float bx = hbcast(o.x, BALL), by = hbcast(o.y, BALL);
+  // Most cycles are quiet: play_on, nobody touched the ball, the ball is on the pitch, no offside flag is up and the clock is not at
+  // a half's end.  In such a cycle every decision below comes out "nothing happens", so a wave whose two matches are both quiet
+  // skips them (some forty branches that each fall through); the test is the union of the conditions those decisions read.
+  const int total_cycles = p.half_time_cycles * p.nr_normal_halfs;
+  const bool busy = mode0 != S2D_GM_PLAY_ON || any_kick || caught_by >= 0 || hold_move >= 0 || foul_call != 0 || g.offside != 0 ||
+                    fabsf(bx) > p.half_l || fabsf(by) > p.half_w || g.cycle >= total_cycles || gr.to_half == 1;
+  if (__ballot(busy) == 0ull) {
+    gr.to_half -= 1;                                       // play_on: the clock moved, and not onto a half's end
+    gr.holder = 0; gr.moves = 0;
+  } else {
   float first = -1.0e9f, second = -1.0e9f;      // two largest dirS*x0 among the kicker's opponents
   const int S = any_kick ? side_of(last_kicker) : SIDE_LEFT;
   const float dirS = S == SIDE_LEFT ? 1.0f : -1.0f;
@@ -657,8 +685,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MR
         }
       }
     }
-    int total = p.half_time_cycles * p.nr_normal_halfs;  // half time / time over: only when the clock has just moved
-    if (advanced && g.cycle >= total) {
+    if (advanced && g.cycle >= total_cycles) {           // half time / time over: only when the clock has just moved
       g.mode = S2D_GM_TIME_OVER; g.mode_side = SIDE_NONE; g.done = 1; if (g.offside > 0) g.offside = 0; if (is_ball) ev |= EV_FINISHED;
     }
     bool at_half = false;                                  // the clock has just reached a multiple of half_time_cycles
@@ -685,6 +712,7 @@ S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MR
   if (recover_half && is_player) m_recover(p, pt[PT_EFFORT_MAX][l], o, false);
   if (restart_form) m_place(o, l, form_side);
   else if (place_ball && is_ball) { o.x = pbx; o.y = pby; o.vx = 0.0f; o.vy = 0.0f; }
+  }                                                        // busy
   // a second card is a red one: the player waits beside the halfway line, outside the pitch, one spot per uniform number
   if (is_player && o.card >= S2D_CARD_RED) {
     o.x = 0.0f; o.y = (side_of(l) == SIDE_LEFT ? -1.0f : 1.0f) * (p.half_w + 6.0f + 1.5f * (float)(l % 11));
