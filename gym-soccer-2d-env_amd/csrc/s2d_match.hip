@@ -72,6 +72,52 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
 };
 typedef float PTab[kHalf];   // one row of the per-slot table
 
+// The stock configuration (s2d_match_default_config) as compile-time constants, with the derivations of mparams_from_config restated
+// as constant expressions: the kernels are instantiated once over MParams (any configuration; ~70 words read from LDS where they
+// are used) and once over MStock, where every use is an immediate -- no LDS reads or waits for them, dead branches (no dash-angle
+// quantisation off, no unlimited stamina capacity, ...) compiled out.  m_is_stock() compares an engine's derived MParams with
+// these bit for bit; anything else runs the general instantiation.  Per-engine words (seed, env ids, switches) stay variables.
+struct MStock {
+  static constexpr float half_l = (float)52.5, half_w = (float)34.0, ball_size = (float)0.085, player_rand = (float)0.1, ball_rand = (float)0.05;
+  static constexpr float player_accel_max = (float)1.0, player_accel_max2 = player_accel_max * player_accel_max;
+  static constexpr float ball_speed_max = (float)3.0, ball_speed_max2 = ball_speed_max * ball_speed_max;
+  static constexpr float ball_accel_max = (float)2.7, ball_accel_max2 = ball_accel_max * ball_accel_max;
+  static constexpr float stamina_max = (float)8000.0, stamina_capacity = (float)130600.0;
+  static constexpr float recover_init = (float)1.0, recover_dec_thr_value = (float)(0.3 * 8000.0), recover_min = (float)0.5, recover_dec = (float)0.002;
+  static constexpr float effort_dec_thr_value = (float)(0.3 * 8000.0), effort_dec = (float)0.005;
+  static constexpr float effort_inc_thr_value = (float)(0.6 * 8000.0), effort_inc = (float)0.01;
+  static constexpr float max_dash_power = (float)100.0, min_dash_power = (float)0.0, max_dash_angle = (float)180.0, min_dash_angle = (float)-180.0;
+  static constexpr float dash_angle_step = (float)1.0, inv_dash_angle_step = (float)(1.0 / 1.0);
+  static constexpr float side_dash_rate = (float)0.4, back_dash_rate = (float)0.6, max_moment = (float)180.0, min_moment = (float)-180.0;
+  static constexpr float collision_vel_rate = (float)-0.1;
+  static constexpr float max_power = (float)100.0, min_power = (float)-100.0, inv_max_power = (float)(1.0 / 100.0);
+  static constexpr float tackle_dist = (float)2.0, tackle_back_dist = (float)0.0, tackle_width = (float)1.25, tackle_power_rate = (float)0.027;
+  static constexpr float max_tackle_power = (float)100.0, max_back_tackle_power = (float)0.0;
+  static constexpr float tackle_reach2 = (float)(1.01 * (2.0 * 2.0 + 1.25 * 1.25));
+  static constexpr float goal_half_width = (float)(14.02 * 0.5), offside_area2 = (float)(2.5 * 2.5), free_kick_distance = (float)9.15;
+  static constexpr float inv_speed_decay = (float)(1.0 / (3.0 * 0.94));
+  static constexpr float catch_half_w = (float)(1.0 * 0.5), catch_probability = (float)1.0, max_catch_angle = (float)90.0, min_catch_angle = (float)-90.0;
+  static constexpr float pen_x = (float)(52.5 - 16.5), pen_half_w = (float)20.16;
+  static constexpr int tackle_cycles = 10, half_time_cycles = 3000, nr_normal_halfs = 2, drop_ball_time = 100, use_offside = 1, catch_ban_cycle = 5;
+  static constexpr int goalie_max_moves = 2, after_goal_wait = 50, kick_off_wait = 0, back_passes = 1, free_kick_faults = 1;
+  static constexpr int stopped_clock = 1, announce_wait = 30, foul_cycles = 5;
+  static constexpr float foul_detect_probability = (float)0.5;
+  int auto_reset, noise;
+  uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
+};
+#define M_CONFIG_FLOATS(X) X(half_l) X(half_w) X(ball_size) X(player_rand) X(ball_rand) X(player_accel_max) X(player_accel_max2) \
+  X(ball_speed_max) X(ball_speed_max2) X(ball_accel_max) X(ball_accel_max2) X(stamina_max) X(stamina_capacity) X(recover_init) \
+  X(recover_dec_thr_value) X(recover_min) X(recover_dec) X(effort_dec_thr_value) X(effort_dec) X(effort_inc_thr_value) X(effort_inc) \
+  X(max_dash_power) X(min_dash_power) X(max_dash_angle) X(min_dash_angle) X(dash_angle_step) X(inv_dash_angle_step) X(side_dash_rate) \
+  X(back_dash_rate) X(max_moment) X(min_moment) X(collision_vel_rate) X(max_power) X(min_power) X(inv_max_power) X(tackle_dist) \
+  X(tackle_back_dist) X(tackle_width) X(tackle_power_rate) X(max_tackle_power) X(max_back_tackle_power) X(tackle_reach2) \
+  X(goal_half_width) X(offside_area2) X(free_kick_distance) X(inv_speed_decay) X(catch_half_w) X(catch_probability) \
+  X(max_catch_angle) X(min_catch_angle) X(pen_x) X(pen_half_w) X(foul_detect_probability)
+#define M_CONFIG_INTS(X) X(tackle_cycles) X(half_time_cycles) X(nr_normal_halfs) X(drop_ball_time) X(use_offside) X(catch_ban_cycle) \
+  X(goalie_max_moves) X(after_goal_wait) X(kick_off_wait) X(back_passes) X(free_kick_faults) X(stopped_clock) X(announce_wait) X(foul_cycles)
+// every configuration word of MParams is in one of the two lists (the remaining six are the per-engine words)
+static_assert(sizeof(MParams) == 4 * (53 + 14 + 6), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
+
 struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int tackle, catch_ban, card; };
 // Per-match words every cycle reads (registers; the same value in the 32 lanes of the match's half-wave) ...
 struct MGame { int cycle, mode, mode_side, last_touch, offside; float reward; int done, nearest_l, nearest_r;
@@ -94,7 +140,7 @@ S2D_DEV int cycles_to_half(int cycle, int h) {
 __constant__ float kFormX[11] = {-50.0f, -35.0f, -35.0f, -35.0f, -35.0f, -20.0f, -20.0f, -20.0f, -20.0f, -10.5f, -10.5f};
 __constant__ float kFormY[11] = {0.0f, -20.0f, -7.0f, 7.0f, 20.0f, -22.0f, -8.0f, 8.0f, 22.0f, -6.0f, 6.0f};
 
-S2D_DEV U4 m_draw(const MParams& p, uint32_t gl, uint32_t gh, uint32_t cyc, uint32_t stream, uint32_t block) {
+template <class P> S2D_DEV U4 m_draw(const P& p, uint32_t gl, uint32_t gh, uint32_t cyc, uint32_t stream, uint32_t block) {
   return philox4x32_10(gl, gh, cyc, (stream << 16) | block, p.seed_lo, p.seed_hi);
 }
 S2D_DEV int side_of(int i) { return i < 11 ? SIDE_LEFT : SIDE_RIGHT; }
@@ -140,18 +186,18 @@ S2D_DEV void m_place(MObj& o, int l, int kickoff_side) {   // place_formation() 
     o.x = 0.0f; o.y = 0.0f; o.vx = 0.0f; o.vy = 0.0f;
   }
 }
-S2D_DEV void m_recover(const MParams& p, float effort_max, MObj& o, bool with_capacity) {
+template <class P> S2D_DEV void m_recover(const P& p, float effort_max, MObj& o, bool with_capacity) {
   o.stamina = p.stamina_max; o.effort = effort_max; o.recovery = p.recover_init;
   if (with_capacity) o.capacity = p.stamina_capacity;
 }
-S2D_DEV void m_reset(const MParams& p, float effort_max, MObj& o, MGame& g, MRare& r, int l) {
+template <class P> S2D_DEV void m_reset(const P& p, float effort_max, MObj& o, MGame& g, MRare& r, int l) {
   o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   g = MGame{0, p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0.0f, 0, 10, 20, 0};
   r = MRare{0, 0, 0, 0, 0, 0, 0, 0, p.half_time_cycles};
   if (l < NP) m_recover(p, effort_max, o, true);
   m_place(o, l, SIDE_LEFT);
 }
-S2D_DEV void m_dash(const MParams& p, const PTab* pt, int l, MObj& o, float power, float dir, float& ax, float& ay) {
+template <class P> S2D_DEV void m_dash(const P& p, const PTab* pt, int l, MObj& o, float power, float dir, float& ax, float& ay) {
   power = clampf(power, p.min_dash_power, p.max_dash_power);
   dir = clampf(dir, p.min_dash_angle, p.max_dash_angle);
   if (p.dash_angle_step > 0.0f) dir = p.dash_angle_step * rintf(dir * p.inv_dash_angle_step);
@@ -173,14 +219,14 @@ S2D_DEV void m_dash(const MParams& p, const PTab* pt, int l, MObj& o, float powe
   sincos_deg(norm_deg_any(o.body + dir), sn, cs);
   ax = acc * cs; ay = acc * sn;
 }
-S2D_DEV void m_turn(const MParams& p, float inertia_moment, MObj& o, float moment, float noise_u) {
+template <class P> S2D_DEV void m_turn(const P& p, float inertia_moment, MObj& o, float moment, float noise_u) {
   moment = clampf(moment, p.min_moment, p.max_moment);
   float speed = hypot2(o.vx, o.vy);
   float f = 1.0f;
   if (p.noise) f = 1.0f + (noise_u * 2.0f - 1.0f) * p.player_rand;
   o.body = norm_deg_any(o.body + f * moment / (1.0f + inertia_moment * speed));
 }
-S2D_DEV bool m_kick(const MParams& p, const PTab* pt, int l, const MObj& o, float bx, float by, float bvx, float bvy,
+template <class P> S2D_DEV bool m_kick(const P& p, const PTab* pt, int l, const MObj& o, float bx, float by, float bvx, float bvy,
                     float power, float dir, float u_mag, float u_ang, float& kx, float& ky) {
   float dx = bx - o.x, dy = by - o.y;
   // dist <= kickable_area decided on the square: sqrt is correctly rounded and monotone, and the table holds
@@ -213,10 +259,10 @@ S2D_DEV bool m_kick(const MParams& p, const PTab* pt, int l, const MObj& o, floa
 // A ball farther away than sqrt(tackle_dist^2 + tackle_width^2) has |x| > tackle_dist or |y| > tackle_width in
 // the body frame, i.e. fail > 1 > u: tackle_reach2 is that bound with a 1 % margin (far more than the rounding
 // of the rotation), so those lanes skip the rotation and -- see the caller -- the Philox draw.
-S2D_DEV bool m_tackle_in_reach(const MParams& p, const MObj& o, float bx, float by) {
+template <class P> S2D_DEV bool m_tackle_in_reach(const P& p, const MObj& o, float bx, float by) {
   return sq2(bx - o.x, by - o.y) <= p.tackle_reach2;
 }
-S2D_DEV bool m_tackle(const MParams& p, const MObj& o, float bx, float by, float dir, float u, bool foul, float& kx, float& ky) {
+template <class P> S2D_DEV bool m_tackle(const P& p, const MObj& o, float bx, float by, float dir, float u, bool foul, float& kx, float& ky) {
   float dx = bx - o.x, dy = by - o.y;
   float sn, cs;
   sincos_deg(o.body, sn, cs);
@@ -240,7 +286,7 @@ S2D_DEV bool m_tackle(const MParams& p, const MObj& o, float bx, float by, float
 }
 // Player::goalieCatch: the ball must lie in the catch rectangle (catch_len long, catch_area_w wide) rooted
 // at the goalie and turned to body + dir; u = uniform draw (used when catch_probability < 1)
-S2D_DEV bool m_catch(const MParams& p, float catch_len, const MObj& o, float bx, float by, float dir, float u) {
+template <class P> S2D_DEV bool m_catch(const P& p, float catch_len, const MObj& o, float bx, float by, float dir, float u) {
   dir = clampf(dir, p.min_catch_angle, p.max_catch_angle);
   float sn, cs;
   sincos_deg(norm_deg_any(o.body + dir), sn, cs);
@@ -249,7 +295,7 @@ S2D_DEV bool m_catch(const MParams& p, float catch_len, const MObj& o, float bx,
   if (!(rx >= 0.0f && rx <= catch_len && fabsf(ry) <= p.catch_half_w)) return false;
   return u < p.catch_probability;
 }
-S2D_DEV void m_update_stamina(const MParams& p, const PTab* pt, int l, MObj& e) {
+template <class P> S2D_DEV void m_update_stamina(const P& p, const PTab* pt, int l, MObj& e) {
   const float effort_min = pt[PT_EFFORT_MIN][l], effort_max = pt[PT_EFFORT_MAX][l];
   if (e.stamina <= p.recover_dec_thr_value) {
     if (e.recovery > p.recover_min) { float r = e.recovery - p.recover_dec; e.recovery = r > p.recover_min ? r : p.recover_min; }
@@ -313,7 +359,7 @@ S2D_DEV void tile_init(float4* row, int l, float size) {
   row[tile_slot(l)] = make_float4(0.0f, 0.0f, size, 0.0f);
   row[l + (BALL + 1)] = make_float4(0.0f, 0.0f, size, 0.0f);
 }
-S2D_DEV void match_cycle(const MParams& p, const PTab* pt, MObj& o, MGame& g, MRare& gr, int l, int half, uint32_t gl, uint32_t gh,
+template <class P> S2D_DEV void match_cycle(const P& p, const PTab* pt, MObj& o, MGame& g, MRare& gr, int l, int half, uint32_t gl, uint32_t gh,
                          int cmd, float a, float bb, MCounts& cnt, float4* pos) {
   int ev = 0;                                              // this lane's events of this cycle (EV_*)
   const bool is_player = l < NP, is_ball = l == BALL;
@@ -755,7 +801,7 @@ S2D_DEV void match_nearest(const MObj& o, MGame& g, int l) {
 // benchmark policy: Philox POLICY stream, block = player, counter = cycle / 2 -- one call serves two cycles (words
 // 0,1 the even one, 2,3 the odd one): command = the two top bits of the first word, magnitude = the bits below them,
 // direction = the second word.  `w` caches the block between the cycles of a fused rollout (`fresh` = draw it).
-S2D_DEV void m_random_action(const MParams& p, uint32_t gl, uint32_t gh, uint32_t cyc, int l, bool fresh, U4& w, int& cmd,
+template <class P> S2D_DEV void m_random_action(const P& p, uint32_t gl, uint32_t gh, uint32_t cyc, int l, bool fresh, U4& w, int& cmd,
                              float& a, float& b) {
   if (fresh || (cyc & 1u) == 0u) w = m_draw(p, gl, gh, cyc >> 1, S2D_ST_POLICY, (uint32_t)l);
   const uint32_t w0 = (cyc & 1u) ? w.z : w.x, w1 = (cyc & 1u) ? w.w : w.y;
@@ -796,7 +842,7 @@ S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g, MRare& 
   r.taker = q.env[ME_TAKER * q.env_stride + e]; r.last_kicker = q.env[ME_LAST_KICKER * q.env_stride + e];
   r.stopped = q.env[ME_STOPPED * q.env_stride + e]; g.tick = q.env[ME_TICK * q.env_stride + e];
 }
-S2D_DEV void m_derive(const MParams& p, const MGame& g, MRare& r) { r.to_half = cycles_to_half(g.cycle, p.half_time_cycles); }
+template <class P> S2D_DEV void m_derive(const P& p, const MGame& g, MRare& r) { r.to_half = cycles_to_half(g.cycle, p.half_time_cycles); }
 S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGame& g, const MRare& r) {
   if (l < SLOTS) {
     int64_t k = e * SLOTS + l;
@@ -842,40 +888,26 @@ __global__ __launch_bounds__(kMBlock) void s2d_match_reset_kernel(MParams p, MPt
 struct MRoll { float* obs; float* reward; int32_t* mode; uint8_t* done; };
 
 // n_steps cycles; actions = [T][N][22][3] or NULL (random policy).  n_steps = 1 with ro = {} is the per-step API.
-__global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p_arg, MPtrs q, int64_t n, int n_steps,
-                                                                     const float* __restrict__ actions, MRoll ro) {
-  __shared__ float4 pos_tile[kEnvsPerBlock][kTileSlots];
-  __shared__ PTab pt[PT_WORDS];                       // per-slot PlayerType parameters, shared by the 8 matches
-  __shared__ unsigned int lds_cnt[8];
-  __shared__ MRare rare[kEnvsPerBlock];                // per-match words only events touch (see MRare)
-  // rollout observations: the two matches of a wave are neighbours in [T][N][24][5], i.e. 960 contiguous bytes per cycle.  Each lane
-  // puts its five words into a wave-private tile (stride 5: no bank conflicts) and the wave stores the block as 60 x 16 bytes --
-  // instead of five 20-byte-strided dword stores per lane (partial lines: what the reach kernels' store-pattern study priced)
-  __shared__ __attribute__((aligned(16))) float obs_tile[kMBlock / 64][2 * SLOTS * S2D_MATCH_OBJ_WORDS];
-  // The ~60 uniform parameters are read from LDS (broadcast reads) where they are used instead of
-  // occupying SGPRs for the whole kernel: as kernargs they cost 142 SGPR spills and 48 B of scratch at
-  // the 128-VGPR cap (26 spills / 12 B this way, +14 % throughput).
-  __shared__ MParams p_lds;
-  static_assert(sizeof(MParams) / 4 <= kMBlock, "one thread per parameter word");
-  if (threadIdx.x < sizeof(MParams) / 4)
-    reinterpret_cast<uint32_t*>(&p_lds)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&p_arg)[threadIdx.x];
-  const MParams& p = p_lds;
-  for (int k = threadIdx.x; k < PT_WORDS * kHalf; k += kMBlock) (&pt[0][0])[k] = q.ptab[k];
-  if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0u;
-  __syncthreads();
+struct MShared {                                      // the workgroup's LDS (declared by the kernel)
+  float4 (*pos_tile)[kTileSlots]; PTab* pt; unsigned int* lds_cnt; MRare* rare; float (*obs_tile)[2 * SLOTS * S2D_MATCH_OBJ_WORDS];
+};
+template <class P>
+S2D_DEV void match_rollout_body(const P& p, const MShared& sh, const MPtrs& q, int64_t n, int n_steps, const float* __restrict__ actions,
+                                const MRoll& ro) {
+  const PTab* pt = sh.pt;
   const int l = threadIdx.x & (kHalf - 1);
   const int half = (threadIdx.x >> 5) & 1;
   const int64_t e = (int64_t)blockIdx.x * kEnvsPerBlock + threadIdx.x / kHalf;
   const bool valid = e < n;
   const int64_t ec = valid ? e : n - 1;              // lanes of out-of-range matches shadow the last match (no stores)
   MObj o; MGame g;
-  MRare& r = rare[threadIdx.x / kHalf];
+  MRare& r = sh.rare[threadIdx.x / kHalf];
   m_load(q, ec, l, o, g, r);
   m_derive(p, g, r);
-  tile_init(pos_tile[threadIdx.x / kHalf], l, pt[PT_SIZE][l]);
+  tile_init(sh.pos_tile[threadIdx.x / kHalf], l, pt[PT_SIZE][l]);
   const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)ec;
   const uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
-  MCounts cnt{lds_cnt, valid, 0u};
+  MCounts cnt{sh.lds_cnt, valid, 0u};
   U4 pol{0, 0, 0, 0};                                     // the policy block of the current pair of cycles
   for (int t = 0; t < n_steps; ++t) {
     int cmd = S2D_MCMD_NONE; float a = 0.0f, b = 0.0f;
@@ -887,9 +919,9 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
         m_random_action(p, gl, gh, (uint32_t)g.tick, l, t == 0, pol, cmd, a, b);
       }
     }
-    match_cycle(p, pt, o, g, r, l, half, gl, gh, cmd, a, b, cnt, pos_tile[threadIdx.x / kHalf]);
+    match_cycle(p, pt, o, g, r, l, half, gl, gh, cmd, a, b, cnt, sh.pos_tile[threadIdx.x / kHalf]);
     if (ro.obs) {                                          // wave-uniform
-      float* const tile = obs_tile[threadIdx.x >> 6];
+      float* const tile = sh.obs_tile[threadIdx.x >> 6];
       if (l < SLOTS) {
         float* tw = tile + (half * SLOTS + l) * S2D_MATCH_OBJ_WORDS;
         tw[0] = o.x; tw[1] = o.y; tw[2] = o.vx; tw[3] = o.vy; tw[4] = o.body;
@@ -918,10 +950,42 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
     unsigned int tk = valid ? cnt.tackles : 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tk += __shfl_down(tk, off);
-    if ((threadIdx.x & 63) == 0 && tk) atomicAdd(&lds_cnt[5], tk);
+    if ((threadIdx.x & 63) == 0 && tk) atomicAdd(&sh.lds_cnt[5], tk);
   }
-  m_flush_counts(q.stats, lds_cnt);
+  m_flush_counts(q.stats, sh.lds_cnt);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&q.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
+}
+
+// STOCK: the configuration words are MStock's constants (m_is_stock() said they equal this engine's); else they are read from LDS
+template <bool STOCK>
+__global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p_arg, MPtrs q, int64_t n, int n_steps,
+                                                                     const float* __restrict__ actions, MRoll ro) {
+  __shared__ float4 pos_tile[kEnvsPerBlock][kTileSlots];
+  __shared__ PTab pt[PT_WORDS];                       // per-slot PlayerType parameters, shared by the 8 matches
+  __shared__ unsigned int lds_cnt[8];
+  __shared__ MRare rare[kEnvsPerBlock];                // per-match words only events touch (see MRare)
+  // rollout observations: the two matches of a wave are neighbours in [T][N][24][5], i.e. 960 contiguous bytes per cycle.  Each lane
+  // puts its five words into a wave-private tile (stride 5: no bank conflicts) and the wave stores the block as 60 x 16 bytes --
+  // instead of five 20-byte-strided dword stores per lane (partial lines: what the reach kernels' store-pattern study priced)
+  __shared__ __attribute__((aligned(16))) float obs_tile[kMBlock / 64][2 * SLOTS * S2D_MATCH_OBJ_WORDS];
+  const MShared sh{pos_tile, pt, lds_cnt, rare, obs_tile};
+  for (int k = threadIdx.x; k < PT_WORDS * kHalf; k += kMBlock) (&pt[0][0])[k] = q.ptab[k];
+  if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0u;
+  if constexpr (STOCK) {
+    __syncthreads();
+    const MStock p{p_arg.auto_reset, p_arg.noise, p_arg.seed_lo, p_arg.seed_hi, p_arg.gid_lo, p_arg.gid_hi};
+    match_rollout_body(p, sh, q, n, n_steps, actions, ro);
+  } else {
+    // The ~70 uniform parameters are read from LDS (broadcast reads) where they are used instead of
+    // occupying SGPRs for the whole kernel: as kernargs they cost 142 SGPR spills and 48 B of scratch at
+    // the 128-VGPR cap (26 spills / 12 B this way, +14 % throughput).
+    __shared__ MParams p_lds;
+    static_assert(sizeof(MParams) / 4 <= kMBlock, "one thread per parameter word");
+    if (threadIdx.x < sizeof(MParams) / 4)
+      reinterpret_cast<uint32_t*>(&p_lds)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&p_arg)[threadIdx.x];
+    __syncthreads();
+    match_rollout_body(p_lds, sh, q, n, n_steps, actions, ro);
+  }
 }
 
 // Relative tables (Player.dist_from_self / angle_from_self of every agent's WorldModel): lane p scans the
@@ -955,6 +1019,7 @@ __global__ __launch_bounds__(kMBlock) void s2d_match_relative_kernel(MPtrs q, in
 // ------------------------------------------------------------------------------------------
 struct S2DMatchEngine {
   S2DMatchConfig cfg; MParams mp; float ptab[PT_WORDS][kHalf]; int64_t n, stride; int device;
+  bool stock = false;                                  // mp's configuration words equal MStock: launches use the constant-folded kernels
   char* arena; size_t arena_bytes; bool owns_arena;
   S2DMatchBuffers buf; MPtrs ptrs;
 };
@@ -1187,6 +1252,19 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   ptab[PT_SIZE][BALL] = p.ball_size; ptab[PT_DECAY][BALL] = (float)s.ball_decay;
 }
 
+// the configuration words of p, bit for bit, against MStock's constants
+static bool m_is_stock(const MParams& p) {
+  auto same = [](float a, float b) { return std::memcmp(&a, &b, sizeof a) == 0; };
+  bool ok = true;
+#define X(name) ok = ok && same(p.name, (float)MStock::name);
+  M_CONFIG_FLOATS(X)
+#undef X
+#define X(name) ok = ok && p.name == (int)MStock::name;
+  M_CONFIG_INTS(X)
+#undef X
+  return ok;
+}
+
 S2D_API size_t s2d_match_arena_bytes(const S2DMatchConfig* cfg, int64_t n_envs) {
   if (!cfg || n_envs <= 0) return 0;
   return m_layout(n_envs).total;
@@ -1225,6 +1303,10 @@ S2D_API int s2d_match_create(const S2DMatchConfig* cfg, int64_t n_envs, int devi
   if (!h) return mfail(S2D_ENOMEM, "host allocation failed");
   h->cfg = *cfg; h->n = n_envs; h->stride = L.stride; h->device = device;
   mparams_from_config(*cfg, h->mp, h->ptab);
+  {                                                     // S2D_MATCH_GENERAL_KERNEL=1: the general instantiation whatever the configuration (tests, A/B)
+    const char* general = std::getenv("S2D_MATCH_GENERAL_KERNEL");
+    h->stock = m_is_stock(h->mp) && !(general && general[0] == '1');
+  }
   if (arena_dev) {
     if (arena_bytes < L.total) { delete h; return mfail(S2D_ENOMEM, "arena smaller than s2d_match_arena_bytes()"); }
     if (reinterpret_cast<uintptr_t>(arena_dev) & 255u) { delete h; return mfail(S2D_EINVAL, "arena must be 256-byte aligned"); }
@@ -1304,10 +1386,18 @@ static int m_launch(S2DMatchHandle h, int n_steps, const float* actions, const S
   MRoll ro{nullptr, nullptr, nullptr, nullptr};
   if (out) ro = MRoll{out->obs, out->reward, out->mode, out->done};
   MDeviceGuard guard(h->device);
-  hipLaunchKernelGGL(s2d_match_rollout_kernel, dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
-                     h->ptrs, h->n, n_steps, actions, ro);
+  if (h->stock)
+    hipLaunchKernelGGL(s2d_match_rollout_kernel<true>, dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
+                       h->ptrs, h->n, n_steps, actions, ro);
+  else
+    hipLaunchKernelGGL(s2d_match_rollout_kernel<false>, dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
+                       h->ptrs, h->n, n_steps, actions, ro);
   MHIP_TRY(hipGetLastError());
   return S2D_OK;
+}
+S2D_API const char* s2d_match_kernel_name(S2DMatchHandle h) {
+  if (!h) return "";
+  return h->stock ? "s2d_match_rollout_kernel<stock>" : "s2d_match_rollout_kernel<general>";
 }
 S2D_API int s2d_match_relative(S2DMatchHandle h, float* dist_dev, float* angle_dev, void* stream) {
   if (!h || !dist_dev || !angle_dev) return mfail(S2D_EINVAL, "NULL argument");

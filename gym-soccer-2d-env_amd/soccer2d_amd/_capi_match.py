@@ -96,6 +96,7 @@ MATCH_PROTOTYPES = (
     ('s2d_match_step', C.c_int, (C.c_void_p, C.c_void_p, C.c_void_p)),
     ('s2d_match_rollout', C.c_int, (C.c_void_p, C.c_int, C.c_void_p, C.POINTER(S2DMatchRollout), C.c_void_p)),
     ('s2d_match_relative', C.c_int, (C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)),
+    ('s2d_match_kernel_name', C.c_char_p, (C.c_void_p,)),
 )
 
 

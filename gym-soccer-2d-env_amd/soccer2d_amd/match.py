@@ -166,6 +166,10 @@ class MatchEngine:
         self._keep = (keep, out)
         return out
 
+    def kernel_name(self):
+        """which instantiation of the cycle kernel this engine launches (`<stock>`: rules and physics folded into the code)"""
+        return self.lib.s2d_match_kernel_name(self._h).decode()
+
     def relative_tables(self):
         """(dist, angle) float32 [N,22,23]: Player.dist_from_self / angle_from_self (and the ball's, column 22)
         as seen by each of the 22 agents (idl/service.proto:84-85, 155-156)."""

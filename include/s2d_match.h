@@ -182,6 +182,12 @@ int s2d_match_rollout(S2DMatchHandle h, int n_steps, const float *actions_dev /*
  * p, degrees; idl/service.proto:84-85, 155-156).  The diagonal (j = p) is 0. */
 int s2d_match_relative(S2DMatchHandle h, float *dist_dev, float *angle_dev, void *stream);
 
+/* Which instantiation of the cycle kernel this engine launches: "...<stock>" when its configuration equals
+ * s2d_match_default_config() in every rule / physics word (those are compile-time constants there), "...<general>" otherwise
+ * (same arithmetic, parameters read at run time; S2D_MATCH_GENERAL_KERNEL=1 in the environment selects it regardless).  Seed,
+ * env_id_offset, auto_reset, noise and the PlayerTypes do not matter for the choice. */
+const char *s2d_match_kernel_name(S2DMatchHandle h);
+
 #ifdef __cplusplus
 }
 #endif

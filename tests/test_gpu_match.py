@@ -501,3 +501,85 @@ def test_match_parity_under_scripted_policies():
     assert_match_same(eng, orc, 'scripted final')
     st = orc.stats()
     assert st[4] > 500 and GM_FREE_KICK_FAULT in modes, (modes, list(st))      # many kicks, and faults were called
+
+
+def _stock_pair(n, **kw):
+    """default rules and physics (the constant-folded `<stock>` kernel) with match clocks moved next to half time / time over"""
+    eng, orc = _pair(n, **kw)
+    assert eng.kernel_name() == 's2d_match_rollout_kernel<stock>'
+    cyc = np.zeros(n, dtype=np.int32)
+    cyc[: n // 3] = 2960 + 2 * (np.arange(n // 3) % 15)                      # the first half ends within the test
+    cyc[n // 3: 2 * (n // 3)] = 5950 + 2 * (np.arange(n // 3) % 20)          # ... and so does the match
+    eng.cycle.copy_(torch.as_tensor(cyc, device='cuda:0'))
+    for e in range(n):
+        orc.set_game(e, cycle=int(cyc[e]))
+    return eng, orc
+
+
+@pytest.mark.parametrize('noise', [False, True])
+def test_stock_kernel_parity_random_policy(noise):
+    """The stock configuration runs the instantiation whose ~70 rule / physics words are compile-time constants: same oracle, every
+    word equal after every cycle, through half time, time over + auto-reset (clocks set next to them), kick-offs and set plays."""
+    n = 45
+    eng, orc = _stock_pair(n, noise=noise)
+    modes = set()
+    for t in range(260):
+        eng.step(None); orc.step(None)
+        if t % 10 == 9 or t < 12:
+            assert_match_same(eng, orc, f'stock t={t}')
+        modes.update(int(m) for m in orc.get('mode'))
+    assert_match_same(eng, orc, 'stock final')
+    assert list(eng.stats.cpu().numpy()) == list(orc.stats())
+    from soccer2d_amd._capi_match import GM_FIRST_HALF_OVER
+    assert GM_FIRST_HALF_OVER in modes and int(orc.stats()[3]) >= n // 3      # half time was called, matches finished
+
+
+def test_stock_kernel_parity_scripted_policies():
+    """kicks, goals, set plays, faults under the stock kernel: the dribbler / chaser pairing of the scripted-policy test"""
+    from soccer2d_amd import league as LG
+    n = 24
+    eng, orc = _stock_pair(n, noise=True)
+    left, right = LG.ParamChaser([40.0, 25.0, 15.0, 1.0]), LG.ParamChaser([60.0, 10.0, 20.0, 2.0])
+    rs = np.random.RandomState(5)
+    for t in range(420):
+        act = torch.zeros((n, 22, 3), device='cuda:0')
+        act[:, :11] = left(eng, 1); act[:, 11:] = right(eng, 2)
+        if t % 7 == 3:                                                           # now and then: tackles (some with the foul flag), catches
+            who = torch.as_tensor(rs.randint(0, 22, n), device='cuda:0')
+            act[torch.arange(n), who, 0] = 4.0 if t % 14 == 3 else 5.0
+            act[torch.arange(n), who, 1] = float(rs.uniform(-90, 90))
+            act[torch.arange(n), who, 2] = float(t % 21 == 3)
+        a = act.cpu().numpy()
+        eng.step(act); orc.step(a)
+        if t % 4 == 0 or t < 40:
+            assert_match_same(eng, orc, f'stock scripted t={t}')
+    assert_match_same(eng, orc, 'stock scripted final')
+    st = orc.stats()
+    assert st[4] > 300 and (st[1] + st[2]) > 0, list(st)                        # many kicks, goals
+
+
+def test_stock_and_general_kernels_agree(monkeypatch):
+    """Same configuration through both instantiations (S2D_MATCH_GENERAL_KERNEL=1 forces the run-time-parameter one): identical
+    state words and rollout records at 2 048 matches x 3 x 64 fused cycles."""
+    from soccer2d_amd.match import MatchEngine, make_match_config
+    n, T = 2048, 64
+    a = MatchEngine(n, 'cuda:0', cfg=make_match_config(noise=True))
+    monkeypatch.setenv('S2D_MATCH_GENERAL_KERNEL', '1')
+    b = MatchEngine(n, 'cuda:0', cfg=make_match_config(noise=True))
+    monkeypatch.delenv('S2D_MATCH_GENERAL_KERNEL')
+    assert a.kernel_name().endswith('<stock>') and b.kernel_name().endswith('<general>')
+    g = torch.Generator(device='cpu').manual_seed(7)
+    cyc = (2 * torch.randint(0, 3000, (n,), generator=g, dtype=torch.int32)).to('cuda:0')
+    a.cycle += cyc; b.cycle += cyc
+    for k in range(3):
+        ra, rb = a.rollout(T), b.rollout(T)
+        torch.cuda.synchronize()
+        for key in ('obs', 'reward', 'mode', 'done'):
+            assert torch.equal(ra[key].view(torch.uint8) if ra[key].dtype != torch.uint8 else ra[key],
+                               rb[key].view(torch.uint8) if rb[key].dtype != torch.uint8 else rb[key]), (k, key)
+    for f in MO.OBJ_FIELDS + ('catch_ban', 'card') + MO.ENV_FIELDS + ('ball_holder', 'goalie_moves', 'set_play_taker', 'last_kicker', 'stopped_cycle', 'tick'):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    assert torch.equal(a.stats, b.stats)
+    # a changed rule word selects the general kernel by itself
+    c = MatchEngine(8, 'cuda:0', cfg=make_match_config(half_time_cycles=100))
+    assert c.kernel_name().endswith('<general>')
