@@ -118,6 +118,33 @@ struct MStock {
 // every configuration word of MParams is in one of the two lists (the remaining six are the per-engine words)
 static_assert(sizeof(MParams) == 4 * (53 + 14 + 6), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
 
+// The per-slot table of an engine whose 22 players are all of the stock PlayerType (the default: s2d_match_default_config), with the
+// same spelling as the LDS table -- types[ROW][lane] -- but every entry an immediate: a cycle reads about ten of them per lane, each
+// an LDS load and a wait in the general kernel.  Column 22 (the ball) differs in the size / decay rows; pad lanes (23..31) get the
+// players' values (the LDS table holds zeros there; nothing reads them).  kickable_area2 is the one derived word that is not a
+// constant expression (the host searches the largest float whose root does not exceed the kickable area): the engine's own value.
+struct MStockTypes {
+  static constexpr float speed_max = (float)1.05, speed_max2 = speed_max * speed_max, stamina_inc = (float)45.0, decay = (float)0.4;
+  static constexpr float inertia = (float)5.0, dash_rate = (float)0.006, size = (float)0.3, inv_kick_margin = (float)(1.0 / 0.7);
+  static constexpr float kick_rand = (float)0.1, extra_stamina = (float)50.0, effort_max = (float)1.0, effort_min = (float)0.6;
+  static constexpr float kick_rate = (float)0.027, catch_len = (float)(1.2 * 1.0), ball_decay = (float)0.94;
+  float kickable_area2;
+  struct Row {
+    int row; float ka2;
+    S2D_DEV float operator[](int l) const {
+      switch (row) {
+        case PT_SPEED_MAX: return speed_max; case PT_SPEED_MAX2: return speed_max2; case PT_STAMINA_INC: return stamina_inc;
+        case PT_DECAY: return l == BALL ? ball_decay : decay; case PT_INERTIA: return inertia; case PT_DASH_RATE: return dash_rate;
+        case PT_SIZE: return l == BALL ? MStock::ball_size : size; case PT_INV_KICK_MARGIN: return inv_kick_margin;
+        case PT_KICKABLE_AREA2: return ka2; case PT_KICK_RAND: return kick_rand; case PT_EXTRA_STAMINA: return extra_stamina;
+        case PT_EFFORT_MAX: return effort_max; case PT_EFFORT_MIN: return effort_min; case PT_KICK_RATE: return kick_rate;
+        default: return catch_len;
+      }
+    }
+  };
+  S2D_DEV Row operator[](int row) const { return Row{row, kickable_area2}; }
+};
+
 struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int tackle, catch_ban, card; };
 // Per-match words every cycle reads (registers; the same value in the 32 lanes of the match's half-wave) ...
 struct MGame { int cycle, mode, mode_side, last_touch, offside; float reward; int done, nearest_l, nearest_r;
@@ -141,7 +168,12 @@ __constant__ float kFormX[11] = {-50.0f, -35.0f, -35.0f, -35.0f, -35.0f, -20.0f,
 __constant__ float kFormY[11] = {0.0f, -20.0f, -7.0f, 7.0f, 20.0f, -22.0f, -8.0f, 8.0f, 22.0f, -6.0f, 6.0f};
 
 template <class P> S2D_DEV U4 m_draw(const P& p, uint32_t gl, uint32_t gh, uint32_t cyc, uint32_t stream, uint32_t block) {
-  return philox4x32_10(gl, gh, cyc, (stream << 16) | block, p.seed_lo, p.seed_hi);
+  // The match id and the seed do not change during a launch, so the compiler would compute the loop-invariant part of the first
+  // round (two 64-bit products) and all ten round keys once per launch and keep them -- 30 registers this kernel does not have:
+  // they were spilled to scratch and reloaded at every draw.  Opaque copies keep the whole block function inside the loop.
+  uint32_t k0 = __builtin_amdgcn_readfirstlane(p.seed_lo), k1 = __builtin_amdgcn_readfirstlane(p.seed_hi);
+  asm volatile("" : "+v"(gl), "+v"(gh), "+s"(k0), "+s"(k1));
+  return philox4x32_10(gl, gh, cyc, (stream << 16) | block, k0, k1);
 }
 S2D_DEV int side_of(int i) { return i < 11 ? SIDE_LEFT : SIDE_RIGHT; }
 S2D_DEV int other_side(int s) { return s == SIDE_LEFT ? SIDE_RIGHT : SIDE_LEFT; }
@@ -197,7 +229,7 @@ template <class P> S2D_DEV void m_reset(const P& p, float effort_max, MObj& o, M
   if (l < NP) m_recover(p, effort_max, o, true);
   m_place(o, l, SIDE_LEFT);
 }
-template <class P> S2D_DEV void m_dash(const P& p, const PTab* pt, int l, MObj& o, float power, float dir, float& ax, float& ay) {
+template <class P, class TY> S2D_DEV void m_dash(const P& p, const TY& pt, int l, MObj& o, float power, float dir, float& ax, float& ay) {
   power = clampf(power, p.min_dash_power, p.max_dash_power);
   dir = clampf(dir, p.min_dash_angle, p.max_dash_angle);
   if (p.dash_angle_step > 0.0f) dir = p.dash_angle_step * rintf(dir * p.inv_dash_angle_step);
@@ -226,7 +258,7 @@ template <class P> S2D_DEV void m_turn(const P& p, float inertia_moment, MObj& o
   if (p.noise) f = 1.0f + (noise_u * 2.0f - 1.0f) * p.player_rand;
   o.body = norm_deg_any(o.body + f * moment / (1.0f + inertia_moment * speed));
 }
-template <class P> S2D_DEV bool m_kick(const P& p, const PTab* pt, int l, const MObj& o, float bx, float by, float bvx, float bvy,
+template <class P, class TY> S2D_DEV bool m_kick(const P& p, const TY& pt, int l, const MObj& o, float bx, float by, float bvx, float bvy,
                     float power, float dir, float u_mag, float u_ang, float& kx, float& ky) {
   float dx = bx - o.x, dy = by - o.y;
   // dist <= kickable_area decided on the square: sqrt is correctly rounded and monotone, and the table holds
@@ -295,7 +327,7 @@ template <class P> S2D_DEV bool m_catch(const P& p, float catch_len, const MObj&
   if (!(rx >= 0.0f && rx <= catch_len && fabsf(ry) <= p.catch_half_w)) return false;
   return u < p.catch_probability;
 }
-template <class P> S2D_DEV void m_update_stamina(const P& p, const PTab* pt, int l, MObj& e) {
+template <class P, class TY> S2D_DEV void m_update_stamina(const P& p, const TY& pt, int l, MObj& e) {
   const float effort_min = pt[PT_EFFORT_MIN][l], effort_max = pt[PT_EFFORT_MAX][l];
   if (e.stamina <= p.recover_dec_thr_value) {
     if (e.recovery > p.recover_min) { float r = e.recovery - p.recover_dec; e.recovery = r > p.recover_min ? r : p.recover_min; }
@@ -359,7 +391,7 @@ S2D_DEV void tile_init(float4* row, int l, float size) {
   row[tile_slot(l)] = make_float4(0.0f, 0.0f, size, 0.0f);
   row[l + (BALL + 1)] = make_float4(0.0f, 0.0f, size, 0.0f);
 }
-template <class P> S2D_DEV void match_cycle(const P& p, const PTab* pt, MObj& o, MGame& g, MRare& gr, int l, int half, uint32_t gl, uint32_t gh,
+template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, MObj& o, MGame& g, MRare& gr, int l, int half, uint32_t gl, uint32_t gh,
                          int cmd, float a, float bb, MCounts& cnt, float4* pos) {
   int ev = 0;                                              // this lane's events of this cycle (EV_*)
   const bool is_player = l < NP, is_ball = l == BALL;
@@ -891,12 +923,11 @@ struct MRoll { float* obs; float* reward; int32_t* mode; uint8_t* done; };
 struct MShared {                                      // the workgroup's LDS (declared by the kernel)
   float4 (*pos_tile)[kTileSlots]; PTab* pt; unsigned int* lds_cnt; MRare* rare; float (*obs_tile)[2 * SLOTS * S2D_MATCH_OBJ_WORDS];
 };
-template <class P>
-S2D_DEV void match_rollout_body(const P& p, const MShared& sh, const MPtrs& q, int64_t n, int n_steps, const float* __restrict__ actions,
-                                const MRoll& ro) {
-  const PTab* pt = sh.pt;
-  const int l = threadIdx.x & (kHalf - 1);
-  const int half = (threadIdx.x >> 5) & 1;
+template <class P, class TY>
+S2D_DEV void match_rollout_body(const P& p, const TY& pt, const MShared& sh, const MPtrs& q, int64_t n, int n_steps,
+                                const float* __restrict__ actions, const MRoll& ro) {
+  const int l = threadIdx.x & (kHalf - 1), l_launch = l;
+  const int half = (threadIdx.x >> 5) & 1, half_launch = half;
   const int64_t e = (int64_t)blockIdx.x * kEnvsPerBlock + threadIdx.x / kHalf;
   const bool valid = e < n;
   const int64_t ec = valid ? e : n - 1;              // lanes of out-of-range matches shadow the last match (no stores)
@@ -910,6 +941,12 @@ S2D_DEV void match_rollout_body(const P& p, const MShared& sh, const MPtrs& q, i
   MCounts cnt{sh.lds_cnt, valid, 0u};
   U4 pol{0, 0, 0, 0};                                     // the policy block of the current pair of cycles
   for (int t = 0; t < n_steps; ++t) {
+    // Everything that depends only on the lane number -- masks such as "is a player", "is the ball", bit positions, Philox block
+    // words -- is loop-invariant, and the compiler computes it all once per launch and keeps it: ~90 scalar and ~20 vector
+    // registers more than there are, spilled and reloaded inside the loop.  One instruction each to recompute: opaque copies of
+    // the lane number and the half make them per-cycle values.
+    int l = l_launch, half = half_launch;
+    asm volatile("" : "+v"(l), "+v"(half));
     int cmd = S2D_MCMD_NONE; float a = 0.0f, b = 0.0f;
     if (l < NP) {
       if (actions) {
@@ -956,8 +993,9 @@ S2D_DEV void match_rollout_body(const P& p, const MShared& sh, const MPtrs& q, i
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&q.stats[0], (unsigned long long)n * (unsigned long long)n_steps);
 }
 
-// STOCK: the configuration words are MStock's constants (m_is_stock() said they equal this engine's); else they are read from LDS
-template <bool STOCK>
+// STOCK: the configuration words are MStock's constants (m_is_stock() said they equal this engine's); else they are read from LDS.
+// STOCK_TYPES (with STOCK): all 22 players of the stock PlayerType, the table's entries are constants too.
+template <bool STOCK, bool STOCK_TYPES>
 __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p_arg, MPtrs q, int64_t n, int n_steps,
                                                                      const float* __restrict__ actions, MRoll ro) {
   __shared__ float4 pos_tile[kEnvsPerBlock][kTileSlots];
@@ -969,12 +1007,19 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
   // instead of five 20-byte-strided dword stores per lane (partial lines: what the reach kernels' store-pattern study priced)
   __shared__ __attribute__((aligned(16))) float obs_tile[kMBlock / 64][2 * SLOTS * S2D_MATCH_OBJ_WORDS];
   const MShared sh{pos_tile, pt, lds_cnt, rare, obs_tile};
-  for (int k = threadIdx.x; k < PT_WORDS * kHalf; k += kMBlock) (&pt[0][0])[k] = q.ptab[k];
+  static_assert(STOCK || !STOCK_TYPES, "constant types come with constant rules");
+  if constexpr (!STOCK_TYPES)
+    for (int k = threadIdx.x; k < PT_WORDS * kHalf; k += kMBlock) (&pt[0][0])[k] = q.ptab[k];
   if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0u;
   if constexpr (STOCK) {
     __syncthreads();
     const MStock p{p_arg.auto_reset, p_arg.noise, p_arg.seed_lo, p_arg.seed_hi, p_arg.gid_lo, p_arg.gid_hi};
-    match_rollout_body(p, sh, q, n, n_steps, actions, ro);
+    if constexpr (STOCK_TYPES) {
+      const MStockTypes types{__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q.ptab[PT_KICKABLE_AREA2 * kHalf])))};
+      match_rollout_body(p, types, sh, q, n, n_steps, actions, ro);
+    } else {
+      match_rollout_body(p, static_cast<const PTab*>(pt), sh, q, n, n_steps, actions, ro);
+    }
   } else {
     // The ~70 uniform parameters are read from LDS (broadcast reads) where they are used instead of
     // occupying SGPRs for the whole kernel: as kernargs they cost 142 SGPR spills and 48 B of scratch at
@@ -984,7 +1029,7 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
     if (threadIdx.x < sizeof(MParams) / 4)
       reinterpret_cast<uint32_t*>(&p_lds)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&p_arg)[threadIdx.x];
     __syncthreads();
-    match_rollout_body(p_lds, sh, q, n, n_steps, actions, ro);
+    match_rollout_body(p_lds, static_cast<const PTab*>(pt), sh, q, n, n_steps, actions, ro);
   }
 }
 
@@ -1020,6 +1065,7 @@ __global__ __launch_bounds__(kMBlock) void s2d_match_relative_kernel(MPtrs q, in
 struct S2DMatchEngine {
   S2DMatchConfig cfg; MParams mp; float ptab[PT_WORDS][kHalf]; int64_t n, stride; int device;
   bool stock = false;                                  // mp's configuration words equal MStock: launches use the constant-folded kernels
+  bool stock_types = false;                            // ... and every player is of the stock PlayerType (ptab's entries equal MStockTypes)
   char* arena; size_t arena_bytes; bool owns_arena;
   S2DMatchBuffers buf; MPtrs ptrs;
 };
@@ -1265,6 +1311,22 @@ static bool m_is_stock(const MParams& p) {
   return ok;
 }
 
+static bool m_types_are_stock(const float (*t)[kHalf]) {
+  auto same = [](float a, float b) { return std::memcmp(&a, &b, sizeof a) == 0; };
+  bool ok = same(t[PT_SIZE][BALL], MStock::ball_size) && same(t[PT_DECAY][BALL], MStockTypes::ball_decay);
+  for (int i = 0; i < NP && ok; ++i) {
+    ok = same(t[PT_SPEED_MAX][i], MStockTypes::speed_max) && same(t[PT_SPEED_MAX2][i], MStockTypes::speed_max2) &&
+         same(t[PT_STAMINA_INC][i], MStockTypes::stamina_inc) && same(t[PT_DECAY][i], MStockTypes::decay) &&
+         same(t[PT_INERTIA][i], MStockTypes::inertia) && same(t[PT_DASH_RATE][i], MStockTypes::dash_rate) &&
+         same(t[PT_SIZE][i], MStockTypes::size) && same(t[PT_INV_KICK_MARGIN][i], MStockTypes::inv_kick_margin) &&
+         same(t[PT_KICKABLE_AREA2][i], t[PT_KICKABLE_AREA2][0]) && same(t[PT_KICK_RAND][i], MStockTypes::kick_rand) &&
+         same(t[PT_EXTRA_STAMINA][i], MStockTypes::extra_stamina) && same(t[PT_EFFORT_MAX][i], MStockTypes::effort_max) &&
+         same(t[PT_EFFORT_MIN][i], MStockTypes::effort_min) && same(t[PT_KICK_RATE][i], MStockTypes::kick_rate) &&
+         same(t[PT_CATCH_LEN][i], MStockTypes::catch_len);
+  }
+  return ok;
+}
+
 S2D_API size_t s2d_match_arena_bytes(const S2DMatchConfig* cfg, int64_t n_envs) {
   if (!cfg || n_envs <= 0) return 0;
   return m_layout(n_envs).total;
@@ -1306,6 +1368,7 @@ S2D_API int s2d_match_create(const S2DMatchConfig* cfg, int64_t n_envs, int devi
   {                                                     // S2D_MATCH_GENERAL_KERNEL=1: the general instantiation whatever the configuration (tests, A/B)
     const char* general = std::getenv("S2D_MATCH_GENERAL_KERNEL");
     h->stock = m_is_stock(h->mp) && !(general && general[0] == '1');
+    h->stock_types = h->stock && m_types_are_stock(h->ptab);
   }
   if (arena_dev) {
     if (arena_bytes < L.total) { delete h; return mfail(S2D_ENOMEM, "arena smaller than s2d_match_arena_bytes()"); }
@@ -1386,18 +1449,21 @@ static int m_launch(S2DMatchHandle h, int n_steps, const float* actions, const S
   MRoll ro{nullptr, nullptr, nullptr, nullptr};
   if (out) ro = MRoll{out->obs, out->reward, out->mode, out->done};
   MDeviceGuard guard(h->device);
-  if (h->stock)
-    hipLaunchKernelGGL(s2d_match_rollout_kernel<true>, dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
+  if (h->stock_types)
+    hipLaunchKernelGGL((s2d_match_rollout_kernel<true, true>), dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
+                       h->ptrs, h->n, n_steps, actions, ro);
+  else if (h->stock)
+    hipLaunchKernelGGL((s2d_match_rollout_kernel<true, false>), dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
                        h->ptrs, h->n, n_steps, actions, ro);
   else
-    hipLaunchKernelGGL(s2d_match_rollout_kernel<false>, dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
+    hipLaunchKernelGGL((s2d_match_rollout_kernel<false, false>), dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
                        h->ptrs, h->n, n_steps, actions, ro);
   MHIP_TRY(hipGetLastError());
   return S2D_OK;
 }
 S2D_API const char* s2d_match_kernel_name(S2DMatchHandle h) {
   if (!h) return "";
-  return h->stock ? "s2d_match_rollout_kernel<stock>" : "s2d_match_rollout_kernel<general>";
+  return h->stock_types ? "s2d_match_rollout_kernel<stock, stock types>" : h->stock ? "s2d_match_rollout_kernel<stock>" : "s2d_match_rollout_kernel<general>";
 }
 S2D_API int s2d_match_relative(S2DMatchHandle h, float* dist_dev, float* angle_dev, void* stream) {
   if (!h || !dist_dev || !angle_dev) return mfail(S2D_EINVAL, "NULL argument");

@@ -506,7 +506,7 @@ def test_match_parity_under_scripted_policies():
 def _stock_pair(n, **kw):
     """default rules and physics (the constant-folded `<stock>` kernel) with match clocks moved next to half time / time over"""
     eng, orc = _pair(n, **kw)
-    assert eng.kernel_name() == 's2d_match_rollout_kernel<stock>'
+    assert eng.kernel_name() == 's2d_match_rollout_kernel<stock, stock types>'
     cyc = np.zeros(n, dtype=np.int32)
     cyc[: n // 3] = 2960 + 2 * (np.arange(n // 3) % 15)                      # the first half ends within the test
     cyc[n // 3: 2 * (n // 3)] = 5950 + 2 * (np.arange(n // 3) % 20)          # ... and so does the match
@@ -567,7 +567,7 @@ def test_stock_and_general_kernels_agree(monkeypatch):
     monkeypatch.setenv('S2D_MATCH_GENERAL_KERNEL', '1')
     b = MatchEngine(n, 'cuda:0', cfg=make_match_config(noise=True))
     monkeypatch.delenv('S2D_MATCH_GENERAL_KERNEL')
-    assert a.kernel_name().endswith('<stock>') and b.kernel_name().endswith('<general>')
+    assert a.kernel_name().endswith('<stock, stock types>') and b.kernel_name().endswith('<general>')
     g = torch.Generator(device='cpu').manual_seed(7)
     cyc = (2 * torch.randint(0, 3000, (n,), generator=g, dtype=torch.int32)).to('cuda:0')
     a.cycle += cyc; b.cycle += cyc
