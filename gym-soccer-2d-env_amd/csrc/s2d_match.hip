@@ -940,6 +940,10 @@ S2D_DEV void match_rollout_body(const P& p, const TY& pt, const MShared& sh, con
   const uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
   MCounts cnt{sh.lds_cnt, valid, 0u};
   U4 pol{0, 0, 0, 0};                                     // the policy block of the current pair of cycles
+  // The state loaded above is first used inside the loop, and that is where the compiler would wait for it -- with s_waitcnt
+  // vmcnt(k), a counter that on gfx9 also counts STORES: from the second cycle on those waits would hold the wave until the
+  // previous cycles' record stores had been acknowledged by memory.  Waiting for the loads here leaves no wait in the loop.
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
   for (int t = 0; t < n_steps; ++t) {
     // Everything that depends only on the lane number -- masks such as "is a player", "is the ball", bit positions, Philox block
     // words -- is loop-invariant, and the compiler computes it all once per launch and keeps it: ~90 scalar and ~20 vector

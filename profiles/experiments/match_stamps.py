@@ -13,7 +13,7 @@ import bench
 NAMES = {0: 'policy + entry broadcasts', 1: '1 commands (dash/turn/kick/tackle)', 2: '1b player movement', 3: '1c catch / foul tests',
          4: '2 ball impulses + move', 5: '3 overlap detection (11 pairs)', 6: '3b Jacobi passes', 7: '3c collision aftermath',
          8: '4 set-play distance', 9: '5 referee', 10: 'parking', 11: '6 decay / timers / stamina', 12: 'event counters / auto reset',
-         13: 'observation tile + store', 14: 'record words', 15: 'loop back'}
+         13: 'observation tile + store', 14: 'record words', 15: 'record words + loop back'}
 dev = torch.device('cuda', 0)
 stream = torch.cuda.current_stream(dev)
 m = bench.measure_match(8192, dev, 0, 64, 16, 3, stream, 200.0, phase='spread')
