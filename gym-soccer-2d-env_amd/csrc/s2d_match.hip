@@ -944,6 +944,20 @@ S2D_DEV void match_rollout_body(const P& p, const TY& pt, const MShared& sh, con
   // vmcnt(k), a counter that on gfx9 also counts STORES: from the second cycle on those waits would hold the wave until the
   // previous cycles' record stores had been acknowledged by memory.  Waiting for the loads here leaves no wait in the loop.
   __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+  // The record rows of cycle t lie n matches behind those of cycle t - 1: one uniform pointer per array, advanced once per cycle
+  // (scalar adds), plus a small per-lane offset inside the workgroup's stretch of the row -- 32 bits, so the stores take their base
+  // from scalar registers.  (Formed per cycle from t, n and the match index, the four addresses were 64-bit vector arithmetic: ~45
+  // of the cycle's ~550 vector instructions.)
+  constexpr int kVecPerMatch = SLOTS * S2D_MATCH_OBJ_WORDS / 4;   // 30 float4 per match
+  const int64_t eb = (int64_t)blockIdx.x * kEnvsPerBlock;  // the workgroup's first match
+  char* obs_row = reinterpret_cast<char*>(ro.obs) + eb * (int64_t)(kVecPerMatch * 16);
+  float* reward_row = ro.reward + eb; int32_t* mode_row = ro.mode + eb; uint8_t* done_row = ro.done + eb;
+  const uint32_t lane = threadIdx.x & 63u, m_in_wg = threadIdx.x / kHalf;
+  const uint32_t obs_off = ((threadIdx.x >> 6) * 2u * kVecPerMatch + lane) * 16u;
+  const int64_t e0 = e - half;                             // first match of this wave (matches of a wave: e0, e0 + 1)
+  const bool obs_lane = (int)lane < (e0 + 1 < n ? 2 * kVecPerMatch : (e0 < n ? kVecPerMatch : 0));
+  float* const obs_slot = sh.obs_tile[threadIdx.x >> 6] + (half * SLOTS + l) * S2D_MATCH_OBJ_WORDS;
+  const float4* const obs_vec = reinterpret_cast<const float4*>(sh.obs_tile[threadIdx.x >> 6]) + lane;
   for (int t = 0; t < n_steps; ++t) {
     // Everything that depends only on the lane number -- masks such as "is a player", "is the ball", bit positions, Philox block
     // words -- is loop-invariant, and the compiler computes it all once per launch and keeps it: ~90 scalar and ~20 vector
@@ -962,28 +976,18 @@ S2D_DEV void match_rollout_body(const P& p, const TY& pt, const MShared& sh, con
     }
     match_cycle(p, pt, o, g, r, l, half, gl, gh, cmd, a, b, cnt, sh.pos_tile[threadIdx.x / kHalf]);
     if (ro.obs) {                                          // wave-uniform
-      float* const tile = sh.obs_tile[threadIdx.x >> 6];
-      if (l < SLOTS) {
-        float* tw = tile + (half * SLOTS + l) * S2D_MATCH_OBJ_WORDS;
-        tw[0] = o.x; tw[1] = o.y; tw[2] = o.vx; tw[3] = o.vy; tw[4] = o.body;
-      }
+      if (l < SLOTS) { obs_slot[0] = o.x; obs_slot[1] = o.y; obs_slot[2] = o.vx; obs_slot[3] = o.vy; obs_slot[4] = o.body; }
       wave_fence();
-      const int lane = threadIdx.x & 63;
-      const int64_t e0 = e - half;                         // first match of this wave (matches of a wave: e0, e0 + 1)
-      constexpr int kVecPerMatch = SLOTS * S2D_MATCH_OBJ_WORDS / 4;   // 30 float4 per match
-      const int n_vec = e0 + 1 < n ? 2 * kVecPerMatch : (e0 < n ? kVecPerMatch : 0);
-      if (lane < n_vec)
-        reinterpret_cast<float4*>(ro.obs + ((int64_t)t * n + e0) * (SLOTS * S2D_MATCH_OBJ_WORDS))[lane] = reinterpret_cast<const float4*>(tile)[lane];
+      if (obs_lane) *reinterpret_cast<float4*>(obs_row + obs_off) = *obs_vec;
       wave_fence();
+      obs_row += n * (int64_t)(kVecPerMatch * 16);
     }
-    if (valid) {
-      const int64_t row = (int64_t)t * n + e;
-      if (l == BALL) {
-        if (ro.reward) ro.reward[row] = g.reward;
-        if (ro.mode) ro.mode[row] = g.mode;
-        if (ro.done) ro.done[row] = (uint8_t)g.done;
-      }
+    if (valid && l == BALL) {
+      if (ro.reward) reward_row[m_in_wg] = g.reward;
+      if (ro.mode) mode_row[m_in_wg] = g.mode;
+      if (ro.done) done_row[m_in_wg] = (uint8_t)g.done;
     }
+    reward_row += n; mode_row += n; done_row += n;         // (never dereferenced when the array is absent)
   }
   match_nearest(o, g, l);
   if (valid) m_store(q, e, l, o, g, r);
