@@ -567,14 +567,17 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   wave_fence();
   {
     const float4* mine = pos + l;
+    // d2 < r^2 for some partner  <=>  min over the partners of (d2 - r^2) < 0 (the sign of a float difference is exact): one running
+    // minimum instead of eleven compare results gathered bit by bit
+    float worst = 1.0f;
 #pragma unroll
     for (int m = 1; m <= 11; ++m) {
       const float4 pj = mine[m];
       float dx = o.x - pj.x, dy = o.y - pj.y;
       float r = ri + pj.z;
-      overlap |= sq2(dx, dy) < r * r;
+      worst = fminf(worst, sq2(dx, dy) - r * r);
     }
-    overlap &= l <= BALL;
+    overlap = worst < 0.0f && l <= BALL;
   }
   wave_fence();
   const bool wave_overlap = __ballot(overlap) != 0ull;     // wave-uniform: everything about collisions hangs on it
@@ -830,15 +833,17 @@ S2D_DEV void match_nearest(const MObj& o, MGame& g, int l) {
   g.nearest_l = (int)(kl & 0xFFull); g.nearest_r = (int)(kr & 0xFFull);
 }
 
-// benchmark policy: Philox POLICY stream, block = player, counter = cycle / 2 -- one call serves two cycles (words
-// 0,1 the even one, 2,3 the odd one): command = the two top bits of the first word, magnitude = the bits below them,
-// direction = the second word.  `w` caches the block between the cycles of a fused rollout (`fresh` = draw it).
+// benchmark policy: Philox POLICY stream, block = player, counter = cycle / 4 -- one call serves four cycles, one word each:
+// command = the two top bits, magnitude = the 15 bits below them, direction = the low 15 bits (both exact in float: integers
+// below 2^15 times a power of two).  `w` caches the block between the cycles of a fused rollout (`fresh` = draw it).
 template <class P> S2D_DEV void m_random_action(const P& p, uint32_t gl, uint32_t gh, uint32_t cyc, int l, bool fresh, U4& w, int& cmd,
                              float& a, float& b) {
-  if (fresh || (cyc & 1u) == 0u) w = m_draw(p, gl, gh, cyc >> 1, S2D_ST_POLICY, (uint32_t)l);
-  const uint32_t w0 = (cyc & 1u) ? w.z : w.x, w1 = (cyc & 1u) ? w.w : w.y;
-  cmd = 1 + (int)(w0 >> 30);
-  float u = rnd_u01(w0 << 2), s = rnd_u01(w1) * 2.0f - 1.0f;
+  if (fresh || (cyc & 3u) == 0u) w = m_draw(p, gl, gh, cyc >> 2, S2D_ST_POLICY, (uint32_t)l);
+  const uint32_t lo = (cyc & 1u) ? w.y : w.x, hi = (cyc & 1u) ? w.w : w.z;
+  const uint32_t wd = (cyc & 2u) ? hi : lo;
+  cmd = 1 + (int)(wd >> 30);
+  const float u = (float)((wd >> 15) & 0x7FFFu) * 3.0517578125e-05f;             // [0, 1)
+  const float s = (float)(wd & 0x7FFFu) * 6.103515625e-05f - 1.0f;               // [-1, 1)
   // selects, not conditional stores through the references: those made {a, b} a stack array in scratch memory
   const bool two = cmd == S2D_MCMD_DASH || cmd == S2D_MCMD_KICK;
   const float ang = s * 180.0f;

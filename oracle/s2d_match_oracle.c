@@ -646,16 +646,15 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   }
 }
 
-/* uniform random policy of the benchmark: Philox POLICY stream, block = player, counter = cycle / 2 (words 0,1 serve
- * the even cycle, 2,3 the odd one): command = the two top bits of the first word, magnitude = the bits below them,
- * direction = the second word */
+/* uniform random policy of the benchmark: Philox POLICY stream, block = player, counter = cycle / 4 (one word per cycle):
+ * command = the two top bits of the word, magnitude = the 15 bits below them, direction = the low 15 bits */
 static void random_actions(const MP *p, uint64_t gid, uint32_t cyc, float *act) {
   for (int i = 0; i < NP; ++i) {
     uint32_t w[4];
-    draw(p->seed, gid, cyc >> 1, ST_POLICY, (uint32_t)i, w);
-    uint32_t w0 = (cyc & 1u) ? w[2] : w[0], w1 = (cyc & 1u) ? w[3] : w[1];
-    int cmd = 1 + (int)(w0 >> 30);
-    REAL u = rnd_u01(w0 << 2), s = rnd_u01(w1) * R(2.0) - R(1.0);
+    draw(p->seed, gid, cyc >> 2, ST_POLICY, (uint32_t)i, w);
+    const uint32_t wd = w[cyc & 3u];
+    int cmd = 1 + (int)(wd >> 30);
+    REAL u = (REAL)((wd >> 15) & 0x7FFFu) * R(3.0517578125e-05), s = (REAL)(wd & 0x7FFFu) * R(6.103515625e-05) - R(1.0);
     REAL a, b = R(0.0);
     if (cmd == S2D_MCMD_DASH || cmd == S2D_MCMD_KICK) { a = u * R(100.0); b = s * R(180.0); }
     else { a = s * R(180.0); }
