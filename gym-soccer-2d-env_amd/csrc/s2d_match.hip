@@ -123,6 +123,7 @@ static_assert(sizeof(MParams) == 4 * (53 + 14 + 6), "a field was added to MParam
 // an LDS load and a wait in the general kernel.  Column 22 (the ball) differs in the size / decay rows; pad lanes (23..31) get the
 // players' values (the LDS table holds zeros there; nothing reads them).  kickable_area2 is the one derived word that is not a
 // constant expression (the host searches the largest float whose root does not exceed the kickable area): the engine's own value.
+template <class T> struct TypesAreConst { static constexpr bool value = false; };
 struct MStockTypes {
   static constexpr float speed_max = (float)1.05, speed_max2 = speed_max * speed_max, stamina_inc = (float)45.0, decay = (float)0.4;
   static constexpr float inertia = (float)5.0, dash_rate = (float)0.006, size = (float)0.3, inv_kick_margin = (float)(1.0 / 0.7);
@@ -144,20 +145,21 @@ struct MStockTypes {
   };
   S2D_DEV Row operator[](int row) const { return Row{row, kickable_area2}; }
 };
+template <> struct TypesAreConst<MStockTypes> { static constexpr bool value = true; };
 
 struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int tackle, catch_ban, card; };
 // Per-match words every cycle reads (registers; the same value in the 32 lanes of the match's half-wave) ...
 struct MGame { int cycle, mode, mode_side, last_touch, offside; float reward; int done, nearest_l, nearest_r;
-               int tick;               /* cycles since the reset, stopped ones included (the Philox counter) */ };
+               int tick;               /* cycles since the reset, stopped ones included (the Philox counter) */
+               int to_half;            /* cycles until the clock reaches the next multiple of half_time_cycles (derived at load: not a
+                                          state word) -- a countdown instead of an integer modulo by a run-time divisor every cycle */ };
 // ... and the ones only events touch (goals, set plays, catches, kicks by the taker, a standing clock): they live in LDS, one row
 // per match, so that they do not occupy registers in a kernel that sits on its 128-VGPR cap (4 resident waves per SIMD).  All
 // 32 lanes of a half read and write the same word with the same value; LDS operations of one wave execute in order.
 struct MRare { int score_l, score_r, timer;
                int holder, moves; /* 1 + index of the goalie holding a caught ball (0 = nobody), his remaining moves */
                int taker, last_kicker; /* 1 + index (0 = nobody): set-play taker not yet followed by another touch; last Kick-command kicker */
-               int stopped;            /* WorldModel.stoped_cycle */
-               int to_half;            /* cycles until the clock reaches the next multiple of half_time_cycles (derived at load: not a
-                                          state word) -- a countdown instead of an integer modulo by a run-time divisor every cycle */ };
+               int stopped;            /* WorldModel.stoped_cycle */ };
 // cycles until `cycle` is the next multiple of h (> 0): the value of the countdown for a clock that reads `cycle`
 S2D_DEV int cycles_to_half(int cycle, int h) {
   const int rem = cycle % h;                             // C remainder: negative for a clock that has wrapped
@@ -224,8 +226,8 @@ template <class P> S2D_DEV void m_recover(const P& p, float effort_max, MObj& o,
 }
 template <class P> S2D_DEV void m_reset(const P& p, float effort_max, MObj& o, MGame& g, MRare& r, int l) {
   o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  g = MGame{0, p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0.0f, 0, 10, 20, 0};
-  r = MRare{0, 0, 0, 0, 0, 0, 0, 0, p.half_time_cycles};
+  g = MGame{0, p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0.0f, 0, 10, 20, 0, p.half_time_cycles};
+  r = MRare{0, 0, 0, 0, 0, 0, 0, 0};
   if (l < NP) m_recover(p, effort_max, o, true);
   m_place(o, l, SIDE_LEFT);
 }
@@ -563,9 +565,27 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   // from the lane's own slot; the sizes are written once per launch (tile_init).  Pad lanes (23 .. 31) compare
   // whatever their slots hold and are masked out at the end.
   bool overlap = false;
-  tile_put(pos, l, o.x, o.y);
-  wave_fence();
-  {
+  // the ball after its move (nothing but a collision moves it again before the referee looks)
+  float bx = hbcast_c<BALL>(o.x, half), by = hbcast_c<BALL>(o.y, half);
+  if constexpr (TypesAreConst<TY>::value) {
+    // One player size: every player-player pair has the same r^2, so the ring keeps the smallest d2 and compares once; the ball
+    // leaves the ring (its slot holds a far-away point for this pass -- the scan below puts the real one back) and every player
+    // tests it directly with the other radius.  Exactly the pairs and comparisons of the general form, ~30 instructions fewer.
+    constexpr float rr_pp = (MStockTypes::size + MStockTypes::size) * (MStockTypes::size + MStockTypes::size);
+    constexpr float r_pb = MStockTypes::size + MStock::ball_size, rr_pb = r_pb * r_pb;
+    tile_put(pos, l, is_ball ? 1.0e9f : o.x, is_ball ? 1.0e9f : o.y);
+    wave_fence();
+    const float4* mine = pos + l;
+    float nearest2 = 1.0e30f;
+#pragma unroll
+    for (int m = 1; m <= 11; ++m) {
+      const float4 pj = mine[m];
+      nearest2 = fminf(nearest2, sq2(o.x - pj.x, o.y - pj.y));
+    }
+    overlap = is_player && (nearest2 < rr_pp || sq2(o.x - bx, o.y - by) < rr_pb);
+  } else {
+    tile_put(pos, l, o.x, o.y);
+    wave_fence();
     const float4* mine = pos + l;
     // d2 < r^2 for some partner  <=>  min over the partners of (d2 - r^2) < 0 (the sign of a float difference is exact): one running
     // minimum instead of eleven compare results gathered bit by bit
@@ -614,8 +634,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
       if (touch_player + 1 != gr.last_kicker) gr.last_kicker = 0;
     }
   }
-  // the ball after its move and the collisions (nothing below moves it before the referee has looked)
-  const float bx = hbcast_c<BALL>(o.x, half), by = hbcast_c<BALL>(o.y, half);
+  if (wave_overlap) { bx = hbcast_c<BALL>(o.x, half); by = hbcast_c<BALL>(o.y, half); }   // ... which may just have happened
   // ---- 4. set play: opponents keep their distance
   if (__ballot(mode0 != S2D_GM_PLAY_ON) != 0ull) {         // wave-uniform
     const float bxn = bx, byn = by;
@@ -642,9 +661,9 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   // skips them (some forty branches that each fall through); the test is the union of the conditions those decisions read.
   const int total_cycles = p.half_time_cycles * p.nr_normal_halfs;
   const bool busy = mode0 != S2D_GM_PLAY_ON || any_kick || caught_by >= 0 || hold_move >= 0 || foul_call != 0 || g.offside != 0 ||
-                    fabsf(bx) > p.half_l || fabsf(by) > p.half_w || g.cycle >= total_cycles || gr.to_half == 1;
+                    fabsf(bx) > p.half_l || fabsf(by) > p.half_w || g.cycle >= total_cycles || g.to_half == 1;
   if (__ballot(busy) == 0ull) {
-    gr.to_half -= 1;                                       // play_on: the clock moved, and not onto a half's end
+    g.to_half -= 1;                                        // play_on: the clock moved, and not onto a half's end
     gr.holder = 0; gr.moves = 0;
   } else {
   float first = -1.0e9f, second = -1.0e9f;      // two largest dirS*x0 among the kicker's opponents
@@ -770,7 +789,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
       g.mode = S2D_GM_TIME_OVER; g.mode_side = SIDE_NONE; g.done = 1; if (g.offside > 0) g.offside = 0; if (is_ball) ev |= EV_FINISHED;
     }
     bool at_half = false;                                  // the clock has just reached a multiple of half_time_cycles
-    if (advanced) { const int left = gr.to_half - 1; at_half = left == 0; gr.to_half = at_half ? p.half_time_cycles : left; }
+    if (advanced) { const int left = g.to_half - 1; at_half = left == 0; g.to_half = at_half ? p.half_time_cycles : left; }
     if (g.mode == S2D_GM_TIME_OVER && g.done) {
     } else if (at_half) {
       int k = g.cycle / p.half_time_cycles;
@@ -879,7 +898,7 @@ S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g, MRare& 
   r.taker = q.env[ME_TAKER * q.env_stride + e]; r.last_kicker = q.env[ME_LAST_KICKER * q.env_stride + e];
   r.stopped = q.env[ME_STOPPED * q.env_stride + e]; g.tick = q.env[ME_TICK * q.env_stride + e];
 }
-template <class P> S2D_DEV void m_derive(const P& p, const MGame& g, MRare& r) { r.to_half = cycles_to_half(g.cycle, p.half_time_cycles); }
+template <class P> S2D_DEV void m_derive(const P& p, MGame& g) { g.to_half = cycles_to_half(g.cycle, p.half_time_cycles); }
 S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGame& g, const MRare& r) {
   if (l < SLOTS) {
     int64_t k = e * SLOTS + l;
@@ -939,7 +958,7 @@ S2D_DEV void match_rollout_body(const P& p, const TY& pt, const MShared& sh, con
   MObj o; MGame g;
   MRare& r = sh.rare[threadIdx.x / kHalf];
   m_load(q, ec, l, o, g, r);
-  m_derive(p, g, r);
+  m_derive(p, g);
   tile_init(sh.pos_tile[threadIdx.x / kHalf], l, pt[PT_SIZE][l]);
   const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)ec;
   const uint32_t gl = (uint32_t)gid, gh = (uint32_t)(gid >> 32);
