@@ -463,12 +463,14 @@ def measure_match(n, dev, rank, T, launches, repeats, stream, settle_ms, noise=F
     # instruction issue, not HBM, bounds this kernel (PMC traffic = 1.02 x algorithmic bytes at 0.1 of the HBM peak): the roofline
     # that says something is wave-instructions per second against the SIMDs' issue peak.  Instructions per wave-cycle come from
     # the committed PMC instruction mix of the same build (profiles/r03/pmc_match_instmix.txt; SQ_INSTS_VALU + SALU + LDS per wave).
-    instr_per_wave_cycle, src = match_instr_per_wave_cycle()
+    instr_per_wave_cycle, src, mix = match_instr_per_wave_cycle()
     waves = -(-n // 2)
     roof = {'bound': 'valu-issue', 'unit': 'G wave-instr/s', 'peak': VALU_PEAK_GINSTR,
             'peak_source': 'profiles/r01/instr_rate_gfx950.txt (1.08 ns per instruction and SIMD at >= 2 waves per SIMD; 1024 SIMDs)',
             'kernel': 's2d_match_rollout_kernel' if mode == 'rollout' else 's2d_match_step_kernel', 'launch_us': ls * 1e6, 'launch_us_events': le * 1e6,
-            'instructions_per_wave_cycle': instr_per_wave_cycle, 'instructions_source': src,
+            'instructions_per_wave_cycle': instr_per_wave_cycle, 'instructions_source': src, 'instruction_mix': mix,
+            # the same work in fewer instructions lowers `achieved` (and `frac`) while `value` rises: read the two together
+            'kernel_variant': eng.kernel_name(),
             'hbm': {'achieved': alg / ls / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg / ls / 1e9 / HBM_PEAK_GBS,
                     'algorithmic_bytes_per_launch': alg, 'algorithmic_bytes_per_env_step': alg / (n * per_launch)}}
     tr, tsrc = load_traffic('match-' + mode, T, n)
@@ -491,10 +493,11 @@ def match_instr_per_wave_cycle():
         if os.path.exists(f):
             try:
                 d = json.load(open(f))
-                return float(d['instructions_per_wave_cycle']), f'profiles/{rnd}/pmc_match_instmix.json'
+                return (float(d['instructions_per_wave_cycle']), f'profiles/{rnd}/pmc_match_instmix.json',
+                        {k: d[k] for k in ('valu', 'salu', 'lds') if k in d})
             except Exception:
                 pass
-    return 1044.0, 'profiles/r01/pmc_match_instmix.txt (625 VALU + 351 SALU + 68 LDS; taken before the round-2 tile rewrite)'
+    return 1044.0, 'profiles/r01/pmc_match_instmix.txt (625 VALU + 351 SALU + 68 LDS; taken before the round-2 tile rewrite)', None
 
 
 class _EnvShim:
