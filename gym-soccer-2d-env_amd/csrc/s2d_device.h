@@ -512,24 +512,25 @@ S2D_DEV float move_sequential(const S2DHot& p, const S2DRare* __restrict__ rp, E
 template <bool NOISE>
 S2D_DEV float sim_move(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, bool accel, float ax, float ay,
                        const NoiseIn& nz) {
-  float d2;
-  if (NOISE) {
-    d2 = move_sequential<true>(p, rp, e, accel, ax, ay, nz);
-  } else {
-    const float vx0 = e.vx, vy0 = e.vy, px0 = e.px, py0 = e.py, bx0 = e.bx, by0 = e.by;
-    const float a2 = sq2(ax, ay);
-    if (accel) { e.vx += ax; e.vy += ay; }
-    const float s2 = sq2(e.vx, e.vy);
-    e.px += e.vx; e.py += e.vy;
-    const float b2 = sq2(e.bvx, e.bvy);
-    e.bx += e.bvx; e.by += e.bvy;
-    d2 = sq2(e.bx - e.px, e.by - e.py);
-    const bool rare = (accel && a2 > p.player_accel_max2) || s2 > p.player_speed_max2 || b2 > p.ball_speed_max2 ||
-                      d2 < p.rsum2;
-    if (rare) {
-      e.vx = vx0; e.vy = vy0; e.px = px0; e.py = py0; e.bx = bx0; e.by = by0;
-      d2 = move_sequential<false>(p, rp, e, accel, ax, ay, nz);
-    }
+  // (with noise the same holds: the clamps test the velocities BEFORE this cycle's noise is added -- a dashing player's 0.4 * v + 0.6
+  // stays below speed_max for any v the noise can leave behind -- so the noisy cycle, too, runs unclamped with one test at the end;
+  // the speeds the noise magnitudes scale with are the roots of the squares the tests need anyway)
+  const float vx0 = e.vx, vy0 = e.vy, px0 = e.px, py0 = e.py, bx0 = e.bx, by0 = e.by, bvx0 = e.bvx, bvy0 = e.bvy;
+  const float a2 = sq2(ax, ay);
+  if (accel) { e.vx += ax; e.vy += ay; }
+  const float s2 = sq2(e.vx, e.vy);
+  if (NOISE) { const float mag = nz.pm * (p.player_rand * sqrt_cr(s2)); e.vx += mag * nz.pc; e.vy += mag * nz.ps; }   // add_noise
+  e.px += e.vx; e.py += e.vy;
+  const float b2 = sq2(e.bvx, e.bvy);
+  if (NOISE) { const float mag = nz.bm * (p.ball_rand * sqrt_cr(b2)); e.bvx += mag * nz.bc; e.bvy += mag * nz.bs; }
+  e.bx += e.bvx; e.by += e.bvy;
+  float d2 = sq2(e.bx - e.px, e.by - e.py);
+  const bool rare = (accel && a2 > p.player_accel_max2) || s2 > p.player_speed_max2 || b2 > p.ball_speed_max2 ||
+                    d2 < p.rsum2;
+  if (rare) {
+    e.vx = vx0; e.vy = vy0; e.px = px0; e.py = py0; e.bx = bx0; e.by = by0;
+    if (NOISE) { e.bvx = bvx0; e.bvy = bvy0; }
+    d2 = move_sequential<NOISE>(p, rp, e, accel, ax, ay, nz);
   }
   return d2;
 }

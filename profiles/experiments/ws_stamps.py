@@ -1,7 +1,7 @@
 """Per-role busy cycles of the four-wave rollout (experiment build with s_memtime stamps, profiles/experiments/ws_stamps.patch):
 cycles between a barrier's release and the wave's arrival at the next one, per iteration, for the record fully written, without
 observations and with no record -- which role is it that the HBM write stream slows down?
-  S2D_LIB=.../stamp.so python profiles/experiments/ws_stamps.py"""
+  S2D_LIB=.../stamp.so python profiles/experiments/ws_stamps.py [--noise]"""
 import ctypes as C
 import os
 import sys
@@ -16,8 +16,9 @@ lib = _capi.load_library()
 lib.s2d_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 dev = torch.device('cuda', 0)
 T, n = 256, 65536
+NOISE = '--noise' in sys.argv
 for record in ('full', 'noobs', 'none'):
-    eng = bench.reach_engine(n, dev, 0, False)
+    eng = bench.reach_engine(n, dev, 0, NOISE)
     bufs = []
     for _ in range(2):
         o = eng.alloc_rollout(T, with_obs=(record == 'full'))
