@@ -689,6 +689,23 @@ def run_reach(args, dev, dist, rank, world):
     return line
 
 
+def box_write_rate(dev, stream, nbytes=1 << 30, reps=8):
+    """What this box's memory system takes from a plain streaming write: torch's fill_ of 1 GiB, GB/s (median of `reps`).  The
+    pool's boxes differ (the same rollout build measured 71-95 G env-steps/s on different ones); this figure travels with the line
+    so that a reader can tell the box from the kernel.  Not a roofline peak: `roofline.peak` stays the 8 TB/s of the data sheet."""
+    import torch
+    buf = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    buf.fill_(1.0); torch.cuda.synchronize()
+    rates = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream); buf.fill_(2.0); e1.record(stream)
+        torch.cuda.synchronize()
+        rates.append(nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del buf
+    return median_of(rates)
+
+
 def secondary_measurements(args, dev, stream, rank, n, T, line, out):
     """More figures of the same run, in the same JSON line: the noise-on rollout (the product's drop-in default) as a
     first-class entry `noise_on`; in `secondary` the one-buffer rollout (what rounds 1-2 reported), the per-step API, BASELINE
@@ -696,6 +713,7 @@ def secondary_measurements(args, dev, stream, rank, n, T, line, out):
     import torch
     R = max(3, min(args.repeats, 5))
     nb = n_rotating(T * n * RECORD_BYTES)
+    line['roofline']['box_fill_gbs'] = box_write_rate(dev, stream)     # see box_write_rate()
     # noise on (rcssserver's stock player_rand / ball_rand), rotating buffers like the headline
     eng = reach_engine(n, dev, rank, True)
     m = measure_rollout(eng, T, 32, nb, R, stream, args.settle_ms)

@@ -82,14 +82,31 @@ S2D_DEV void tile_write(float* tile, const ObsOut& ob, int lane, bool active) {
     for (int k = 0; k < S2D_OBS_DIM; ++k) tile[lane * S2D_OBS_DIM + k] = ob.o[k];
   }
 }
-S2D_DEV void tile_flush(const float* tile, int lane, float* __restrict__ dst, int valid) {
+// Record stores.  A launch whose record does not fit the 256 MiB Infinity Cache streams it out: non-temporal stores (`nt`, a
+// wave-uniform flag the host sets from the record's size) keep those lines from being parked in L2 on their way -- 4 % on the
+// 838 MB record of the headline configuration, steadier from region to region (profiles/r03/ab_store_policy_long.txt); a record
+// that fits (64 cycles x 65 536 envs = 218 MB) keeps the plain stores, which are 3 % faster there.
+typedef float v4f32_t __attribute__((ext_vector_type(4)));
+S2D_DEV void rec_store16(float4* p, const float4& v, bool nt) {
+  if (nt) {
+    const v4f32_t w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(w) : "memory");
+  } else {
+    *p = v;
+  }
+}
+template <typename T>
+S2D_DEV void rec_store(T* p, T v, bool nt) {
+  if (nt) __builtin_nontemporal_store(v, p); else *p = v;
+}
+S2D_DEV void tile_flush(const float* tile, int lane, float* __restrict__ dst, int valid, bool nt = false) {
   const bool vec = (valid == kObsTile) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
   if (vec) {
     const float4* t4 = reinterpret_cast<const float4*>(tile);
     float4* d4 = reinterpret_cast<float4*>(dst);
-    d4[lane] = t4[lane];
-    d4[kWave + lane] = t4[kWave + lane];
-    if (lane < 32) d4[2 * kWave + lane] = t4[2 * kWave + lane];
+    rec_store16(d4 + lane, t4[lane], nt);
+    rec_store16(d4 + kWave + lane, t4[kWave + lane], nt);
+    if (lane < 32) rec_store16(d4 + 2 * kWave + lane, t4[2 * kWave + lane], nt);
   } else {
 #pragma unroll
     for (int j = 0; j < S2D_OBS_DIM; ++j) {
@@ -477,8 +494,10 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
 
 // T fused cycles per launch: the 17 state words stay in registers, only the rollout record
 // (obs 40 B + action 4 B + reward 4 B + done 1 B + result 1 B per env-step) streams out.
+static constexpr int64_t kInfinityCacheBytes = 256ll << 20;   // MI355X
 struct RolloutOut {
   float* obs; void* action; float* reward; uint8_t* done; uint8_t* result;
+  int nt;                                                  // the record is larger than the Infinity Cache: stream it (rec_store)
 };
 
 template <int MODE, bool NOISE>
@@ -716,6 +735,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   __shared__ float2 sc_lut[361];                           //   and (sin, cos) of the whole degrees -180 .. 180
   const int lane = threadIdx.x & (kWave - 1);
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 agent, 3 ball
+  const bool nt = ro.nt != 0;
   const int64_t wave_first = (int64_t)blockIdx.x * kWave;
   const int64_t i = wave_first + lane;
   const bool active = i < n;
@@ -765,7 +785,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         if (lut) {
           if (s == 0 || (k & 3u) == 0u) quad = policy_quad(p, gl, gh, k, S2D_ST_POLICY);
           const int a = (int)rnd_below(quad_word(quad, k), (uint32_t)p.n_actions);
-          if (ro.action) static_cast<int32_t*>(ro.action)[row + i] = a;
+          if (ro.action) rec_store(static_cast<int32_t*>(ro.action) + row + i, (int32_t)a, nt);
           const float4 e4 = act_lut[a];
           c = CmdPrep{e4.x, e4.y, e4.z}; dir = e4.w; cmd = S2D_CMD_DASH;
         } else {
@@ -934,9 +954,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
             for (int k = 0; k < 4; ++k) oa[k] = sl[SL_FIRST + k][lane];
             prev_dist = sl[SL_DIST][lane]; prev_angle = sl[SL_REL][lane];   // reach_ball_env.py:166 carry seeded
           }
-          if (ro.reward) ro.reward[row + i] = reward;
-          if (ro.done) ro.done[row + i] = (uint8_t)done;
-          if (ro.result) ro.result[row + i] = (uint8_t)res;
+          if (ro.reward) rec_store(ro.reward + row + i, reward, nt);
+          if (ro.done) rec_store(ro.done + row + i, (uint8_t)done, nt);
+          if (ro.result) rec_store(ro.result + row + i, (uint8_t)res, nt);
           cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
           if (ro.obs) {                                    // this wave's four words of the row
             float* t = &tile[b][lane * S2D_OBS_DIM];
@@ -969,7 +989,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     __syncthreads();                                       // prepared episodes published
     for (int s = 0; s < n_iter; ++s) {
       if (s >= 3 && ro.obs)                                // observation block of step s - 3, completed in iteration s - 1
-        tile_flush(tile[(s - 1) & 1], lane, ro.obs + ((int64_t)(s - 3) * n + wave_first) * S2D_OBS_DIM, valid);
+        tile_flush(tile[(s - 1) & 1], lane, ro.obs + ((int64_t)(s - 3) * n + wave_first) * S2D_OBS_DIM, valid, nt);
       if (s >= 2 && s < n_steps + 2 && active) {           // step s - 2
         const int b = s & 1;
         float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
@@ -1472,9 +1492,12 @@ S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int a
   int rc = check_action_kind(h, actions_dev, action_kind);
   if (rc != S2D_OK) return rc;
   if (n_steps == 0) return S2D_OK;
-  RolloutOut ro{nullptr, nullptr, nullptr, nullptr, nullptr};
+  RolloutOut ro{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (out) {
-    ro = RolloutOut{out->obs, out->action, out->reward, out->done, out->result};
+    ro = RolloutOut{out->obs, out->action, out->reward, out->done, out->result, 0};
+    const int64_t per_step = (out->obs ? 4 * S2D_OBS_DIM : 0) + (out->action ? (h->mode == S2D_MODE_TURN4 ? 16 : 4) : 0) + (out->reward ? 4 : 0) + (out->done ? 1 : 0) +
+                             (out->result ? 1 : 0);
+    ro.nt = (int64_t)n_steps * h->n * per_step > kInfinityCacheBytes;
     if (h->cfg.task.use_continuous_action && h->cfg.task.use_turning && (reinterpret_cast<uintptr_t>(out->action) & 15u))
       return fail(S2D_EINVAL, "rollout action buffer float[T][N][4] must be 16-byte aligned");
     if (reinterpret_cast<uintptr_t>(out->obs) & 3u) return fail(S2D_EINVAL, "rollout obs buffer must be 4-byte aligned");
