@@ -711,6 +711,13 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
       if (gr.timer >= p.announce_wait) {
         g.mode = (mode0 == S2D_GM_BACK_PASS || mode0 == S2D_GM_FREE_KICK_FAULT) ? S2D_GM_IND_FREE_KICK : S2D_GM_FREE_KICK;
         g.mode_side = other_side(side0); gr.timer = 0;
+        // PenaltyKick_ (idl/service.proto:278): the foul was called inside the offender's own penalty area -- the other side restarts
+        // from the penalty spot of that half (11 m from the goal line: a constant of the pitch, like rcssserver's) instead of the foul's
+        const bool own_area = fabsf(by) <= p.pen_half_w && (side0 == SIDE_LEFT ? bx <= -p.pen_x : bx >= p.pen_x);
+        if (mode0 == S2D_GM_FOUL_CHARGE && own_area) {
+          g.mode = S2D_GM_PENALTY_KICK; g.offside = 0;
+          place_ball = true; pbx = (side0 == SIDE_LEFT ? -1.0f : 1.0f) * (p.half_l - 11.0f); pby = 0.0f;
+        }
       }
     } else if (is_setplay(mode0)) {
       if (any_kick) { g.mode = S2D_GM_PLAY_ON; gr.timer = 0; }

@@ -9,6 +9,7 @@ MATCH_PLAYER_TYPES, GOALIE_LEFT, GOALIE_RIGHT = 18, 0, 11
 GM_TIME_OVER, GM_PLAY_ON, GM_KICK_OFF, GM_KICK_IN, GM_FREE_KICK, GM_CORNER_KICK, GM_GOAL_KICK, GM_AFTER_GOAL, GM_OFF_SIDE = 1, 2, 3, 4, 5, 6, 7, 8, 9
 GM_BEFORE_KICK_OFF, GM_BACK_PASS, GM_FREE_KICK_FAULT = 0, 18, 19          # idl/service.proto:268, 286-287
 GM_FIRST_HALF_OVER, GM_FOUL_CHARGE, GM_CATCH_FAULT, GM_IND_FREE_KICK, GM_GOALIE_CATCH = 11, 14, 20, 21, 30   # :279, 282, 288-289, 298
+GM_PENALTY_KICK = 10                                   # :278 (a foul inside the offender's own penalty area; the shoot-out modes are not built)
 GM_NAMES = {0: 'BeforeKickOff', 1: 'TimeOver', 2: 'PlayOn', 3: 'KickOff_', 4: 'KickIn_', 5: 'FreeKick_', 6: 'CornerKick_', 7: 'GoalKick_',
             8: 'AfterGoal_', 9: 'OffSide_', 11: 'FirstHalfOver', 14: 'FoulCharge_', 18: 'BackPass_', 19: 'FreeKickFault_',
             20: 'CatchFault_', 21: 'IndFreeKick_', 30: 'GoalieCatch_'}

@@ -36,14 +36,15 @@ extern "C" {
 enum { S2D_MCMD_NONE = 0, S2D_MCMD_DASH = 1, S2D_MCMD_TURN = 2, S2D_MCMD_KICK = 3, S2D_MCMD_TACKLE = 4,
        S2D_MCMD_CATCH = 5, S2D_MCMD_MOVE = 6 };
 /* GameModeType values used (idl/service.proto:267-301).  mode_side: for the restarts (KickOff_, KickIn_, FreeKick_, CornerKick_,
- * GoalKick_, IndFreeKick_, GoalieCatch_) the side that takes it; for the ANNOUNCEMENTS (AfterGoal_, OffSide_, BackPass_,
+ * GoalKick_, IndFreeKick_, GoalieCatch_, PenaltyKick_ -- a FoulCharge_ called inside the offender's own penalty area, restarted from
+ * that half's penalty spot) the side that takes it; for the ANNOUNCEMENTS (AfterGoal_, OffSide_, BackPass_,
  * FreeKickFault_, CatchFault_, FoulCharge_: rcssserver's goal_l, offside_l, back_pass_l, ...) the side the call is named after --
  * the scorer, the offender.  An announcement is a dead ball with the clock stopped; after announce_wait (after_goal_wait) cycles
  * the referee turns it into the restart for the other side. */
 enum {
   S2D_GM_BEFORE_KICK_OFF = 0, S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4,
   S2D_GM_FREE_KICK = 5, S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_AFTER_GOAL = 8, S2D_GM_OFF_SIDE = 9,
-  S2D_GM_FIRST_HALF_OVER = 11, S2D_GM_FOUL_CHARGE = 14, S2D_GM_BACK_PASS = 18, S2D_GM_FREE_KICK_FAULT = 19,
+  S2D_GM_PENALTY_KICK = 10, S2D_GM_FIRST_HALF_OVER = 11, S2D_GM_FOUL_CHARGE = 14, S2D_GM_BACK_PASS = 18, S2D_GM_FREE_KICK_FAULT = 19,
   S2D_GM_CATCH_FAULT = 20, S2D_GM_IND_FREE_KICK = 21, S2D_GM_GOALIE_CATCH = 30
 };
 /* cards (rcssserver's yellow_card / red_card referee messages; no field of the proto's Player carries them) */

@@ -526,6 +526,11 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
       if (m->setplay_timer >= p->announce_wait) {
         m->mode = (mode0 == S2D_GM_BACK_PASS || mode0 == S2D_GM_FREE_KICK_FAULT) ? S2D_GM_IND_FREE_KICK : S2D_GM_FREE_KICK;
         m->mode_side = other_side(side0); m->setplay_timer = 0;
+        /* PenaltyKick_ (idl/service.proto:278): a foul called inside the offender's own penalty area is restarted from the penalty
+         * spot of that half, 11 m from the goal line (a constant of the pitch in rcssserver too), by the other side */
+        const int own_area = R(fabs)(b->y) <= p->pen_half_w && (side0 == SIDE_LEFT ? b->x <= -p->pen_x : b->x >= p->pen_x);
+        if (mode0 == S2D_GM_FOUL_CHARGE && own_area)
+          restart(m, S2D_GM_PENALTY_KICK, other_side(side0), (side0 == SIDE_LEFT ? R(-1.0) : R(1.0)) * (p->half_l - R(11.0)), R(0.0));
       }
     } else if (is_setplay(mode0)) {
       if (any_kick) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; }

@@ -583,3 +583,53 @@ def test_stock_and_general_kernels_agree(monkeypatch):
     # a changed rule word selects the general kernel by itself
     c = MatchEngine(8, 'cuda:0', cfg=make_match_config(half_time_cycles=100))
     assert c.kernel_name().endswith('<general>')
+
+
+@pytest.mark.parametrize('stock', [True, False])
+def test_penalty_kick_on_device(stock):
+    """PenaltyKick_: a seen intentional foul inside the offender's own penalty area -> FoulCharge_ -> the other side restarts from the
+    penalty spot; device == oracle after every cycle, in the stock instantiation (default rules: 30-cycle announcement, referee
+    sees every second foul) and in the general one."""
+    from soccer2d_amd._capi_match import GM_FOUL_CHARGE, GM_PENALTY_KICK, GM_PLAY_ON, MCMD_KICK, MCMD_TACKLE
+    n = 16
+    kw = {} if stock else dict(announce_wait=5, foul_detect_probability=1.0)
+    eng, orc = _pair(n, auto_reset=0, noise=stock, **kw)             # (noise: 16 different tackle / referee draws in the stock run)
+    assert eng.kernel_name().endswith('<stock, stock types>' if stock else '<general>')
+
+    def both(a):
+        eng.step(torch.as_tensor(a, device='cuda:0')); orc.step(a)
+        assert_match_same(eng, orc, 'penalty kick')
+
+    def acts(**pp):
+        a = np.zeros((n, 22, 3), dtype=np.float32)
+        for k, v in pp.items():
+            a[:, int(k[1:])] = v
+        return a
+
+    def put(slot, **kw):
+        for e in range(n):
+            orc.set_obj(e, slot, **kw)
+            eng.catch_ban[e, slot] = 0
+            for k, v in kw.items():
+                getattr(eng, k)[e, slot] = v
+    for e in range(n):
+        orc.set_game(e, mode=GM_PLAY_ON, mode_side=0); eng.mode[e] = GM_PLAY_ON; eng.mode_side[e] = 0
+    put(16, x=48.0, y=-2.0, body=180.0)                              # right #6 inside the right penalty area, facing -x ...
+    put(9, x=47.0, y=-2.2, body=0.0); put(22, x=47.3, y=-2.1, vx=0.0, vy=0.0)   # ... a left forward on the ball 1 m in front of him
+    put(13, x=43.0, y=1.0)                                           # a right defender 1.8 m from the penalty spot
+    both(acts(p16=[MCMD_TACKLE, 0, 1]))
+    called = orc.get('mode') == GM_FOUL_CHARGE
+    assert called.any() and (orc.get('mode_side')[called] == 2).all()
+    for _ in range(30 if stock else 5):
+        both(acts())
+    mode = orc.get('mode')
+    assert (mode[called] == GM_PENALTY_KICK).all() and (orc.get('mode_side')[called] == 1).all()
+    assert (orc.get('x')[called, 22] == 41.5).all() and (orc.get('y')[called, 22] == 0.0).all()
+    both(acts())
+    x, y = eng.x.cpu().numpy(), eng.y.cpu().numpy()
+    assert (np.hypot(x[called, 11:22] - 41.5, y[called, 11:22]).min(axis=1) >= 9.15 - 1e-4).all()   # the defenders keep their distance
+    put(9, x=41.0, y=0.0, body=0.0)
+    both(acts(p9=[MCMD_KICK, 70, 0]))
+    assert (orc.get('mode')[called] == GM_PLAY_ON).all() and (eng.vx.cpu().numpy()[called, 22] > 0).all()
+    for _ in range(10):
+        both(acts())

@@ -540,3 +540,40 @@ def test_intentional_foul_brings_the_victim_down_and_may_be_carded():
     for _ in range(100):
         m.step(acts(p5=[MCMD_DASH, 100, 0]))
     assert m.get('x')[0][5] == 0.0 and m.get('y')[0][5] == pytest.approx(-(34.0 + 6.0 + 1.5 * 5)) and m.get('cycle')[0] >= 50   # through half time
+
+
+def test_foul_inside_the_own_penalty_area_is_a_penalty_kick():
+    """PenaltyKick_ (idl/service.proto:278): FoulCharge_ called with the ball inside the offender's own penalty area -> after the
+    announcement the other side restarts from the penalty spot of that half (11 m from the goal line), defenders cleared
+    free_kick_distance from it; a kick by the taker's side puts the ball into play.  Outside the area: FreeKick_ where it happened."""
+    from soccer2d_amd._capi_match import GM_FOUL_CHARGE, GM_FREE_KICK, GM_PENALTY_KICK
+    seen = 0
+    for seed in range(12):
+        m = fresh(seed=seed, foul_detect_probability=1.0); play_on(m)
+        m.set_obj(0, 5, x=-45.0, y=3.0, body=0.0)            # left #6 inside his own penalty area, facing +x
+        m.set_obj(0, 15, x=-44.0, y=3.2, body=180.0)         # a right forward 1 m in front of him, the ball at his feet
+        m.set_obj(0, 22, x=-44.3, y=3.1, vx=0.0, vy=0.0)
+        m.set_obj(0, 2, x=-40.0, y=1.0)                      # a left defender who stands 1.8 m from the penalty spot
+        m.step(acts(p5=[MCMD_TACKLE, 0, 1]))
+        if m.get('mode')[0] != GM_FOUL_CHARGE:               # the tackle itself failed
+            continue
+        seen += 1
+        assert m.get('mode_side')[0] == LEFT
+        for _ in range(30):
+            m.step(acts())
+        assert m.get('mode')[0] == GM_PENALTY_KICK and m.get('mode_side')[0] == RIGHT
+        assert m.get('x')[0][22] == -41.5 and m.get('y')[0][22] == 0.0 and m.get('vx')[0][22] == 0.0
+        m.step(acts())                                       # the kept-away side (left) is cleared from the spot
+        d = np.hypot(m.get('x')[0][:11] + 41.5, m.get('y')[0][:11])
+        assert d.min() >= 9.15 - 1e-4
+        m.set_obj(0, 15, x=-41.0, y=0.0, body=180.0)         # the fouled forward takes it
+        m.step(acts(p15=[MCMD_KICK, 60, 0]))
+        assert m.get('mode')[0] == GM_PLAY_ON and m.get('vx')[0][22] < 0
+    assert seen >= 6
+    # the same foul at midfield stays a free kick where it happened
+    m = _foul_scene(foul_detect_probability=1.0)
+    m.step(acts(p5=[MCMD_TACKLE, 0, 1]))
+    if m.get('mode')[0] == GM_FOUL_CHARGE:
+        for _ in range(30):
+            m.step(acts())
+        assert m.get("mode")[0] == GM_FREE_KICK and abs(m.get("x")[0][22]) < 8.0
