@@ -153,11 +153,13 @@ struct MObj { float x, y, vx, vy, body, stamina, effort, recovery, capacity; int
 struct MGame { int cycle, mode, mode_side, last_touch, offside; float reward; int done, nearest_l, nearest_r;
                int tick;               /* cycles since the reset, stopped ones included (the Philox counter) */
                int to_half;            /* cycles until the clock reaches the next multiple of half_time_cycles (derived at load: not a
-                                          state word) -- a countdown instead of an integer modulo by a run-time divisor every cycle */ };
+                                          state word) -- a countdown instead of an integer modulo by a run-time divisor every cycle */
+               int timer;              /* set-play / dead-ball timer: read and counted in every cycle of a waiting match, whose wave
+                                          is the one the launch waits for -- a register, not an LDS round trip */ };
 // ... and the ones only events touch (goals, set plays, catches, kicks by the taker, a standing clock): they live in LDS, one row
 // per match, so that they do not occupy registers in a kernel that sits on its 128-VGPR cap (4 resident waves per SIMD).  All
 // 32 lanes of a half read and write the same word with the same value; LDS operations of one wave execute in order.
-struct MRare { int score_l, score_r, timer;
+struct MRare { int score_l, score_r;
                int holder, moves; /* 1 + index of the goalie holding a caught ball (0 = nobody), his remaining moves */
                int taker, last_kicker; /* 1 + index (0 = nobody): set-play taker not yet followed by another touch; last Kick-command kicker */
                int stopped;            /* WorldModel.stoped_cycle */ };
@@ -227,8 +229,8 @@ template <class P> S2D_DEV void m_recover(const P& p, float effort_max, MObj& o,
 }
 template <class P> S2D_DEV void m_reset(const P& p, float effort_max, MObj& o, MGame& g, MRare& r, int l) {
   o = MObj{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  g = MGame{0, p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0.0f, 0, 10, 20, 0, p.half_time_cycles};
-  r = MRare{0, 0, 0, 0, 0, 0, 0, 0};
+  g = MGame{0, p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF, SIDE_LEFT, 0, 0, 0.0f, 0, 10, 20, 0, p.half_time_cycles, 0};
+  r = MRare{0, 0, 0, 0, 0, 0, 0};
   if (l < NP) m_recover(p, effort_max, o, true);
   m_place(o, l, SIDE_LEFT);
 }
@@ -685,13 +687,13 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     } else {                                               // the value the timer has to stay below after this cycle's increment
       const int limit = !ball_dead(mode0) ? p.drop_ball_time + 1 : mode0 == S2D_GM_AFTER_GOAL ? p.after_goal_wait :
                         is_announcement(mode0) ? p.announce_wait : mode0 == S2D_GM_BEFORE_KICK_OFF ? p.kick_off_wait : 0;
-      idle = gr.timer + 1 < limit;
+      idle = g.timer + 1 < limit;
     }
   }
   const bool busy = !(calm && idle);
   if (__ballot(busy) == 0ull) {
     if (advanced) g.to_half -= 1;                          // the clock moved, and not onto a half's end
-    if (mode0 != S2D_GM_PLAY_ON && mode0 != S2D_GM_TIME_OVER) gr.timer += 1;
+    if (mode0 != S2D_GM_PLAY_ON && mode0 != S2D_GM_TIME_OVER) g.timer += 1;
     if (mode0 != S2D_GM_TIME_OVER && mode0 != S2D_GM_FREE_KICK) { gr.holder = 0; gr.moves = 0; }
   } else {
   float first = -1.0e9f, second = -1.0e9f;      // two largest dirS*x0 among the kicker's opponents
@@ -709,25 +711,25 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   bool recover_half = false;
   if (mode0 != S2D_GM_TIME_OVER) {
     if (mode0 == S2D_GM_AFTER_GOAL) {                      // dead ball until the wait is over, then the conceding side kicks off
-      gr.timer += 1;
-      if (gr.timer >= p.after_goal_wait) {
+      g.timer += 1;
+      if (g.timer >= p.after_goal_wait) {
         const int ks = other_side(side0);
         restart_form = true; form_side = ks;
-        g.mode = S2D_GM_KICK_OFF; g.mode_side = ks; gr.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        g.mode = S2D_GM_KICK_OFF; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
         gr.taker = 0; gr.last_kicker = 0;
       }
     } else if (mode0 == S2D_GM_BEFORE_KICK_OFF) {          // nobody plays the ball, players may Move
-      gr.timer += 1;
-      if (gr.timer >= p.kick_off_wait) { g.mode = S2D_GM_KICK_OFF; gr.timer = 0; }
+      g.timer += 1;
+      if (g.timer >= p.kick_off_wait) { g.mode = S2D_GM_KICK_OFF; g.timer = 0; }
     } else if (mode0 == S2D_GM_FIRST_HALF_OVER) {          // one cycle of "half time", then the next half's kick-off
-      g.mode = p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF; gr.timer = 0;
+      g.mode = p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF; g.timer = 0;
     } else if (mode0 == S2D_GM_GOALIE_CATCH) {             // one cycle of "goalie_catch_ball", then his free kick
-      g.mode = S2D_GM_FREE_KICK; gr.timer = 0;
+      g.mode = S2D_GM_FREE_KICK; g.timer = 0;
     } else if (is_announcement(mode0)) {                   // offside_l, back_pass_l, ...: after the wait, the restart for the other side
-      gr.timer += 1;
-      if (gr.timer >= p.announce_wait) {
+      g.timer += 1;
+      if (g.timer >= p.announce_wait) {
         g.mode = (mode0 == S2D_GM_BACK_PASS || mode0 == S2D_GM_FREE_KICK_FAULT) ? S2D_GM_IND_FREE_KICK : S2D_GM_FREE_KICK;
-        g.mode_side = other_side(side0); gr.timer = 0;
+        g.mode_side = other_side(side0); g.timer = 0;
         // PenaltyKick_ (idl/service.proto:278): the foul was called inside the offender's own penalty area -- the other side restarts
         // from the penalty spot of that half (11 m from the goal line: a constant of the pitch, like rcssserver's) instead of the foul's
         const bool own_area = fabsf(by) <= p.pen_half_w && (side0 == SIDE_LEFT ? bx <= -p.pen_x : bx >= p.pen_x);
@@ -737,8 +739,8 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
         }
       }
     } else if (is_setplay(mode0)) {
-      if (any_kick) { g.mode = S2D_GM_PLAY_ON; gr.timer = 0; }
-      else { gr.timer += 1; if (gr.timer > p.drop_ball_time) { g.mode = S2D_GM_PLAY_ON; gr.timer = 0; } }
+      if (any_kick) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; }
+      else { g.timer += 1; if (g.timer > p.drop_ball_time) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; } }
     }
     // offside candidates: each lane tests itself, the mask is assembled by ballot
     float line = 0.0f;
@@ -765,7 +767,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
         // outside: catch fault
         const int lk = gr.last_kicker - 1;
         const bool back_pass = p.back_passes && in_area && lk >= 0 && lk != caught_by && side_of(lk) == gs;
-        place_ball = true; gr.timer = 0; g.offside = 0; gr.taker = 0; gr.last_kicker = 0;
+        place_ball = true; g.timer = 0; g.offside = 0; gr.taker = 0; gr.last_kicker = 0;
         if (back_pass) {                                    // back_pass_l / _r: named after the offending side
           pbx = gs == SIDE_LEFT ? -p.pen_x : p.pen_x; pby = by > 0.0f ? p.pen_half_w : -p.pen_half_w;
           g.mode = S2D_GM_BACK_PASS; g.mode_side = gs;
@@ -776,26 +778,26 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
         }
       } else if (foul_call != 0) {                          // the referee saw the foul: FoulCharge_ where the ball is
         place_ball = true; pbx = clampf(bx, -p.half_l, p.half_l); pby = clampf(by, -p.half_w, p.half_w);
-        g.mode = S2D_GM_FOUL_CHARGE; g.mode_side = side_of(foul_call - 1); gr.timer = 0; g.offside = 0;
+        g.mode = S2D_GM_FOUL_CHARGE; g.mode_side = side_of(foul_call - 1); g.timer = 0; g.offside = 0;
       } else if (fk_fault) {                                // the taker touched the ball twice
         place_ball = true; pbx = clampf(bx, -p.half_l, p.half_l); pby = clampf(by, -p.half_w, p.half_w);
-        g.mode = S2D_GM_FREE_KICK_FAULT; g.mode_side = side_of(taker0 - 1); gr.timer = 0; g.offside = 0;
+        g.mode = S2D_GM_FREE_KICK_FAULT; g.mode_side = side_of(taker0 - 1); g.timer = 0; g.offside = 0;
         gr.taker = 0; gr.last_kicker = 0;
       } else if (bx > p.half_l && fabsf(by) < p.goal_half_width) {
         gr.score_l += 1; g.reward = 1.0f; if (is_ball) ev |= EV_GOAL_L;
-        gr.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
         if (p.after_goal_wait > 0) { place_ball = true; pbx = bx; pby = by; g.mode = S2D_GM_AFTER_GOAL; g.mode_side = SIDE_LEFT; }
         else { restart_form = true; form_side = SIDE_RIGHT; g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_RIGHT; }
       } else if (bx < -p.half_l && fabsf(by) < p.goal_half_width) {
         gr.score_r += 1; g.reward = -1.0f; if (is_ball) ev |= EV_GOAL_R;
-        gr.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+        g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
         if (p.after_goal_wait > 0) { place_ball = true; pbx = bx; pby = by; g.mode = S2D_GM_AFTER_GOAL; g.mode_side = SIDE_RIGHT; }
         else { restart_form = true; form_side = SIDE_LEFT; g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_LEFT; }
       } else if (fabsf(bx) > p.half_l || fabsf(by) > p.half_w) {
         if (is_ball) ev |= EV_OUT;
         int toucher = g.last_touch == SIDE_NONE ? SIDE_LEFT : g.last_touch;
         float sy = by < 0.0f ? -1.0f : 1.0f, sxn = bx < 0.0f ? -1.0f : 1.0f;
-        place_ball = true; gr.timer = 0; g.offside = 0;
+        place_ball = true; g.timer = 0; g.offside = 0;
         if (fabsf(bx) <= p.half_l) {
           g.mode = S2D_GM_KICK_IN; g.mode_side = other_side(toucher);
           pbx = clampf(bx, -p.half_l, p.half_l); pby = sy * p.half_w;
@@ -815,7 +817,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
           int t = __ffs((int)hit) - 1;            // first flagged player in index order
           if (is_ball) ev |= EV_OFFSIDE;
           place_ball = true; pbx = 0.0f; pby = 0.0f;   // coordinates fetched below (needs a shuffle)
-          g.mode = S2D_GM_OFF_SIDE; g.mode_side = side_of(t); gr.timer = 0;          // offside_l / _r: named after the offender
+          g.mode = S2D_GM_OFF_SIDE; g.mode_side = side_of(t); g.timer = 0;          // offside_l / _r: named after the offender
           g.offside = -1 - t;                       // marker: ball goes to player t (resolved below)
         }
       }
@@ -830,7 +832,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
       int k = g.cycle / p.half_time_cycles;
       int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
       recover_half = true; restart_form = true; form_side = ks; place_ball = false;
-      g.mode = S2D_GM_FIRST_HALF_OVER; g.mode_side = ks; gr.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+      g.mode = S2D_GM_FIRST_HALF_OVER; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
     }
     if (place_ball || restart_form) { gr.taker = 0; gr.last_kicker = 0; }   // every restart ends the double-touch / back-pass bookkeeping
     if (g.mode != S2D_GM_FREE_KICK && g.mode != S2D_GM_GOALIE_CATCH) { gr.holder = 0; gr.moves = 0; }   // nobody holds the ball any more
@@ -929,7 +931,7 @@ S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g, MRare& 
   g.cycle = q.env[ME_CYCLE * q.env_stride + e]; g.mode = q.env[ME_MODE * q.env_stride + e];
   g.mode_side = q.env[ME_MODE_SIDE * q.env_stride + e]; r.score_l = q.env[ME_SCORE_L * q.env_stride + e];
   r.score_r = q.env[ME_SCORE_R * q.env_stride + e]; g.last_touch = q.env[ME_LAST_TOUCH * q.env_stride + e];
-  r.timer = q.env[ME_TIMER * q.env_stride + e]; g.offside = q.env[ME_OFFSIDE * q.env_stride + e];
+  g.timer = q.env[ME_TIMER * q.env_stride + e]; g.offside = q.env[ME_OFFSIDE * q.env_stride + e];
   g.reward = 0.0f; g.done = 0; g.nearest_l = 0; g.nearest_r = 0;        // outputs: match_nearest() after the launch's last cycle
   r.holder = q.env[ME_HOLDER * q.env_stride + e]; r.moves = q.env[ME_MOVES * q.env_stride + e];
   r.taker = q.env[ME_TAKER * q.env_stride + e]; r.last_kicker = q.env[ME_LAST_KICKER * q.env_stride + e];
@@ -952,7 +954,7 @@ S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGam
     q.env[ME_CYCLE * q.env_stride + e] = g.cycle; q.env[ME_MODE * q.env_stride + e] = g.mode;
     q.env[ME_MODE_SIDE * q.env_stride + e] = g.mode_side; q.env[ME_SCORE_L * q.env_stride + e] = r.score_l;
     q.env[ME_SCORE_R * q.env_stride + e] = r.score_r; q.env[ME_LAST_TOUCH * q.env_stride + e] = g.last_touch;
-    q.env[ME_TIMER * q.env_stride + e] = r.timer; q.env[ME_OFFSIDE * q.env_stride + e] = g.offside;
+    q.env[ME_TIMER * q.env_stride + e] = g.timer; q.env[ME_OFFSIDE * q.env_stride + e] = g.offside;
     q.env[ME_NEAREST_L * q.env_stride + e] = g.nearest_l; q.env[ME_NEAREST_R * q.env_stride + e] = g.nearest_r;
     q.env[ME_HOLDER * q.env_stride + e] = r.holder; q.env[ME_MOVES * q.env_stride + e] = r.moves;
     q.env[ME_TAKER * q.env_stride + e] = r.taker; q.env[ME_LAST_KICKER * q.env_stride + e] = r.last_kicker;
