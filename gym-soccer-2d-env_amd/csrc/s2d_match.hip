@@ -467,20 +467,22 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     if (p.noise) m_noise(o.vx, o.vy, p.player_rand, rnd_u01(nz.x), rnd_u01(nz.y));
     o.x += o.vx; o.y += o.vy;
   }
-  // Two copies of the rest of the cycle.  In most cycles nothing was caught, moved by hand, fouled or kicked, the mode is play_on and
-  // no offside flag is up; the copy for those cycles has these facts as constants, so the event blocks below and every later test
-  // on them fold away instead of being evaluated and skipped.  The wave takes the general copy as soon as one of its two matches
-  // needs it.
+  // Three copies of the rest of the cycle.  In most cycles nothing was caught, moved by hand, fouled or kicked (CALM), and mostly the
+  // mode is play_on with no offside flag up as well (PLAY); the copies for those cycles have these facts as constants, so the event
+  // blocks below and every later test on them fold away instead of being evaluated and skipped.  CALM without PLAY is the copy of
+  // the WAITING matches (a set play not yet taken, a dead ball's countdown): their waves are the ones a launch waits for, so their
+  // cycle has to be as short as a quiet one.  A wave takes the most general copy one of its two matches needs.
   const int mode_start = mode0;
-  const bool eventful = __ballot(caught || hold_moved || foul_try || kicked || mode0 != S2D_GM_PLAY_ON || g.offside != 0) != 0ull;
-  auto rest_of_cycle = [&](auto plain_tag) {
-  constexpr bool Q = decltype(plain_tag)::value;
-  const int mode0 = Q ? (int)S2D_GM_PLAY_ON : mode_start;
-  if (Q) g.offside = 0;                                    // (it is)
+  const bool cmd_events = __ballot(caught || hold_moved || foul_try || kicked) != 0ull;
+  const bool mode_events = __ballot(mode0 != S2D_GM_PLAY_ON || g.offside != 0) != 0ull;
+  auto rest_of_cycle = [&](auto calm_tag, auto play_tag) {
+  constexpr bool CALM = decltype(calm_tag)::value, PLAY = decltype(play_tag)::value;
+  const int mode0 = PLAY ? (int)S2D_GM_PLAY_ON : mode_start;
+  if (PLAY) g.offside = 0;                                 // (it is)
   // a successful catch wins the cycle: every kick / tackle impulse of this cycle is dropped
   // ... and so does a move of the goalie who holds the ball (the holder is a goalie: bits 0 / 11)
   int caught_by = -1, hold_move = -1;
-  if (!Q && __ballot(caught || hold_moved) != 0ull) {      // wave-uniform, rare
+  if (!CALM && __ballot(caught || hold_moved) != 0ull) {   // wave-uniform, rare
     const uint32_t goalies = (1u << S2D_MATCH_GOALIE_LEFT) | (1u << S2D_MATCH_GOALIE_RIGHT);
     const uint32_t cmask = hballot(caught, half) & goalies, hmask = hballot(hold_moved, half) & goalies;
     caught_by = cmask ? __ffs((int)cmask) - 1 : -1;
@@ -492,7 +494,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   // tackler's tackle area brings him down for foul_cycles; the referee sees it with foul_detect_probability.  Positions of the
   // start of the cycle; the first such tackler (lowest index) counts.  Wave-uniform and rare: only tackles with foul set get here.
   int foul_call = 0;                                       // 1 + tackler if the referee saw a foul, else 0
-  if (!Q && __ballot(foul_try) != 0ull) {
+  if (!CALM && __ballot(foul_try) != 0ull) {
     const bool has_ball = is_player && o.card < S2D_CARD_RED && sq2(bx0 - x0, by0 - y0) <= pt[PT_KICKABLE_AREA2][l];
     const uint32_t hb = hballot(has_ball, half) & 0x3FFFFFu;
     float sn, cs;
@@ -520,7 +522,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   float bax = 0.0f, bay = 0.0f;
   bool any_kick = false, fk_fault = false;
   int last_kicker = -1, taker0 = 0;
-  const bool wave_kick = !Q && __ballot(kicked) != 0ull;    // wave-uniform: kicks are rare events
+  const bool wave_kick = !CALM && __ballot(kicked) != 0ull; // wave-uniform: kicks are rare events
   if (wave_kick) {
     const uint32_t kmask = hballot(kicked, half) & 0x3FFFFFu;
     any_kick = kmask != 0u;
@@ -681,7 +683,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   const bool calm = !(any_kick || caught_by >= 0 || hold_move >= 0 || foul_call != 0) && g.offside == 0 &&
                     !(advanced && (g.cycle >= total_cycles || g.to_half == 1));
   bool idle = mode0 == S2D_GM_PLAY_ON && fabsf(bx) <= p.half_l && fabsf(by) <= p.half_w;   // play goes on, the ball is on the pitch
-  if (!Q && mode0 != S2D_GM_PLAY_ON) {
+  if (!PLAY && mode0 != S2D_GM_PLAY_ON) {
     if (mode0 == S2D_GM_TIME_OVER) {
       idle = true;
     } else {                                               // the value the timer has to stay below after this cycle's increment
@@ -856,7 +858,9 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     o.vx = 0.0f; o.vy = 0.0f;
   }
   };
-  if (eventful) rest_of_cycle(std::false_type{}); else rest_of_cycle(std::true_type{});
+  if (cmd_events) rest_of_cycle(std::false_type{}, std::false_type{});
+  else if (mode_events) rest_of_cycle(std::true_type{}, std::false_type{});
+  else rest_of_cycle(std::true_type{}, std::true_type{});
   // ---- 6. decay, tackle timers, stamina
   if (l <= BALL) { const float decay = pt[PT_DECAY][l]; o.vx *= decay; o.vy *= decay; }   // column 22 = ball_decay
   if (is_player) {
