@@ -1025,7 +1025,21 @@ S2D_DEV void match_rollout_body(const P& p, const TY& pt, const MShared& sh, con
   const bool obs_lane = (int)lane < (e0 + 1 < n ? 2 * kVecPerMatch : (e0 < n ? kVecPerMatch : 0));
   float* const obs_slot = sh.obs_tile[threadIdx.x >> 6] + (half * SLOTS + l) * S2D_MATCH_OBJ_WORDS;
   const float4* const obs_vec = reinterpret_cast<const float4*>(sh.obs_tile[threadIdx.x >> 6]) + lane;
+  // Fair shares of the SIMD.  Among waves of equal priority the issue arbiter prefers the OLDEST: of the four waves a SIMD holds,
+  // the first one dispatched ran its 64 cycles in 322 k clocks, the fourth in 470 k (profiles/r03/match_wave_durations.txt) -- same
+  // work, and the launch waits for the fourth.  The waves therefore take turns at the four priority levels, a new turn every four
+  // cycles, starting from their slot number on the SIMD (HW_ID.wave_id): at any time the four hold four different levels, and over
+  // a launch every wave spends the same time at each.
+  const int simd_slot = (int)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);   // HW_REG_HW_ID bits 3:0
   for (int t = 0; t < n_steps; ++t) {
+    if ((t & 3) == 0) {
+      switch ((simd_slot + (t >> 2)) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
     // Everything that depends only on the lane number -- masks such as "is a player", "is the ball", bit positions, Philox block
     // words -- is loop-invariant, and the compiler computes it all once per launch and keeps it: ~90 scalar and ~20 vector
     // registers more than there are, spilled and reloaded inside the loop.  One instruction each to recompute: opaque copies of
