@@ -672,7 +672,13 @@ static constexpr int kSlots = 3;
 // the longest chain (2/1/1/0); with the dash-only fast path it is the observing waves that have none left -- steady clocks,
 // 65 536 envs x 64 cycles, us per launch, simulate/agent/ball/policy (profiles/r02/ab_prio.txt): 0/0/0/0 51.2, 2/1/1/0 47.9,
 // 1/1/1/0 48.2, 2/2/2/0 48.2, 2/2/1/0 48.0, 3/2/1/0 47.8, 1/2/2/0 46.7; second box: 1/2/2/0 45.9, 1/3/2/0 45.6, 1/2/3/0 46.0,
-// 0/2/2/0 46.8, 1/3/3/0 46.2, 0/1/1/0 46.7, 2/3/3/0 46.0 (noise on: 1/2/2/0 58.7, 0/2/2/0 64.6).  Overridable for experiments.
+// 0/2/2/0 46.8, 1/3/3/0 46.2, 0/1/1/0 46.7, 2/3/3/0 46.0 (noise on: 1/2/2/0 58.7, 0/2/2/0 64.6).  Round 3 re-did the comparison in
+// CLOCKS (s_memtime around each workgroup's loop, 65 536 envs x 256 cycles: independent of the clock level the box happens to
+// run at; the launch lasts as long as the slowest workgroup; profiles/r03/ws_prio_clocks*.txt), median / max over the workgroups:
+// 1/2/2/0 305.9 k / 331.2 k, 1/2/3/0 311.2 k / 322.5 k, 1/3/2/0 325.6 k / 338.8 k, 1/3/3/0 306.0 k / 329.5 k, 2/2/3/0 313.3 k /
+// 333.6 k, 1/1/3/0 313.3 k / 335.1 k, 0/2/3/0 312.0 k / 327.8 k (noise on: 384.9 k -> 383.2 k max) -- four different levels, the
+// ball wave (which streams the observations) on top: no tie is left to the arbiter's oldest-first rule, which favours the
+// workgroups a CU received first.  Overridable for experiments.
 #ifndef S2D_PRIO_S
 #define S2D_PRIO_S 1
 #endif
@@ -680,7 +686,7 @@ static constexpr int kSlots = 3;
 #define S2D_PRIO_A 2
 #endif
 #ifndef S2D_PRIO_B
-#define S2D_PRIO_B 2
+#define S2D_PRIO_B 3
 #endif
 static constexpr int kWsBlock = 4 * kWave;
 
