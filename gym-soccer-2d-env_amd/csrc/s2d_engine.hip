@@ -725,7 +725,12 @@ S2D_DEV NextEpisode slot_take(const float (*slot)[kWave], int lane) {
                      slot[7][lane], slot[8][lane], slot[9][lane], slot[10][lane], slot[11][lane], slot[12][lane]};
 }
 
-template <int MODE, bool NOISE>
+// REC: what the kernel knows about the record at compile time.  0: nothing (every array may be absent, `nt` is a run-time flag);
+// 1 / 2: all five arrays are there and the stores are plain / non-temporal.  The presence tests and the nt selection are
+// wave-uniform branches, eleven of them per cycle in the two waves that store -- and those are the long waves when noise is off:
+// with them compiled out the slowest workgroup of a 256-cycle launch counts 296 k clocks instead of 321 k
+// (profiles/r03/ws_static_record.txt).  Instantiated for the discrete-action, noise-off configuration (the DQN script's).
+template <int MODE, bool NOISE, int REC = 0>
 __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
                                                                         float* __restrict__ S, int64_t stride,
                                                                         int64_t n, int n_steps,
@@ -741,7 +746,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   __shared__ float2 sc_lut[361];                           //   and (sin, cos) of the whole degrees -180 .. 180
   const int lane = threadIdx.x & (kWave - 1);
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 agent, 3 ball
-  const bool nt = ro.nt != 0;
+  const bool nt = REC == 2 || (REC == 0 && ro.nt != 0);
   const int64_t wave_first = (int64_t)blockIdx.x * kWave;
   const int64_t i = wave_first + lane;
   const bool active = i < n;
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         if (lut) {
           if (s == 0 || (k & 3u) == 0u) quad = policy_quad(p, gl, gh, k, S2D_ST_POLICY);
           const int a = (int)rnd_below(quad_word(quad, k), (uint32_t)p.n_actions);
-          if (ro.action) rec_store(static_cast<int32_t*>(ro.action) + row + i, (int32_t)a, nt);
+          if (REC != 0 || ro.action) rec_store(static_cast<int32_t*>(ro.action) + row + i, (int32_t)a, nt);
           const float4 e4 = act_lut[a];
           c = CmdPrep{e4.x, e4.y, e4.z}; dir = e4.w; cmd = S2D_CMD_DASH;
         } else {
@@ -960,11 +965,11 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
             for (int k = 0; k < 4; ++k) oa[k] = sl[SL_FIRST + k][lane];
             prev_dist = sl[SL_DIST][lane]; prev_angle = sl[SL_REL][lane];   // reach_ball_env.py:166 carry seeded
           }
-          if (ro.reward) rec_store(ro.reward + row + i, reward, nt);
-          if (ro.done) rec_store(ro.done + row + i, (uint8_t)done, nt);
-          if (ro.result) rec_store(ro.result + row + i, (uint8_t)res, nt);
+          if (REC != 0 || ro.reward) rec_store(ro.reward + row + i, reward, nt);
+          if (REC != 0 || ro.done) rec_store(ro.done + row + i, (uint8_t)done, nt);
+          if (REC != 0 || ro.result) rec_store(ro.result + row + i, (uint8_t)res, nt);
           cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
-          if (ro.obs) {                                    // this wave's four words of the row
+          if (REC != 0 || ro.obs) {                                    // this wave's four words of the row
             float* t = &tile[b][lane * S2D_OBS_DIM];
             t[0] = oa[0]; t[1] = oa[1]; t[2] = oa[2]; t[3] = oa[3];
           }
@@ -994,7 +999,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
     __syncthreads();                                       // prepared episodes published
     for (int s = 0; s < n_iter; ++s) {
-      if (s >= 3 && ro.obs)                                // observation block of step s - 3, completed in iteration s - 1
+      if (s >= 3 && (REC != 0 || ro.obs))                                // observation block of step s - 3, completed in iteration s - 1
         tile_flush(tile[(s - 1) & 1], lane, ro.obs + ((int64_t)(s - 3) * n + wave_first) * S2D_OBS_DIM, valid, nt);
       if (s >= 2 && s < n_steps + 2 && active) {           // step s - 2
         const int b = s & 1;
@@ -1009,7 +1014,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
 #pragma unroll
           for (int k = 4; k < S2D_OBS_DIM; ++k) ob6[k] = sl[SL_FIRST + k][lane];
         }
-        if (ro.obs) {
+        if (REC != 0 || ro.obs) {
           float* t = &tile[b][lane * S2D_OBS_DIM];
 #pragma unroll
           for (int k = 4; k < S2D_OBS_DIM; ++k) t[k] = ob6[k];
@@ -1521,7 +1526,10 @@ S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int a
   // small batches: four waves per env group (policy | simulate | agent | ball)
   const bool ws = h->rollout_ws < 0 ? (h->n <= kWsMaxEnvs) : (h->rollout_ws != 0);
   if (ws) {
-    hipLaunchKernelGGL(table_ws[h->mode][h->noise ? 1 : 0], dim3((unsigned)((h->n + kWave - 1) / kWave)),
+    RollK kern_ws = table_ws[h->mode][h->noise ? 1 : 0];
+    if (h->mode == S2D_MODE_DISCRETE && !h->noise && ro.obs && ro.action && ro.reward && ro.done && ro.result)
+      kern_ws = ro.nt ? s2d_reach_rollout_ws_kernel<S2D_MODE_DISCRETE, false, 2> : s2d_reach_rollout_ws_kernel<S2D_MODE_DISCRETE, false, 1>;
+    hipLaunchKernelGGL(kern_ws, dim3((unsigned)((h->n + kWave - 1) / kWave)),
                        dim3(kWsBlock), 0, static_cast<hipStream_t>(stream), h->hot, h->rare_dev,
                        reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, n_steps, actions_dev, action_kind,
                        ro, h->out);
