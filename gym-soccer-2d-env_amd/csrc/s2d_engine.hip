@@ -99,8 +99,9 @@ template <typename T>
 S2D_DEV void rec_store(T* p, T v, bool nt) {
   if (nt) __builtin_nontemporal_store(v, p); else *p = v;
 }
-S2D_DEV void tile_flush(const float* tile, int lane, float* __restrict__ dst, int valid, bool nt = false) {
-  const bool vec = (valid == kObsTile) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+// all_vec: the caller has established once that every row of its launch is a full, 16-byte-aligned tile (no per-call test)
+S2D_DEV void tile_flush(const float* tile, int lane, float* __restrict__ dst, int valid, bool nt = false, bool all_vec = false) {
+  const bool vec = all_vec || ((valid == kObsTile) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0));
   if (vec) {
     const float4* t4 = reinterpret_cast<const float4*>(tile);
     float4* d4 = reinterpret_cast<float4*>(dst);
@@ -997,10 +998,14 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     const bool auto_reset = p_sgpr.auto_reset != 0;
     float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
+    // every row of this group's observation stream is a whole tile at a 16-byte-aligned address when the first one is and the row
+    // stride (n x 40 bytes) keeps it so
+    const bool obs_all_vec = valid == kObsTile && ((n * S2D_OBS_DIM * 4) & 15) == 0 &&
+                             (reinterpret_cast<uintptr_t>(ro.obs + wave_first * S2D_OBS_DIM) & 15u) == 0;
     __syncthreads();                                       // prepared episodes published
     for (int s = 0; s < n_iter; ++s) {
       if (s >= 3 && (REC != 0 || ro.obs))                                // observation block of step s - 3, completed in iteration s - 1
-        tile_flush(tile[(s - 1) & 1], lane, ro.obs + ((int64_t)(s - 3) * n + wave_first) * S2D_OBS_DIM, valid, nt);
+        tile_flush(tile[(s - 1) & 1], lane, ro.obs + ((int64_t)(s - 3) * n + wave_first) * S2D_OBS_DIM, valid, nt, obs_all_vec);
       if (s >= 2 && s < n_steps + 2 && active) {           // step s - 2
         const int b = s & 1;
         float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
