@@ -679,7 +679,8 @@ static constexpr int kSlots = 3;
 // 1/2/2/0 305.9 k / 331.2 k, 1/2/3/0 311.2 k / 322.5 k, 1/3/2/0 325.6 k / 338.8 k, 1/3/3/0 306.0 k / 329.5 k, 2/2/3/0 313.3 k /
 // 333.6 k, 1/1/3/0 313.3 k / 335.1 k, 0/2/3/0 312.0 k / 327.8 k (noise on: 384.9 k -> 383.2 k max) -- four different levels, the
 // ball wave (which streams the observations) on top: no tie is left to the arbiter's oldest-first rule, which favours the
-// workgroups a CU received first.  Overridable for experiments.
+// workgroups a CU received first.  With noise on the simulating wave is the long one and the policy wave the next: 3/2/2/1
+// (policy last) counts 381.2 k against 386.9 k for 1/2/3/0 (ws_prio_clocks_noise.txt).  Overridable for experiments.
 #ifndef S2D_PRIO_S
 #define S2D_PRIO_S 1
 #endif
@@ -766,6 +767,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   }
 
   if (role == 0) {
+    if constexpr (NOISE) __builtin_amdgcn_s_setprio(1);    // two Philox blocks per four cycles: the second-longest chain with noise
     // ------------------------------------------------------------------ P-wave
     const S2DHot& p = p_sgpr;
     const bool use_k = uses_policy_step<MODE, NOISE>(kind);
@@ -825,7 +827,8 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     }
   } else if (role == 1) {
     // ------------------------------------------------------------------ S-wave
-    __builtin_amdgcn_s_setprio(S2D_PRIO_S);                // the critical stream of the group
+    if constexpr (NOISE) __builtin_amdgcn_s_setprio(3);    // with noise it is this wave's chain that is the longest (3/2/2/1)
+    else __builtin_amdgcn_s_setprio(S2D_PRIO_S);
     const S2DHot p = hot_in_vgprs(p_sgpr);
     Env e;
     uint32_t gl = 0, gh = 0;
@@ -927,7 +930,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       S[F_EPISODE * stride + i] = __int_as_float(e.episode);
     }
   } else if (role == 2) {
-    __builtin_amdgcn_s_setprio(S2D_PRIO_A);
+    __builtin_amdgcn_s_setprio(S2D_PRIO_A);                // (2 with and without noise)
     // ------------------------------------------------------------------ A-wave (player half, reward, labels)
     const S2DHot p = hot_in_vgprs(p_sgpr);                 // no kernarg re-loads (s_load + s_waitcnt) inside the loop
     const bool auto_reset = p_sgpr.auto_reset != 0;
@@ -993,7 +996,8 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, cnt1, cnt2, cnt3);
   } else {
     // ------------------------------------------------------------------ B-wave (ball half, observation stream)
-    __builtin_amdgcn_s_setprio(S2D_PRIO_B);
+    if constexpr (NOISE) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(S2D_PRIO_B);
     const S2DHot p = hot_in_vgprs(p_sgpr);                 // no kernarg re-loads inside the loop
     const bool auto_reset = p_sgpr.auto_reset != 0;
     float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here
