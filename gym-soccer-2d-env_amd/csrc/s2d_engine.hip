@@ -947,8 +947,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
     int64_t row = 0;
     __syncthreads();                                       // prepared episodes published
-    for (int s = 0; s < n_iter; ++s) {
-      if (s >= 2 && s < n_steps + 2) {                     // step s - 2
+    auto agent_iteration = [&](int s, auto steady_tag) {   // (three stretches: see the ball wave)
+      constexpr bool STEADY = decltype(steady_tag)::value;
+      if (STEADY || (s >= 2 && s < n_steps + 2)) {         // step s - 2
         const int b = s & 1;
         res = 0;
         if (active) {
@@ -981,6 +982,12 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         row += n;
       }
       __syncthreads();
+    };
+    {
+      int s = 0;
+      for (; s < 3 && s < n_iter; ++s) agent_iteration(s, std::false_type{});
+      for (; s < n_steps + 2; ++s) agent_iteration(s, std::true_type{});
+      for (; s < n_iter; ++s) agent_iteration(s, std::false_type{});
     }
     if (active) {
       S[F_PREV_DIST * stride + i] = prev_dist; S[F_PREV_ANGLE * stride + i] = prev_angle;
@@ -1007,10 +1014,13 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     const bool obs_all_vec = valid == kObsTile && ((n * S2D_OBS_DIM * 4) & 15) == 0 &&
                              (reinterpret_cast<uintptr_t>(ro.obs + wave_first * S2D_OBS_DIM) & 15u) == 0;
     __syncthreads();                                       // prepared episodes published
-    for (int s = 0; s < n_iter; ++s) {
-      if (s >= 3 && (REC != 0 || ro.obs))                                // observation block of step s - 3, completed in iteration s - 1
+    // The loop in three stretches: filling (s < 3), steady (3 <= s < n_steps + 2: every stage of the pipeline has work, the range tests
+    // are compiled out -- wave-uniform branches the long waves pay for in every cycle) and draining.  One barrier per iteration in all.
+    auto ball_iteration = [&](int s, auto steady_tag) {
+      constexpr bool STEADY = decltype(steady_tag)::value;
+      if ((STEADY || s >= 3) && (REC != 0 || ro.obs))      // observation block of step s - 3, completed in iteration s - 1
         tile_flush(tile[(s - 1) & 1], lane, ro.obs + ((int64_t)(s - 3) * n + wave_first) * S2D_OBS_DIM, valid, nt, obs_all_vec);
-      if (s >= 2 && s < n_steps + 2 && active) {           // step s - 2
+      if ((STEADY || (s >= 2 && s < n_steps + 2)) && active) {   // step s - 2
         const int b = s & 1;
         float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
         float bvx = snap[b][WS_BVX][lane], bvy = snap[b][WS_BVY][lane];
@@ -1030,6 +1040,12 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         }
       }
       __syncthreads();
+    };
+    {
+      int s = 0;
+      for (; s < 3 && s < n_iter; ++s) ball_iteration(s, std::false_type{});
+      for (; s < n_steps + 2; ++s) ball_iteration(s, std::true_type{});
+      for (; s < n_iter; ++s) ball_iteration(s, std::false_type{});
     }
     if (active) {
 #pragma unroll
