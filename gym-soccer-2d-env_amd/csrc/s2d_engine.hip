@@ -870,8 +870,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     __syncthreads();                                       // prepared episodes (and this wave's tables) published
     auto loop = [&](auto fast_tag) {
       constexpr bool FAST = decltype(fast_tag)::value;
-      for (int s = 0; s < n_iter; ++s) {
-        if (s >= 1 && s <= n_steps && active) {            // step s - 1
+      auto simulate_iteration = [&](int s, auto steady_tag) {   // (three stretches: see the ball wave)
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        if ((STEADY || (s >= 1 && s <= n_steps)) && active) {   // step s - 1
           const int b = (s - 1) & 1;
           int cmd = S2D_CMD_DASH;                          // only the turning mode has another command
           if (MODE == S2D_MODE_TURN4) cmd = __float_as_int(act[b][WA_CMD][lane]);
@@ -906,7 +907,11 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           }
         }
         __syncthreads();
-      }
+      };
+      int s = 0;
+      for (; s < 1 && s < n_iter; ++s) simulate_iteration(s, std::false_type{});
+      for (; s <= n_steps; ++s) simulate_iteration(s, std::true_type{});
+      for (; s < n_iter; ++s) simulate_iteration(s, std::false_type{});
     };
     if (fast) {
       loop(std::true_type{});
