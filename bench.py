@@ -360,9 +360,10 @@ def roofline_of(alg_bytes_launch, launch_s, launch_s_events, kernel, traffic_key
          'kernel': kernel, 'launch_us': launch_s * 1e6,
          'algorithmic_bytes_per_launch': alg_bytes_launch,
          'algorithmic_bytes_per_env_step': alg_bytes_launch / (n * steps_per_launch),
-         # what the PMC profiles say limits the kernel: HBM traffic equals the algorithmic bytes; the SIMDs' instruction issue
-         # is what is saturated in the fused kernels, launch + memory latency in the one-cycle kernel
-         'limiter': 'valu-issue' if steps_per_launch > 1 else 'launch-latency'}
+         # what limits the kernel (HBM traffic equals the algorithmic bytes): in the fused kernels the slowest workgroup's dependent
+         # chain at the clock the chip grants, launch + memory latency in the one-cycle kernel
+         'limiter': ("slowest workgroup's instruction chain x the shader clock granted under the kernel's power draw (1.5-2.0 GHz, DESIGN section 7)"
+                     if steps_per_launch > 1 else 'launch-latency')}
     if launch_s_events:
         r['launch_us_events'] = launch_s_events * 1e6
         r['frac_events'] = alg_bytes_launch / launch_s_events / 1e9 / HBM_PEAK_GBS
