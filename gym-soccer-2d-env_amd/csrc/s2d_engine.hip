@@ -20,322 +20,7 @@
 
 #include "s2d_device.h"
 
-#define S2D_API extern "C" __attribute__((visibility("default")))
-
-#ifndef S2D_BLOCK
-#define S2D_BLOCK 256
-#endif
-static constexpr int kBlock = S2D_BLOCK;
-static constexpr int kWave = 64;
-static constexpr int kWavesPerBlock = kBlock / kWave;
-static constexpr int kObsTile = kWave * S2D_OBS_DIM;  // 640 floats per wave
-static constexpr int64_t kWsMaxEnvs = 524288;         // the wave-specialised rollout wins or ties up to here at steady clocks (profiles/r01/ws_vs_unified_sweep.txt)
-
-// ------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------
-struct StepOut {
-  float* obs;            // [N][10]
-  float* reward;         // [N]
-  uint8_t* done;         // [N]
-  uint8_t* result;       // [N]
-  float* terminal_obs;   // [N][10]
-  float* action_dir;     // [N]
-  uint8_t* action_cmd;   // [N]
-  unsigned long long* stats;
-  float* prep;           // persistent prepared episodes of the per-step API: [2][PS_WORDS][stride] words + [2][stride] tags
-};
-
-// ---- persistent prepared episodes (per-step API) ------------------------------------------------------------------------
-// s2d_step runs one wave per 64 envs, and a launch lasts as long as its slowest wave.  Drawing a reset inline (Philox blocks,
-// the rejection loop, a simulator cycle, the first observation: ~2.8 us with one or two active lanes) therefore cost EVERY
-// launch those 2.8 us, because some wave always has an episode ending (profiles/r02/ab_step.txt: 7.3 us per launch against
-// 4.5 us for a workload whose episodes never end).  Episode j of env g is a function of (g, j) alone, so every env keeps its
-// next two episodes prepared in the arena: slot j & 1 holds episode j, tagged with j.  A slot is the seven words of the
-// post-reset state that depend on the draw (player x, y, body; ball x, y, vx, vy after the reset's command-less cycle); the
-// rest is constant (player at rest, stamina model one cycle after a recover) or a function of those seven (first
-// observation, reward carry) and is rebuilt in the few waves that reset -- every extra load of a step costs all waves
-// ~15 ns (profiles/r02/ab_step.txt), a rebuilt word only the resetting ones.  A step loads both slots with the state (no
-// load waits for another one's result); a reset is a register copy plus ~0.4 us of arithmetic.  Slots are refilled off the critical path by extra
-// workgroups appended to the same launch's grid: each looks at its envs' `episode` e and prepares episode e + 2 if slot
-// e & 1 does not hold it yet -- never the slot a main wave may be reading in the same launch -- and finishes well inside
-// the launch.  s2d_reset prepares both slots of the envs it resets; a slot whose tag does not match (first use after the
-// rollout kernels advanced the episode counter) is ignored and the reset is drawn inline, once.
-enum { PS_PX, PS_PY, PS_BODY, PS_BX, PS_BY, PS_BVX, PS_BVY, PS_WORDS };
-S2D_DEV uint32_t* prep_tags(float* prep, int64_t stride) { return reinterpret_cast<uint32_t*>(prep + 2 * PS_WORDS * stride); }
-
-// LDS ops of one wave execute in order, so a wave-private tile needs no s_barrier; the
-// wavefront-scope fences only stop the compiler from reordering the cross-lane accesses.
-S2D_DEV void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Transpose a wave's [64][10] observation block through LDS and store it as one contiguous
-// run.  `dst` = address of the block's first row (wave-uniform); `valid` = number of floats of
-// the run that exist (640, or fewer in the last wave).  The two halves may run in different
-// waves (tile_write by the observing wave, tile_flush by another one after an s_barrier).
-S2D_DEV void tile_write(float* tile, const ObsOut& ob, int lane, bool active) {
-  if (active) {
-#pragma unroll
-    for (int k = 0; k < S2D_OBS_DIM; ++k) tile[lane * S2D_OBS_DIM + k] = ob.o[k];
-  }
-}
-// Record stores.  A launch whose record does not fit the 256 MiB Infinity Cache streams it out: non-temporal stores (`nt`, a
-// wave-uniform flag the host sets from the record's size) keep those lines from being parked in L2 on their way -- 4 % on the
-// 838 MB record of the headline configuration, steadier from region to region (profiles/r03/ab_store_policy_long.txt); a record
-// that fits (64 cycles x 65 536 envs = 218 MB) keeps the plain stores, which are 3 % faster there.
-typedef float v4f32_t __attribute__((ext_vector_type(4)));
-S2D_DEV void rec_store16(float4* p, const float4& v, bool nt) {
-  if (nt) {
-    const v4f32_t w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(w) : "memory");
-  } else {
-    *p = v;
-  }
-}
-template <typename T>
-S2D_DEV void rec_store(T* p, T v, bool nt) {
-  if (nt) __builtin_nontemporal_store(v, p); else *p = v;
-}
-// all_vec: the caller has established once that every row of its launch is a full, 16-byte-aligned tile (no per-call test)
-S2D_DEV void tile_flush(const float* tile, int lane, float* __restrict__ dst, int valid, bool nt = false, bool all_vec = false) {
-  const bool vec = all_vec || ((valid == kObsTile) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0));
-  if (vec) {
-    const float4* t4 = reinterpret_cast<const float4*>(tile);
-    float4* d4 = reinterpret_cast<float4*>(dst);
-    rec_store16(d4 + lane, t4[lane], nt);
-    rec_store16(d4 + kWave + lane, t4[kWave + lane], nt);
-    if (lane < 32) rec_store16(d4 + 2 * kWave + lane, t4[2 * kWave + lane], nt);
-  } else {
-#pragma unroll
-    for (int j = 0; j < S2D_OBS_DIM; ++j) {
-      int idx = j * kWave + lane;
-      if (idx < valid) dst[idx] = tile[idx];
-    }
-  }
-}
-S2D_DEV void store_obs_tile(float* tile, const ObsOut& ob, int lane, bool active, float* __restrict__ dst,
-                            int valid) {
-  tile_write(tile, ob, lane, active);
-  wave_lds_fence();
-  tile_flush(tile, lane, dst, valid);
-  wave_lds_fence();
-}
-
-// Episode counters: every group of 64 envs owns one row of stats[S2D_STATS_ROWS(n)][8], and in every kernel that group is
-// one wave (or the agent wave of one workgroup), so the row is updated with a plain load at the start of the launch and a plain
-// store at its end -- lanes 0 .. 3 hold counters 0 .. 3; the env-step counter of the whole batch is kept by the first group, so a
-// wave in which no episode ended stores nothing.  (Round 1 used striped atomics: no contention to speak of, yet the
-// three atomics at the end of a wave cost s2d_step 0.3 us per launch, profiles/r02/ab_step_ablation.txt.)
-S2D_DEV unsigned long long* stats_row(unsigned long long* stats, int64_t wave_first) { return stats + (wave_first / kWave) * 8; }
-S2D_DEV unsigned long long stats_load(const unsigned long long* row, int lane) { return lane < 4 ? row[lane] : 0ull; }
-// steps / goal / out / timeout: wave-uniform increments
-S2D_DEV void stats_store(unsigned long long* row, int lane, unsigned long long old, unsigned long long steps, unsigned int goal,
-                         unsigned int out, unsigned int timeout) {
-  const unsigned long long add = lane == 0 ? steps : lane == 1 ? goal : lane == 2 ? out : timeout;
-  if (lane < 4 && add != 0ull) row[lane] = old + add;
-}
-S2D_DEV unsigned int wave_count(bool pred) { return (unsigned int)__popcll(__ballot(pred)); }
-
-// caller-provided action of env i at rollout step t (layouts of include/s2d.h)
-template <int MODE>
-S2D_DEV Action4 load_action(const void* __restrict__ actions, int kind, int64_t idx) {
-  Action4 a{0.0f, 0.0f, 0.0f, 0.0f};
-  if (MODE == S2D_MODE_DISCRETE) {
-    a.a0 = (kind == S2D_ACT_DISCRETE_I64) ? (float)static_cast<const long long*>(actions)[idx]
-                                          : (float)static_cast<const int32_t*>(actions)[idx];
-  } else if (MODE == S2D_MODE_CONT1) {
-    a.a0 = static_cast<const float*>(actions)[idx];
-  } else {
-    float4 v = static_cast<const float4*>(actions)[idx];
-    a.a0 = v.x; a.a1 = v.y; a.a2 = v.z; a.a3 = v.w;
-  }
-  return a;
-}
-// in-kernel uniform random policy at policy step k (s2d_device.h: policy_quad).  `quad` caches
-// the POLICY block of counter k >> 2; `refresh` = it has to be drawn now.
-template <int MODE>
-S2D_DEV Action4 random_action(const S2DHot& p, uint32_t gid_lo, uint32_t gid_hi, uint32_t k, U4& quad, bool refresh) {
-  Action4 a{0.0f, 0.0f, 0.0f, 0.0f};
-  if (MODE == S2D_MODE_TURN4) {
-    U4 w = s2d_draw(p, gid_lo, gid_hi, k, S2D_ST_POLICY, 1);
-    a.a0 = rnd_u01(w.x) * 2.0f - 1.0f; a.a1 = rnd_u01(w.y) * 2.0f - 1.0f;
-    a.a2 = rnd_u01(w.z) * 2.0f - 1.0f; a.a3 = rnd_u01(w.w) * 2.0f - 1.0f;
-  } else {
-    if (refresh) quad = policy_quad(p, gid_lo, gid_hi, k, S2D_ST_POLICY);
-    uint32_t w = quad_word(quad, k);
-    if (MODE == S2D_MODE_DISCRETE) a.a0 = (float)rnd_below(w, (uint32_t)p.n_actions);
-    else a.a0 = rnd_u01(w) * 2.0f - 1.0f;
-  }
-  return a;
-}
-// does a launch of this mode / action kind / noise setting consume the env's policy_step?  (wave-uniform)
-template <int MODE, bool NOISE>
-S2D_DEV bool uses_policy_step(int kind) { return kind == S2D_ACT_RANDOM || MODE == S2D_MODE_TURN4 || NOISE; }
-
-template <int MODE>
-S2D_DEV void store_rollout_action(void* __restrict__ dst, int64_t idx, const Action4& a) {
-  if (MODE == S2D_MODE_DISCRETE) static_cast<int32_t*>(dst)[idx] = (int32_t)a.a0;
-  else if (MODE == S2D_MODE_CONT1) static_cast<float*>(dst)[idx] = a.a0;
-  else static_cast<float4*>(dst)[idx] = make_float4(a.a0, a.a1, a.a2, a.a3);
-}
-
-// action of one env for the step at policy step k -> decoded command (A2, reach_ball_env.py:53-85)
-// with the command-only part of the dash already evaluated.  `quad` / `squad` cache the POLICY /
-// SELECT blocks across the four steps they serve.
-template <int MODE>
-S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int kind, int64_t idx, uint32_t gid_lo,
-                       uint32_t gid_hi, uint32_t k, bool refresh, U4& quad, U4& squad, void* __restrict__ action_out,
-                       int& cmd, float& dir) {
-  if (kind == S2D_ACT_COMMAND) {                           // a decoded body command, executed as it is (wave-uniform branch)
-    const float4 v = static_cast<const float4*>(actions)[idx];
-    cmd = (int)v.x; dir = v.z;
-    return cmd_prepare(p, cmd, v.y, v.z);
-  }
-  Action4 a = (kind == S2D_ACT_RANDOM) ? random_action<MODE>(p, gid_lo, gid_hi, k, quad, refresh)
-                                       : load_action<MODE>(actions, kind, idx);
-  if (action_out) store_rollout_action<MODE>(action_out, idx, a);
-  float u = 0.0f;
-  if (MODE == S2D_MODE_TURN4) {                          // reach_ball_env.py:71
-    if (refresh) squad = policy_quad(p, gid_lo, gid_hi, k, S2D_ST_SELECT);
-    u = rnd_u01(quad_word(squad, k));
-  }
-  float power;
-  action_map<MODE>(p, a, u, cmd, power, dir);
-  return cmd_prepare(p, cmd, power, dir);
-}
-
-// Prepared reset samples of one wave (LDS, struct-of-arrays over the 64 lanes).  The sample of
-// an env's NEXT episode depends only on (gid, cycle at which the current episode began), so a
-// rollout kernel draws them for many lanes at once -- a full wave at launch, then whenever
-// kRefillMin lanes have used theirs -- instead of running the Philox + rejection loop with one
-// or two active lanes each time an episode ends.
-// Without noise the tile holds the whole post-reset state (NextEpisode, 13 words), with noise the sample (7).
-struct PrepTile { float v[13 + S2D_OBS_DIM + 2][kWave]; };   // NextEpisode + FirstObs
-#ifndef S2D_REFILL_MIN
-#define S2D_REFILL_MIN 8
-#endif
-static constexpr int kRefillMin = S2D_REFILL_MIN;
-
-template <bool NOISE>
-S2D_DEV void prep_fill(const S2DHot& p, const S2DRare* __restrict__ rp, PrepTile& t, int lane, const Env& e,
-                       uint32_t gid_lo, uint32_t gid_hi) {
-  const S2DRare r = *rp;
-  const NextEpisode q = episode_prepare<NOISE>(p, rp, r, gid_lo, gid_hi, reset_key(e));
-  t.v[0][lane] = q.px; t.v[1][lane] = q.py; t.v[2][lane] = q.vx; t.v[3][lane] = q.vy; t.v[4][lane] = q.body;
-  t.v[5][lane] = q.stamina; t.v[6][lane] = q.effort; t.v[7][lane] = q.recovery; t.v[8][lane] = q.capacity;
-  t.v[9][lane] = q.bx; t.v[10][lane] = q.by; t.v[11][lane] = q.bvx; t.v[12][lane] = q.bvy;
-  const FirstObs f = first_obs(p, q);
-#pragma unroll
-  for (int k = 0; k < S2D_OBS_DIM; ++k) t.v[13 + k][lane] = f.o[k];
-  t.v[13 + S2D_OBS_DIM][lane] = f.dist; t.v[14 + S2D_OBS_DIM][lane] = f.rel;
-}
-// the same by the whole wave together (reset_sample_coop; wave-uniform call, `need` = this lane's tile entry is to be drawn;
-// `scratch` = 64 wave-private LDS words)
-template <bool NOISE>
-S2D_DEV void prep_fill_coop(const S2DHot& p, const S2DRare* __restrict__ rp, PrepTile& t, int lane, uint32_t key,
-                            uint32_t gid_lo, uint32_t gid_hi, bool need, uint32_t* scratch) {
-  const S2DRare r = *rp;
-  const NextEpisode q = episode_prepare_coop<NOISE>(p, rp, r, gid_lo, gid_hi, key, need, lane, scratch);
-  const FirstObs f = first_obs(p, q);
-  if (need) {
-    t.v[0][lane] = q.px; t.v[1][lane] = q.py; t.v[2][lane] = q.vx; t.v[3][lane] = q.vy; t.v[4][lane] = q.body;
-    t.v[5][lane] = q.stamina; t.v[6][lane] = q.effort; t.v[7][lane] = q.recovery; t.v[8][lane] = q.capacity;
-    t.v[9][lane] = q.bx; t.v[10][lane] = q.by; t.v[11][lane] = q.bvx; t.v[12][lane] = q.bvy;
-#pragma unroll
-    for (int k = 0; k < S2D_OBS_DIM; ++k) t.v[13 + k][lane] = f.o[k];
-    t.v[13 + S2D_OBS_DIM][lane] = f.dist; t.v[14 + S2D_OBS_DIM][lane] = f.rel;
-  }
-}
-S2D_DEV NextEpisode prep_take_episode(const PrepTile& t, int lane) {
-  return NextEpisode{t.v[0][lane], t.v[1][lane], t.v[2][lane], t.v[3][lane], t.v[4][lane], t.v[5][lane], t.v[6][lane],
-                     t.v[7][lane], t.v[8][lane], t.v[9][lane], t.v[10][lane], t.v[11][lane], t.v[12][lane]};
-}
-
-S2D_DEV const S2DTables* tables_of(const S2DRare* rp) {
-  return reinterpret_cast<const S2DTables*>(reinterpret_cast<const char*>(rp) + 256);
-}
-
-// A1: one Soccer2DEnv.step (soccer_2d_env.py:226-269) for the env held in registers, given the
-// decoded command.  Returns the observation to hand back (post auto-reset), reward/done/result.
-// prep == nullptr: the reset sample is drawn on the spot (per-step API).
-// FAST: the dash-only fast path (s2d_device.h, S2DTables): ep_lds = effort * power by step number, sc_lut = (sin, cos) of the
-// whole degrees -180 .. 180; the caller has checked that the env sits on the table.
-template <bool NOISE, bool FAST = false>
-S2D_DEV void step_env(const S2DHot& p, const S2DRare* __restrict__ rp, Env& e, uint32_t gid_lo, uint32_t gid_hi,
-                      uint32_t k, int cmd, const CmdPrep& c, ObsOut& ob, float& reward, int& done, int& result,
-                      float* __restrict__ terminal_row, PrepTile* prep, int lane, bool& have_prep,
-                      const float* ep_lds = nullptr, const float2* sc_lut = nullptr) {
-  NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  if (NOISE) nz = noise_prepare(p, gid_lo, gid_hi, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);
-  float d2;
-  if constexpr (FAST) {
-    const float ep = ep_lds[e.step_number];
-    const float2 sc = sc_lut[(int)norm_deg(e.body + c.dir) + 180];
-    e.step_number += 1;                                  // reach_ball_env.py:55
-    d2 = sim_cycle_dash_fast<NOISE>(p, rp, e, ep, c.dir_rate, sc.x, sc.y, nz);
-  } else {
-    e.step_number += 1;                                  // reach_ball_env.py:55
-    d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);   // trainer forces PlayOn each cycle (:242)
-  }
-  observe_and_check(p, e, d2, ob, done, reward, result);
-  if (done && p.auto_reset) {                  // SB3 VecEnv convention
-#pragma unroll
-    for (int k = 0; k < S2D_OBS_DIM; ++k) terminal_row[k] = ob.o[k];
-    if (prep) {
-      if (!have_prep) prep_fill<NOISE>(p, rp, *prep, lane, e, gid_lo, gid_hi);   // episode shorter than the refill cadence
-      have_prep = false;
-      episode_begin(e, prep_take_episode(*prep, lane));    // state, first observation and carry were prepared together
-#pragma unroll
-      for (int k = 0; k < S2D_OBS_DIM; ++k) ob.o[k] = prep->v[13 + k][lane];
-      e.prev_dist = prep->v[13 + S2D_OBS_DIM][lane]; e.prev_angle = prep->v[14 + S2D_OBS_DIM][lane];
-      return;
-    } else {
-      d2 = env_reset<NOISE>(p, rp, e, gid_lo, gid_hi);
-    }
-    int dn2, r2; float w2;
-    observe_and_check(p, e, d2, ob, dn2, w2, r2);        // reach_ball_env.py:166: carry seeded, outputs dropped
-  }
-}
-
-// prepare episode `episode` of the env and store it in its persistent slot (episode & 1), tag last
-template <bool NOISE>
-S2D_DEV void prep_store(const S2DHot& p, const S2DRare* __restrict__ rp, float* __restrict__ prep, int64_t stride, int64_t i,
-                        uint32_t gl, uint32_t gh, uint32_t episode) {
-  const S2DRare r = *rp;
-  const NextEpisode q = episode_prepare<NOISE>(p, rp, r, gl, gh, episode);
-  float* d = prep + (int64_t)(episode & 1u) * PS_WORDS * stride + i;
-  const float w[PS_WORDS] = {q.px, q.py, q.body, q.bx, q.by, q.bvx, q.bvy};
-#pragma unroll
-  for (int k = 0; k < PS_WORDS; ++k) d[k * stride] = w[k];
-  prep_tags(prep, stride)[(int64_t)(episode & 1u) * stride + i] = episode;
-}
-// the refill workgroups' form: the whole wave draws together (reset_sample_coop; `need` = this lane's slot is to be drawn)
-template <bool NOISE>
-S2D_DEV void prep_store_coop(const S2DHot& p, const S2DRare* __restrict__ rp, float* __restrict__ prep, int64_t stride, int64_t i,
-                             uint32_t gl, uint32_t gh, uint32_t episode, bool need, int lane, uint32_t* scratch) {
-  const S2DRare r = *rp;
-  const NextEpisode q = episode_prepare_coop<NOISE>(p, rp, r, gl, gh, episode, need, lane, scratch);
-  if (need) {
-    float* d = prep + (int64_t)(episode & 1u) * PS_WORDS * stride + i;
-    const float w[PS_WORDS] = {q.px, q.py, q.body, q.bx, q.by, q.bvx, q.bvy};
-#pragma unroll
-    for (int k = 0; k < PS_WORDS; ++k) d[k * stride] = w[k];
-    prep_tags(prep, stride)[(int64_t)(episode & 1u) * stride + i] = episode;
-  }
-}
-// the post-reset state from a slot: the drawn words + what every reset leaves behind (reset_apply: player at rest -- its
-// velocity stays +0 through the command-less cycle, with noise on too: the noise magnitude is proportional to the speed --
-// and the stamina model one update after a recover)
-S2D_DEV NextEpisode prep_episode(const S2DHot& p, const S2DRare* __restrict__ rp, const float* w) {
-  Env t{};
-  t.stamina = p.stamina_max; t.recovery = rp->recover_init; t.effort = p.effort_init; t.capacity = p.stamina_capacity;
-  update_stamina(p, t);
-  return NextEpisode{w[PS_PX], w[PS_PY], 0.0f, 0.0f, w[PS_BODY], t.stamina, t.effort, t.recovery, t.capacity,
-                     w[PS_BX], w[PS_BY], w[PS_BVX], w[PS_BVY]};
-}
+#include "s2d_kernels.h"
 
 // ------------------------------------------------------------------------------------------
 // kernels
@@ -493,13 +178,6 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
               wave_count(active && res == S2D_RESULT_OUT), wave_count(active && res == S2D_RESULT_TIMEOUT));
 }
 
-// T fused cycles per launch: the 17 state words stay in registers, only the rollout record
-// (obs 40 B + action 4 B + reward 4 B + done 1 B + result 1 B per env-step) streams out.
-static constexpr int64_t kInfinityCacheBytes = 256ll << 20;   // MI355X
-struct RolloutOut {
-  float* obs; void* action; float* reward; uint8_t* done; uint8_t* result;
-  int nt;                                                  // the record is larger than the Infinity Cache: stream it (rec_store)
-};
 
 template <int MODE, bool NOISE>
 __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
@@ -664,23 +342,10 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 // more than kSlots episodes within one launch prepares inline (and publishes through the slot it used
 // longest ago, which every reader has left at least two barriers earlier).
 // The arithmetic is the same functions in the same order as in the unified kernel: results are bit-identical.
-enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_FLAGS, WS_WORDS };
-enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_NPM, WA_NPS, WA_NPC, WA_NBM, WA_NBS, WA_NBC, WA_NTU, WA_WORDS };   // command + prepared noise
-enum { SL_FIRST = 13, SL_DIST = SL_FIRST + S2D_OBS_DIM, SL_REL, SL_WORDS };   // slot = NextEpisode (13 words) + FirstObs (12)
-static constexpr int kSlots = 3;
-// Issue priority of the four role waves of a group (s_setprio): a SIMD holds one wave of each role (of four different
-// groups, profiles/r01/wave_placement.txt) and the arbiter should prefer them by their slack.  Round 1's simulate wave had
-// the longest chain (2/1/1/0); with the dash-only fast path it is the observing waves that have none left -- steady clocks,
-// 65 536 envs x 64 cycles, us per launch, simulate/agent/ball/policy (profiles/r02/ab_prio.txt): 0/0/0/0 51.2, 2/1/1/0 47.9,
-// 1/1/1/0 48.2, 2/2/2/0 48.2, 2/2/1/0 48.0, 3/2/1/0 47.8, 1/2/2/0 46.7; second box: 1/2/2/0 45.9, 1/3/2/0 45.6, 1/2/3/0 46.0,
-// 0/2/2/0 46.8, 1/3/3/0 46.2, 0/1/1/0 46.7, 2/3/3/0 46.0 (noise on: 1/2/2/0 58.7, 0/2/2/0 64.6).  Round 3 re-did the comparison in
-// CLOCKS (s_memtime around each workgroup's loop, 65 536 envs x 256 cycles: independent of the clock level the box happens to
-// run at; the launch lasts as long as the slowest workgroup; profiles/r03/ws_prio_clocks*.txt), median / max over the workgroups:
-// 1/2/2/0 305.9 k / 331.2 k, 1/2/3/0 311.2 k / 322.5 k, 1/3/2/0 325.6 k / 338.8 k, 1/3/3/0 306.0 k / 329.5 k, 2/2/3/0 313.3 k /
-// 333.6 k, 1/1/3/0 313.3 k / 335.1 k, 0/2/3/0 312.0 k / 327.8 k (noise on: 384.9 k -> 383.2 k max) -- four different levels, the
-// ball wave (which streams the observations) on top: no tie is left to the arbiter's oldest-first rule, which favours the
-// workgroups a CU received first.  With noise on the simulating wave is the long one and the policy wave the next: 3/2/2/1
-// (policy last) counts 381.2 k against 386.9 k for 1/2/3/0 (ws_prio_clocks_noise.txt).  Overridable for experiments.
+// Issue priority of the four role waves of a group (s_setprio): a SIMD holds one wave of each role (of four different groups)
+// and the arbiter should prefer them by their slack.  Noise off: simulate / agent / ball / policy = 1/2/3/0 (the ball wave, which
+// streams the observations, on top); noise on: 3/2/2/1.  The sweeps behind these (in us and in clocks): profiles/r03/ws_prio_sweeps.txt.
+// Overridable for experiments.
 #ifndef S2D_PRIO_S
 #define S2D_PRIO_S 1
 #endif
@@ -690,42 +355,6 @@ static constexpr int kSlots = 3;
 #ifndef S2D_PRIO_B
 #define S2D_PRIO_B 3
 #endif
-static constexpr int kWsBlock = 4 * kWave;
-
-// one prepared episode of this lane's env -> LDS slot (struct-of-arrays over the lanes)
-template <bool NOISE>
-S2D_DEV void slot_fill(const S2DHot& p, const S2DRare* __restrict__ rp, float (*slot)[kWave], int lane, uint32_t gl,
-                       uint32_t gh, uint32_t episode) {
-  const S2DRare r = *rp;
-  const NextEpisode q = episode_prepare<NOISE>(p, rp, r, gl, gh, episode);
-  slot[0][lane] = q.px; slot[1][lane] = q.py; slot[2][lane] = q.vx; slot[3][lane] = q.vy; slot[4][lane] = q.body;
-  slot[5][lane] = q.stamina; slot[6][lane] = q.effort; slot[7][lane] = q.recovery; slot[8][lane] = q.capacity;
-  slot[9][lane] = q.bx; slot[10][lane] = q.by; slot[11][lane] = q.bvx; slot[12][lane] = q.bvy;
-  const FirstObs f = first_obs(p, q);
-#pragma unroll
-  for (int k = 0; k < S2D_OBS_DIM; ++k) slot[SL_FIRST + k][lane] = f.o[k];
-  slot[SL_DIST][lane] = f.dist; slot[SL_REL][lane] = f.rel;
-}
-// the prologue's form: the whole wave draws together (reset_sample_coop; `need` = this lane has an env)
-template <bool NOISE>
-S2D_DEV void slot_fill_coop(const S2DHot& p, const S2DRare* __restrict__ rp, float (*slot)[kWave], int lane, uint32_t gl,
-                            uint32_t gh, uint32_t episode, bool need, uint32_t* scratch) {
-  const S2DRare r = *rp;
-  const NextEpisode q = episode_prepare_coop<NOISE>(p, rp, r, gl, gh, episode, need, lane, scratch);
-  const FirstObs f = first_obs(p, q);
-  if (need) {
-    slot[0][lane] = q.px; slot[1][lane] = q.py; slot[2][lane] = q.vx; slot[3][lane] = q.vy; slot[4][lane] = q.body;
-    slot[5][lane] = q.stamina; slot[6][lane] = q.effort; slot[7][lane] = q.recovery; slot[8][lane] = q.capacity;
-    slot[9][lane] = q.bx; slot[10][lane] = q.by; slot[11][lane] = q.bvx; slot[12][lane] = q.bvy;
-#pragma unroll
-    for (int k = 0; k < S2D_OBS_DIM; ++k) slot[SL_FIRST + k][lane] = f.o[k];
-    slot[SL_DIST][lane] = f.dist; slot[SL_REL][lane] = f.rel;
-  }
-}
-S2D_DEV NextEpisode slot_take(const float (*slot)[kWave], int lane) {
-  return NextEpisode{slot[0][lane], slot[1][lane], slot[2][lane], slot[3][lane], slot[4][lane], slot[5][lane], slot[6][lane],
-                     slot[7][lane], slot[8][lane], slot[9][lane], slot[10][lane], slot[11][lane], slot[12][lane]};
-}
 
 // REC: what the kernel knows about the record at compile time.  0: nothing (every array may be absent, `nt` is a run-time flag);
 // 1 / 2: all five arrays are there and the stores are plain / non-temporal.  The presence tests and the nt selection are
@@ -748,7 +377,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
   __shared__ float2 sc_lut[361];                           //   and (sin, cos) of the whole degrees -180 .. 180
   const int lane = threadIdx.x & (kWave - 1);
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 agent, 3 ball
-  const bool nt = REC == 2 || (REC == 0 && ro.nt != 0);
+  const bool nt = REC == 2 || (REC == 0 && ro.nt != 0);     // the small arrays (action, reward, done, result)
+  // (One policy for all five arrays.  In the store pattern alone plain observation stores next to nt done / result stores are 3 %
+  // faster than everything nt -- profiles/r04/store_pattern5.txt -- but in this kernel they are 2-4 % slower: profiles/r04/ab_obs_plain.txt.)
   const int64_t wave_first = (int64_t)blockIdx.x * kWave;
   const int64_t i = wave_first + lane;
   const bool active = i < n;
@@ -1188,6 +819,11 @@ extern "C" void s2d_internal_set_error(const char* msg) { g_err = msg ? msg : ""
       return fail(S2D_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
   } while (0)
 
+// s2d_rollout2.hip (same library, hidden symbol): launches the two-envs-per-lane pipeline if the batch and the record allow it
+extern "C" int s2d_internal_rollout2(int mode, int noise, const S2DHot* hot, const S2DRare* rare_dev, float* S, int64_t stride,
+                                     int64_t n, int n_steps, const void* actions_dev, int kind, const RolloutOut* ro,
+                                     const StepOut* o, void* stream, char* name);
+
 struct S2DEngine {
   S2DConfig cfg;
   S2DHot hot;
@@ -1196,6 +832,9 @@ struct S2DEngine {
   int mode;      // S2D_MODE_*
   bool noise;
   int rollout_ws;  // -1 auto (by batch size), 0 unified kernel, 1 wave-specialised kernel
+  int rollout_e;   // envs per lane of the wave-specialised rollout: 2 (s2d_rollout2.hip, where the batch and the record allow it) or 1
+  int rollout_nt;  // -1 by record size, 0 / 1: plain / non-temporal record stores (experiments)
+  char kernel_name[96];   // full instantiation of the last rollout launch
   int64_t n, stride;
   int device;
   char* arena;
@@ -1385,6 +1024,11 @@ S2D_API int s2d_create(const S2DConfig* cfg, int64_t n_envs, int device, void* a
   h->noise = cfg->noise != 0;
   h->rollout_ws = -1;
   if (const char* v = std::getenv("S2D_ROLLOUT_WS")) h->rollout_ws = std::atoi(v) != 0 ? 1 : 0;
+  // envs per lane of the wave-specialised rollout: 1 (default).  2 = s2d_rollout2.hip: bit-identical, whole-line record stores,
+  // but 2 waves per SIMD at 65 536 envs leave the waves issue-bound: opt-in
+  h->rollout_e = 1; h->rollout_nt = -1; h->kernel_name[0] = 0;
+  if (const char* v = std::getenv("S2D_ROLLOUT_E")) h->rollout_e = std::atoi(v) == 2 ? 2 : 1;
+  if (const char* v = std::getenv("S2D_ROLLOUT_NT")) h->rollout_nt = std::atoi(v) != 0 ? 1 : 0;
   if (arena_dev) {
     if (arena_bytes < L.total) { delete h; return fail(S2D_ENOMEM, "arena smaller than s2d_arena_bytes()"); }
     if (reinterpret_cast<uintptr_t>(arena_dev) & 255u) { delete h; return fail(S2D_EINVAL, "arena must be 256-byte aligned"); }
@@ -1538,7 +1182,7 @@ S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int a
     ro = RolloutOut{out->obs, out->action, out->reward, out->done, out->result, 0};
     const int64_t per_step = (out->obs ? 4 * S2D_OBS_DIM : 0) + (out->action ? (h->mode == S2D_MODE_TURN4 ? 16 : 4) : 0) + (out->reward ? 4 : 0) + (out->done ? 1 : 0) +
                              (out->result ? 1 : 0);
-    ro.nt = (int64_t)n_steps * h->n * per_step > kInfinityCacheBytes;
+    ro.nt = h->rollout_nt >= 0 ? h->rollout_nt : ((int64_t)n_steps * h->n * per_step > kInfinityCacheBytes);
     if (h->cfg.task.use_continuous_action && h->cfg.task.use_turning && (reinterpret_cast<uintptr_t>(out->action) & 15u))
       return fail(S2D_EINVAL, "rollout action buffer float[T][N][4] must be 16-byte aligned");
     if (reinterpret_cast<uintptr_t>(out->obs) & 3u) return fail(S2D_EINVAL, "rollout obs buffer must be 4-byte aligned");
@@ -1555,16 +1199,29 @@ S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int a
       {s2d_reach_rollout_ws_kernel<S2D_MODE_TURN4, false>, s2d_reach_rollout_ws_kernel<S2D_MODE_TURN4, true>}};
   // small batches: four waves per env group (policy | simulate | agent | ball)
   const bool ws = h->rollout_ws < 0 ? (h->n <= kWsMaxEnvs) : (h->rollout_ws != 0);
+  static const char* const mode_names[3] = {"discrete", "continuous", "turning"};
   if (ws) {
+    // two envs per lane (s2d_rollout2.hip) where the batch is a multiple of 128 envs and the record is complete and aligned
+    if (h->rollout_e == 2 && s2d_internal_rollout2(h->mode, h->noise ? 1 : 0, &h->hot, h->rare_dev, reinterpret_cast<float*>(h->buf.player_x),
+                                                   h->stride, h->n, n_steps, actions_dev, action_kind, &ro, &h->out, stream, h->kernel_name)) {
+      HIP_TRY(hipGetLastError());
+      h->last_kernel = h->kernel_name;
+      return S2D_OK;
+    }
     RollK kern_ws = table_ws[h->mode][h->noise ? 1 : 0];
-    if (h->mode == S2D_MODE_DISCRETE && !h->noise && ro.obs && ro.action && ro.reward && ro.done && ro.result)
+    int rec = 0;
+    if (h->mode == S2D_MODE_DISCRETE && !h->noise && ro.obs && ro.action && ro.reward && ro.done && ro.result) {
       kern_ws = ro.nt ? s2d_reach_rollout_ws_kernel<S2D_MODE_DISCRETE, false, 2> : s2d_reach_rollout_ws_kernel<S2D_MODE_DISCRETE, false, 1>;
+      rec = ro.nt ? 2 : 1;
+    }
     hipLaunchKernelGGL(kern_ws, dim3((unsigned)((h->n + kWave - 1) / kWave)),
                        dim3(kWsBlock), 0, static_cast<hipStream_t>(stream), h->hot, h->rare_dev,
                        reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, n_steps, actions_dev, action_kind,
                        ro, h->out);
     HIP_TRY(hipGetLastError());
-    h->last_kernel = "s2d_reach_rollout_ws_kernel";
+    std::snprintf(h->kernel_name, sizeof h->kernel_name, "s2d_reach_rollout_ws_kernel<%s,noise=%d,rec=%d,nt=%d>", mode_names[h->mode],
+                  h->noise ? 1 : 0, rec, ro.nt ? 1 : 0);
+    h->last_kernel = h->kernel_name;
     return S2D_OK;
   }
   hipLaunchKernelGGL(table[h->mode][h->noise ? 1 : 0], dim3(grid_for(h->n)), dim3(kBlock), 0,
@@ -1572,7 +1229,8 @@ S2D_API int s2d_rollout(S2DHandle h, int n_steps, const void* actions_dev, int a
                      reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n, n_steps, actions_dev, action_kind,
                      ro, h->out);
   HIP_TRY(hipGetLastError());
-  h->last_kernel = "s2d_reach_rollout_kernel";
+  std::snprintf(h->kernel_name, sizeof h->kernel_name, "s2d_reach_rollout_kernel<%s,noise=%d>", mode_names[h->mode], h->noise ? 1 : 0);
+  h->last_kernel = h->kernel_name;
   return S2D_OK;
 }
 

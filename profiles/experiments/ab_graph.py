@@ -69,6 +69,10 @@ def main():
     if a.child:
         return child(a)
     res = {}
+
+    def label(lib):                                        # lib/exp/<name>/libs2d_hip.so -> <name>; lib/libs2d_hip.so -> product
+        b, d = label(lib), os.path.basename(os.path.dirname(os.path.abspath(lib)))
+        return b if b != 'libs2d_hip.so' else ('product' if d == 'lib' else d)
     for r in range(a.rounds):
         for T in [int(x) for x in a.fuse.split(',')]:
             for nz in [int(x) for x in a.noise.split(',')]:
@@ -79,11 +83,11 @@ def main():
                     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
                     line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
                     if not line:
-                        print(f'{os.path.basename(lib)} T={T} noise={nz}: FAILED\n{p.stderr[-600:]}', flush=True)
+                        print(f'{label(lib)} T={T} noise={nz}: FAILED\n{p.stderr[-600:]}', flush=True)
                         continue
                     d = json.loads(line[-1])
-                    res.setdefault((os.path.basename(lib), T, nz), []).append(d)
-                    print(f'round {r} {os.path.basename(lib):28s} T={T:4d} noise={nz} {d["us"]:8.2f} us/launch frac={d["frac"]:.3f} checksum={d["checksum"]}', flush=True)
+                    res.setdefault((label(lib), T, nz), []).append(d)
+                    print(f'round {r} {label(lib):28s} T={T:4d} noise={nz} {d["us"]:8.2f} us/launch frac={d["frac"]:.3f} checksum={d["checksum"]}', flush=True)
     print('---- medians over rounds')
     for (lib, T, nz), ds in sorted(res.items(), key=lambda kv: (kv[0][1], kv[0][2], kv[0][0])):
         us = statistics.median(d['us'] for d in ds)
