@@ -17,9 +17,10 @@ dqn_stable_baselines3.py:18-31, uniform random policy drawn in-kernel, reset dis
 reach_ball_env.py:170-218), --envs 4096 = configs[1], --task match (8 192 matches) = configs[3],
 --gpus N --league-exchange = configs[4].  Every other size is named "custom".
 
-Protocol: settle phase, W untimed steps, then R = 5 timed regions of EXACTLY K steps
-each (one hipGraph replay per region, bracketed by barrier + synchronize on both sides, max over
-ranks); `value` is the MEDIAN region, the five figures are kept in `repeats`.  The default record
+Protocol: settle phase, W untimed steps, graph capture, 3 untimed replays (the capture
+leaves the device idle; its clock ramps up again during them), then R = 5 timed regions of EXACTLY
+K steps each (one hipGraph replay per region, bracketed by barrier + synchronize on both sides, max
+over ranks); `value` is the MEDIAN region, the five figures are kept in `repeats`.  The default record
 is written into ROTATING buffers (> 512 MiB in flight, so no line of it can live in the 256 MiB
 Infinity Cache): the headline is the pure-HBM figure; the one-buffer figure is in `secondary`.
 
@@ -304,11 +305,20 @@ def graph_of(issue):
     return g
 
 
-def timed_regions(run, repeats, stream, dist, dev):
+WARM_REGIONS = 3
+
+
+def timed_regions(run, repeats, stream, dist, dev, warm_regions=WARM_REGIONS):
     """`repeats` timed regions of one `run()` each: barrier + synchronize on both sides, wall clock and ONE HIP event pair on the
-    launch stream per region.  Returns (wall seconds per region, max over ranks; event seconds per region, this rank)."""
+    launch stream per region.  Returns (wall seconds per region, max over ranks; event seconds per region, this rank).
+    `warm_regions` untimed runs come first: capturing the graph leaves the device idle for tens of milliseconds and its clock ramps
+    up again over the next ~10 ms of load -- round 3's five timed regions of every line rose monotonically (87 -> 102 G) because the
+    first two were that ramp, not the kernel."""
     import torch
     wall, evs = [], []
+    for _ in range(max(0, warm_regions)):
+        run()
+    torch.cuda.synchronize()
     for _ in range(repeats):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if dist is not None:
@@ -390,7 +400,7 @@ def n_rotating(per_buf_bytes):
     return max(2, -(-(600 << 20) // per_buf_bytes))
 
 
-def measure_rollout(eng, T, launches, nbuf, repeats, stream, settle_ms, dist=None, dev=None, warm=4):
+def measure_rollout(eng, T, launches, nbuf, repeats, stream, settle_ms, dist=None, dev=None, warm=4, warm_regions=WARM_REGIONS):
     """`repeats` regions of `launches` rollout launches of T cycles each, cycling through nbuf record buffers.
     Returns dict(value-free raw figures): median wall / event seconds per launch, the per-region figures."""
     n = eng.num_envs
@@ -405,7 +415,7 @@ def measure_rollout(eng, T, launches, nbuf, repeats, stream, settle_ms, dist=Non
     import torch
     torch.cuda.synchronize()
     g = graph_of(lambda: issue(launches))
-    wall, evs = timed_regions(g.replay, repeats, stream, dist, dev)
+    wall, evs = timed_regions(g.replay, repeats, stream, dist, dev, warm_regions)
     alg = n * (2 * STATE_BYTES + T * RECORD_BYTES)
     return {'wall': wall, 'events': evs, 'launch_s': median_of(wall) / launches, 'launch_s_events': median_of(evs) / launches,
             'alg_bytes_launch': alg, 'launches': launches, 'buffers': nbuf, 'bytes_in_flight': nbuf * T * n * RECORD_BYTES}
@@ -580,7 +590,7 @@ def run_reach(args, dev, dist, rank, world):
     cold = None
     if default_line:
         # the cold figure: the first GPU work of this process -- 4 warm-up launches, one region of 20, no settle phase
-        m = measure_rollout(eng, T, 20, 1, 1, stream, 0.0)
+        m = measure_rollout(eng, T, 20, 1, 1, stream, 0.0, warm_regions=0)
         cold = rollout_entry(m, n, T, eng.kernel_name(), None)
         cold['settle_ms'] = 0
 

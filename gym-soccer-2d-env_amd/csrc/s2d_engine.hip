@@ -356,6 +356,20 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 #define S2D_PRIO_B 3
 #endif
 
+// experiment build (-DS2D_STAMPS): per role wave, the busy clocks (barrier release -> arrival at the next barrier), the clocks of its
+// whole loop and the 100 MHz real-time stamps of its begin and end, written by lane 0 into terminal_obs row wave_first + 2 * role
+#ifdef S2D_STAMPS
+#define WS_STAMP_DECL uint64_t st_busy = 0, st_t0 = __builtin_amdgcn_s_memtime(); const uint64_t st_begin = st_t0, st_rt0 = __builtin_amdgcn_s_memrealtime()
+#define WS_BARRIER() do { st_busy += __builtin_amdgcn_s_memtime() - st_t0; __syncthreads(); st_t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define WS_STAMP_STORE() do { if (lane == 0) { float* q_ = o.terminal_obs + (wave_first + 2 * role) * S2D_OBS_DIM; \
+    q_[0] = (float)st_busy; q_[1] = (float)(__builtin_amdgcn_s_memtime() - st_begin); q_[2] = (float)(st_rt0 & 0xffffff); \
+    q_[3] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffff); } } while (0)
+#else
+#define WS_STAMP_DECL do {} while (0)
+#define WS_BARRIER() __syncthreads()
+#define WS_STAMP_STORE() do {} while (0)
+#endif
+
 // REC: what the kernel knows about the record at compile time.  0: nothing (every array may be absent, `nt` is a run-time flag);
 // 1 / 2: all five arrays are there and the stores are plain / non-temporal.  The presence tests and the nt selection are
 // wave-uniform branches, eleven of them per cycle in the two waves that store -- and those are the long waves when noise is off:
@@ -423,6 +437,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       act_lut[lane] = make_float4(c.power, c.dir, c.dir_rate, d0);
     }
     __syncthreads();                                       // prepared episodes published
+    WS_STAMP_DECL;
     for (int s = 0; s < n_iter; ++s) {
       if (s < n_steps && active) {
         const uint32_t k = k0 + (uint32_t)s;
@@ -450,8 +465,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         }
         row += n;
       }
-      __syncthreads();
+      WS_BARRIER();
     }
+    WS_STAMP_STORE();
     if (active) {
       if (use_k) kplane[i] = k0 + (uint32_t)n_steps;
       o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
@@ -499,6 +515,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       }
     }
     __syncthreads();                                       // prepared episodes (and this wave's tables) published
+    WS_STAMP_DECL;
     auto loop = [&](auto fast_tag) {
       constexpr bool FAST = decltype(fast_tag)::value;
       auto simulate_iteration = [&](int s, auto steady_tag) {   // (three stretches: see the ball wave)
@@ -537,7 +554,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
             nth += 1; j = (j + 1 == kSlots) ? 0 : j + 1;
           }
         }
-        __syncthreads();
+        WS_BARRIER();
       };
       int s = 0;
       for (; s < 1 && s < n_iter; ++s) simulate_iteration(s, std::false_type{});
@@ -553,6 +570,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     } else {
       loop(std::false_type{});
     }
+    WS_STAMP_STORE();
     if (active) {                                          // prev_dist / prev_angle belong to the A-wave
       S[F_PX * stride + i] = e.px; S[F_PY * stride + i] = e.py;
       S[F_VX * stride + i] = e.vx; S[F_VY * stride + i] = e.vy;
@@ -583,6 +601,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
     int64_t row = 0;
     __syncthreads();                                       // prepared episodes published
+    WS_STAMP_DECL;
     auto agent_iteration = [&](int s, auto steady_tag) {   // (three stretches: see the ball wave)
       constexpr bool STEADY = decltype(steady_tag)::value;
       if (STEADY || (s >= 2 && s < n_steps + 2)) {         // step s - 2
@@ -617,7 +636,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         }
         row += n;
       }
-      __syncthreads();
+      WS_BARRIER();
     };
     {
       int s = 0;
@@ -625,6 +644,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       for (; s < n_steps + 2; ++s) agent_iteration(s, std::true_type{});
       for (; s < n_iter; ++s) agent_iteration(s, std::false_type{});
     }
+    WS_STAMP_STORE();
     if (active) {
       S[F_PREV_DIST * stride + i] = prev_dist; S[F_PREV_ANGLE * stride + i] = prev_angle;
       o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
@@ -650,6 +670,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     const bool obs_all_vec = valid == kObsTile && ((n * S2D_OBS_DIM * 4) & 15) == 0 &&
                              (reinterpret_cast<uintptr_t>(ro.obs + wave_first * S2D_OBS_DIM) & 15u) == 0;
     __syncthreads();                                       // prepared episodes published
+    WS_STAMP_DECL;
     // The loop in three stretches: filling (s < 3), steady (3 <= s < n_steps + 2: every stage of the pipeline has work, the range tests
     // are compiled out -- wave-uniform branches the long waves pay for in every cycle) and draining.  One barrier per iteration in all.
     auto ball_iteration = [&](int s, auto steady_tag) {
@@ -675,7 +696,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           for (int k = 4; k < S2D_OBS_DIM; ++k) t[k] = ob6[k];
         }
       }
-      __syncthreads();
+      WS_BARRIER();
     };
     {
       int s = 0;
@@ -683,6 +704,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
       for (; s < n_steps + 2; ++s) ball_iteration(s, std::true_type{});
       for (; s < n_iter; ++s) ball_iteration(s, std::false_type{});
     }
+    WS_STAMP_STORE();
     if (active) {
 #pragma unroll
       for (int k = 4; k < S2D_OBS_DIM; ++k) o.obs[i * S2D_OBS_DIM + k] = ob6[k];   // last observation, ball half

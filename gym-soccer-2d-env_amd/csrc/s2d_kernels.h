@@ -195,6 +195,21 @@ S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int ki
   return cmd_prepare(p, cmd, power, dir);
 }
 
+// action -> decoded command with the command-only half of the dash (decide() without the load and the store: for callers that
+// keep the action, e.g. to park it for a storing wave)
+template <int MODE>
+S2D_DEV CmdPrep decode_action(const S2DHot& p, const Action4& a, uint32_t gl, uint32_t gh, uint32_t k, bool refresh, U4& squad,
+                              int& cmd, float& dir) {
+  float u = 0.0f;
+  if (MODE == S2D_MODE_TURN4) {                            // reach_ball_env.py:71
+    if (refresh) squad = policy_quad(p, gl, gh, k, S2D_ST_SELECT);
+    u = rnd_u01(quad_word(squad, k));
+  }
+  float power;
+  action_map<MODE>(p, a, u, cmd, power, dir);
+  return cmd_prepare(p, cmd, power, dir);
+}
+
 // Prepared reset samples of one wave (LDS, struct-of-arrays over the 64 lanes).  The sample of
 // an env's NEXT episode depends only on (gid, cycle at which the current episode began), so a
 // rollout kernel draws them for many lanes at once -- a full wave at launch, then whenever

@@ -83,20 +83,6 @@ S2D_DEV void load_action2(const void* __restrict__ actions, int kind, int64_t id
     a0 = Action4{v.x, v.y, v.z, v.w}; a1 = Action4{w.x, w.y, w.z, w.w};
   }
 }
-// action -> decoded command with the command-only half of the dash (decide() of s2d_kernels.h without the load and the store)
-template <int MODE>
-S2D_DEV CmdPrep decode_action(const S2DHot& p, const Action4& a, uint32_t gl, uint32_t gh, uint32_t k, bool refresh, U4& squad,
-                              int& cmd, float& dir) {
-  float u = 0.0f;
-  if (MODE == S2D_MODE_TURN4) {                            // reach_ball_env.py:71
-    if (refresh) squad = policy_quad(p, gl, gh, k, S2D_ST_SELECT);
-    u = rnd_u01(quad_word(squad, k));
-  }
-  float power;
-  action_map<MODE>(p, a, u, cmd, power, dir);
-  return cmd_prepare(p, cmd, power, dir);
-}
-
 // experiment build (-DS2D_STAMPS): busy clocks of every role wave (barrier release -> arrival at the next barrier) and the clocks of
 // its whole loop, written by lane 0 into the terminal_obs rows of the group's first envs (role r: row first + 2 r, words 0 / 1)
 #ifdef S2D_STAMPS

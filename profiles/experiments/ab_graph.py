@@ -71,7 +71,7 @@ def main():
     res = {}
 
     def label(lib):                                        # lib/exp/<name>/libs2d_hip.so -> <name>; lib/libs2d_hip.so -> product
-        b, d = label(lib), os.path.basename(os.path.dirname(os.path.abspath(lib)))
+        b, d = os.path.basename(lib), os.path.basename(os.path.dirname(os.path.abspath(lib)))
         return b if b != 'libs2d_hip.so' else ('product' if d == 'lib' else d)
     for r in range(a.rounds):
         for T in [int(x) for x in a.fuse.split(',')]:
