@@ -376,13 +376,17 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 // with them compiled out the slowest workgroup of a 256-cycle launch counts 296 k clocks instead of 321 k
 // (profiles/r03/ws_static_record.txt).  Instantiated for the discrete-action, noise-off configuration (the DQN script's).
 template <int MODE, bool NOISE, int REC = 0>
-__global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
+__global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
                                                                         float* __restrict__ S, int64_t stride,
                                                                         int64_t n, int n_steps,
                                                                         const void* __restrict__ actions, int kind,
                                                                         RolloutOut ro, StepOut o) {
   constexpr int kActWords = NOISE ? (int)WA_WORDS : (int)WA_NPM;
-  __shared__ float act[2][kActWords][kWave];               // decoded command (+ prepared noise) of step t, double-buffered
+  // decoded command (+ prepared noise) of step t in slot t mod 3: the policy wave runs TWO steps ahead of the simulating wave, which
+  // fetches the command of its NEXT step at the start of an iteration and, at the iteration's end -- when the body angle after a
+  // possible reset is known --, issues the two table reads that depend on it (dash fast path), so that an iteration starts on
+  // registers: ~200 clocks of LDS round trips off the longest chain of the group (profiles/r04/ws_stamps_prefetch.txt)
+  __shared__ float act[3][kActWords][kWave];
   __shared__ float snap[2][WS_WORDS][kWave];               // post-cycle snapshot of step t, double-buffered
   __shared__ float slots[kSlots][SL_WORDS][kWave];         // prepared episodes first_ep + k of every lane (see above)
   __shared__ __attribute__((aligned(16))) float tile[2][kObsTile];   // observation rows of step t, double-buffered
@@ -438,26 +442,27 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
     }
     __syncthreads();                                       // prepared episodes published
     WS_STAMP_DECL;
-    for (int s = 0; s < n_iter; ++s) {
-      if (s < n_steps && active) {
-        const uint32_t k = k0 + (uint32_t)s;
+    int wslot = 0;                                         // ring slot of the step computed next (step mod 3)
+    auto policy_step = [&](int t) {                        // command of step t -> act[t mod 3]
+      if (active) {
+        const uint32_t k = k0 + (uint32_t)t;
         CmdPrep c;
         if (lut) {
-          if (s == 0 || (k & 3u) == 0u) quad = policy_quad(p, gl, gh, k, S2D_ST_POLICY);
+          if (t == 0 || (k & 3u) == 0u) quad = policy_quad(p, gl, gh, k, S2D_ST_POLICY);
           const int a = (int)rnd_below(quad_word(quad, k), (uint32_t)p.n_actions);
           if (REC != 0 || ro.action) rec_store(static_cast<int32_t*>(ro.action) + row + i, (int32_t)a, nt);
           const float4 e4 = act_lut[a];
           c = CmdPrep{e4.x, e4.y, e4.z}; dir = e4.w; cmd = S2D_CMD_DASH;
         } else {
-          c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, s == 0 || (k & 3u) == 0u, quad, squad, ro.action, cmd, dir);
+          c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, t == 0 || (k & 3u) == 0u, quad, squad, ro.action, cmd, dir);
         }
-        const int b = s & 1;
+        const int b = wslot;
         if (MODE == S2D_MODE_TURN4) act[b][WA_CMD][lane] = __int_as_float(cmd);
         act[b][WA_POWER][lane] = c.power;
         act[b][WA_DIR][lane] = c.dir; act[b][WA_RATE][lane] = c.dir_rate;
         if constexpr (NOISE) {                             // the state-independent half of this cycle's noise; the sine / cosine of
           // the whole-degree directions are entries of the table the simulating wave built before the first barrier
-          const NoiseWords nw = noise_words(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN, nblk, s == 0 || (k & 1u) == 0u);
+          const NoiseWords nw = noise_words(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN, nblk, t == 0 || (k & 1u) == 0u);
           const float2 ps = sc_lut[noise_dir_index(nw.wp)], bs = sc_lut[noise_dir_index(nw.wb)];
           act[b][WA_NPM][lane] = noise_mag(nw.wp); act[b][WA_NPS][lane] = ps.x; act[b][WA_NPC][lane] = ps.y;
           act[b][WA_NBM][lane] = noise_mag(nw.wb); act[b][WA_NBS][lane] = bs.x; act[b][WA_NBC][lane] = bs.y;
@@ -465,6 +470,11 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         }
         row += n;
       }
+      wslot = wslot == 2 ? 0 : wslot + 1;
+    };
+    for (int s = 0; s < n_iter; ++s) {                     // iteration s: step s + 1 (iteration 0: steps 0 and 1)
+      if (s == 0 && n_steps > 0) policy_step(0);
+      if (s + 1 < n_steps) policy_step(s + 1);
       WS_BARRIER();
     }
     WS_STAMP_STORE();
@@ -514,30 +524,54 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
         sc_lut[k] = make_float2(sn, cs);
       }
     }
+    const ResetStamina rst = reset_stamina(p, rp);         // what every reset leaves in the stamina words (not kept in the slots)
     __syncthreads();                                       // prepared episodes (and this wave's tables) published
     WS_STAMP_DECL;
     auto loop = [&](auto fast_tag) {
       constexpr bool FAST = decltype(fast_tag)::value;
-      auto simulate_iteration = [&](int s, auto steady_tag) {   // (three stretches: see the ball wave)
+      struct ActRegs { float cmd, power, dir, rate, npm, nps, npc, nbm, nbs, nbc, ntu; };
+      ActRegs cur{}, nxt{};                                // command of the step simulated in this iteration / in the next one
+      float ep_cur = 0.0f; float2 sc_cur = make_float2(0.0f, 0.0f);   // dash fast path: the two table entries of `cur`
+      int rslot = 1;                                       // ring slot of the step fetched next (wave-uniform; step 0 is fetched by the filling iteration)
+      auto fetch = [&](int slot) {
+        ActRegs r{};
+        if (MODE == S2D_MODE_TURN4) r.cmd = act[slot][WA_CMD][lane];
+        if (!FAST) r.power = act[slot][WA_POWER][lane];
+        r.dir = act[slot][WA_DIR][lane]; r.rate = act[slot][WA_RATE][lane];
+        if constexpr (NOISE) {
+          r.npm = act[slot][WA_NPM][lane]; r.nps = act[slot][WA_NPS][lane]; r.npc = act[slot][WA_NPC][lane];
+          r.nbm = act[slot][WA_NBM][lane]; r.nbs = act[slot][WA_NBS][lane]; r.nbc = act[slot][WA_NBC][lane];
+          if (MODE == S2D_MODE_TURN4) r.ntu = act[slot][WA_NTU][lane];
+        }
+        return r;
+      };
+      auto lookups = [&]() {                               // what the dash of `cur` needs of the CURRENT state (after a possible reset)
+        if constexpr (FAST) {
+          ep_cur = ep_lds[e.step_number];                  // effort * power of the dash at this step number
+          sc_cur = sc_lut[(int)norm_deg(e.body + cur.dir) + 180];
+        }
+      };
+      // stretches: s = 1 fills (fetches its own command: the one exposed round trip), 2 <= s < n_steps steady, s = n_steps has no next step
+      auto simulate_iteration = [&](int s, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         if ((STEADY || (s >= 1 && s <= n_steps)) && active) {   // step s - 1
+          if (!STEADY && s == 1) { cur = fetch(0); lookups(); }
+          const bool more = STEADY || s < n_steps;
+          if (more) nxt = fetch(rslot);                    // step s: lands while step s - 1 is computed
           const int b = (s - 1) & 1;
           int cmd = S2D_CMD_DASH;                          // only the turning mode has another command
-          if (MODE == S2D_MODE_TURN4) cmd = __float_as_int(act[b][WA_CMD][lane]);
+          if (MODE == S2D_MODE_TURN4) cmd = __float_as_int(cur.cmd);
           NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
           if constexpr (NOISE) {
-            nz = NoiseIn{act[b][WA_NPM][lane], act[b][WA_NPS][lane], act[b][WA_NPC][lane], act[b][WA_NBM][lane],
-                         act[b][WA_NBS][lane], act[b][WA_NBC][lane], 0.0f};
-            if (MODE == S2D_MODE_TURN4) nz.tu = act[b][WA_NTU][lane];
+            nz = NoiseIn{cur.npm, cur.nps, cur.npc, cur.nbm, cur.nbs, cur.nbc, 0.0f};
+            if (MODE == S2D_MODE_TURN4) nz.tu = cur.ntu;
           }
           float d2;
           if constexpr (FAST) {
-            const float ep = ep_lds[e.step_number];        // effort * power of the dash at this step number
-            const float2 sc = sc_lut[(int)norm_deg(e.body + act[b][WA_DIR][lane]) + 180];
             e.step_number += 1;                            // reach_ball_env.py:55
-            d2 = sim_cycle_dash_fast<NOISE>(p, rp, e, ep, act[b][WA_RATE][lane], sc.x, sc.y, nz);
+            d2 = sim_cycle_dash_fast<NOISE>(p, rp, e, ep_cur, cur.rate, sc_cur.x, sc_cur.y, nz);
           } else {
-            const CmdPrep c{act[b][WA_POWER][lane], act[b][WA_DIR][lane], act[b][WA_RATE][lane]};
+            const CmdPrep c{cur.power, cur.dir, cur.rate};
             e.step_number += 1;                            // reach_ball_env.py:55
             d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);
           }
@@ -550,15 +584,17 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws_kernel(S2DHot p
           if (took) {                                      // rare: the prepared episode is a copy
             if (nth >= kSlots)                             // more than kSlots episodes ended in this launch: prepare inline
               slot_fill<NOISE>(p, rp, slots[j], lane, gl, gh, (uint32_t)e.episode + 1u);
-            episode_begin(e, slot_take(slots[j], lane));
+            episode_begin(e, slot_take<kWave>(slots[j], lane, rst));
             nth += 1; j = (j + 1 == kSlots) ? 0 : j + 1;
           }
+          if (more) { cur = nxt; lookups(); }              // in flight across the barrier
         }
+        if (STEADY || (s >= 1 && s < n_steps)) rslot = rslot == 2 ? 0 : rslot + 1;   // (wave-uniform, also for lanes without an env)
         WS_BARRIER();
       };
       int s = 0;
-      for (; s < 1 && s < n_iter; ++s) simulate_iteration(s, std::false_type{});
-      for (; s <= n_steps; ++s) simulate_iteration(s, std::true_type{});
+      for (; s < 2 && s < n_iter; ++s) simulate_iteration(s, std::false_type{});
+      for (; s < n_steps; ++s) simulate_iteration(s, std::true_type{});
       for (; s < n_iter; ++s) simulate_iteration(s, std::false_type{});
     };
     if (fast) {

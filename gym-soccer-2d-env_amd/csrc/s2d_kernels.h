@@ -351,23 +351,41 @@ struct RolloutOut {
 
 enum { WS_PX, WS_PY, WS_BODY, WS_BX, WS_BY, WS_BVX, WS_BVY, WS_FLAGS, WS_WORDS };
 enum { WA_CMD, WA_POWER, WA_DIR, WA_RATE, WA_NPM, WA_NPS, WA_NPC, WA_NBM, WA_NBS, WA_NBC, WA_NTU, WA_WORDS };   // command + prepared noise
-enum { SL_FIRST = 13, SL_DIST = SL_FIRST + S2D_OBS_DIM, SL_REL, SL_WORDS };   // slot = NextEpisode (13 words) + FirstObs (12)
+// A prepared episode in LDS: the nine words of the post-reset state that depend on the draw (player x, y, vx, vy, body; ball x, y,
+// vx, vy -- the player's velocity is +0 or, after a collision in the reset's cycle, -0) + the first observation and the reward carry.
+// The four stamina words a reset leaves behind are the same for every episode (recover, then one update_stamina): reset_stamina().
+enum { SL_BX = 5, SL_FIRST = 9, SL_DIST = SL_FIRST + S2D_OBS_DIM, SL_REL, SL_WORDS };
 static constexpr int kSlots = 3;
 static constexpr int kWsBlock = 4 * kWave;
 
-// one prepared episode of this lane's env -> LDS slot (struct-of-arrays over the lanes)
+struct ResetStamina { float stamina, effort, recovery, capacity; };
+S2D_DEV ResetStamina reset_stamina(const S2DHot& p, const S2DRare* __restrict__ rp) {   // reset_apply()'s stamina block, one cycle later
+  Env t{};
+  t.stamina = p.stamina_max; t.recovery = rp->recover_init; t.effort = p.effort_init; t.capacity = p.stamina_capacity;
+  update_stamina(p, t);
+  return ResetStamina{t.stamina, t.effort, t.recovery, t.capacity};
+}
+// slot rows are `W` floats wide (64 envs per workgroup, or 128); col = this env's column
+template <int W>
+S2D_DEV void slot_put(float (*slot)[W], int col, const NextEpisode& q, const FirstObs& f) {
+  slot[0][col] = q.px; slot[1][col] = q.py; slot[2][col] = q.vx; slot[3][col] = q.vy; slot[4][col] = q.body;
+  slot[SL_BX][col] = q.bx; slot[SL_BX + 1][col] = q.by; slot[SL_BX + 2][col] = q.bvx; slot[SL_BX + 3][col] = q.bvy;
+#pragma unroll
+  for (int k = 0; k < S2D_OBS_DIM; ++k) slot[SL_FIRST + k][col] = f.o[k];
+  slot[SL_DIST][col] = f.dist; slot[SL_REL][col] = f.rel;
+}
+template <int W>
+S2D_DEV NextEpisode slot_take(const float (*slot)[W], int col, const ResetStamina& st) {
+  return NextEpisode{slot[0][col], slot[1][col], slot[2][col], slot[3][col], slot[4][col], st.stamina, st.effort, st.recovery, st.capacity,
+                     slot[SL_BX][col], slot[SL_BX + 1][col], slot[SL_BX + 2][col], slot[SL_BX + 3][col]};
+}
+// one prepared episode of this lane's env -> LDS slot
 template <bool NOISE>
 S2D_DEV void slot_fill(const S2DHot& p, const S2DRare* __restrict__ rp, float (*slot)[kWave], int lane, uint32_t gl,
                        uint32_t gh, uint32_t episode) {
   const S2DRare r = *rp;
   const NextEpisode q = episode_prepare<NOISE>(p, rp, r, gl, gh, episode);
-  slot[0][lane] = q.px; slot[1][lane] = q.py; slot[2][lane] = q.vx; slot[3][lane] = q.vy; slot[4][lane] = q.body;
-  slot[5][lane] = q.stamina; slot[6][lane] = q.effort; slot[7][lane] = q.recovery; slot[8][lane] = q.capacity;
-  slot[9][lane] = q.bx; slot[10][lane] = q.by; slot[11][lane] = q.bvx; slot[12][lane] = q.bvy;
-  const FirstObs f = first_obs(p, q);
-#pragma unroll
-  for (int k = 0; k < S2D_OBS_DIM; ++k) slot[SL_FIRST + k][lane] = f.o[k];
-  slot[SL_DIST][lane] = f.dist; slot[SL_REL][lane] = f.rel;
+  slot_put<kWave>(slot, lane, q, first_obs(p, q));
 }
 // the prologue's form: the whole wave draws together (reset_sample_coop; `need` = this lane has an env)
 template <bool NOISE>
@@ -376,16 +394,5 @@ S2D_DEV void slot_fill_coop(const S2DHot& p, const S2DRare* __restrict__ rp, flo
   const S2DRare r = *rp;
   const NextEpisode q = episode_prepare_coop<NOISE>(p, rp, r, gl, gh, episode, need, lane, scratch);
   const FirstObs f = first_obs(p, q);
-  if (need) {
-    slot[0][lane] = q.px; slot[1][lane] = q.py; slot[2][lane] = q.vx; slot[3][lane] = q.vy; slot[4][lane] = q.body;
-    slot[5][lane] = q.stamina; slot[6][lane] = q.effort; slot[7][lane] = q.recovery; slot[8][lane] = q.capacity;
-    slot[9][lane] = q.bx; slot[10][lane] = q.by; slot[11][lane] = q.bvx; slot[12][lane] = q.bvy;
-#pragma unroll
-    for (int k = 0; k < S2D_OBS_DIM; ++k) slot[SL_FIRST + k][lane] = f.o[k];
-    slot[SL_DIST][lane] = f.dist; slot[SL_REL][lane] = f.rel;
-  }
-}
-S2D_DEV NextEpisode slot_take(const float (*slot)[kWave], int lane) {
-  return NextEpisode{slot[0][lane], slot[1][lane], slot[2][lane], slot[3][lane], slot[4][lane], slot[5][lane], slot[6][lane],
-                     slot[7][lane], slot[8][lane], slot[9][lane], slot[10][lane], slot[11][lane], slot[12][lane]};
+  if (need) slot_put<kWave>(slot, lane, q, f);
 }

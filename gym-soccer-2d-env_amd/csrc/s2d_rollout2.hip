@@ -49,20 +49,6 @@ template <bool NT> S2D_DEV void rec_f32x4(float4* p, const float4& v) {
   else *p = v;
 }
 
-// one prepared episode of env `col` of the group -> LDS slot (struct-of-arrays over the 128 envs)
-S2D_DEV void slot2_put(float (*slot)[kGroup], int col, const NextEpisode& q, const FirstObs& f) {
-  slot[0][col] = q.px; slot[1][col] = q.py; slot[2][col] = q.vx; slot[3][col] = q.vy; slot[4][col] = q.body;
-  slot[5][col] = q.stamina; slot[6][col] = q.effort; slot[7][col] = q.recovery; slot[8][col] = q.capacity;
-  slot[9][col] = q.bx; slot[10][col] = q.by; slot[11][col] = q.bvx; slot[12][col] = q.bvy;
-#pragma unroll
-  for (int k = 0; k < S2D_OBS_DIM; ++k) slot[SL_FIRST + k][col] = f.o[k];
-  slot[SL_DIST][col] = f.dist; slot[SL_REL][col] = f.rel;
-}
-S2D_DEV NextEpisode slot2_take(const float (*slot)[kGroup], int col) {
-  return NextEpisode{slot[0][col], slot[1][col], slot[2][col], slot[3][col], slot[4][col], slot[5][col], slot[6][col],
-                     slot[7][col], slot[8][col], slot[9][col], slot[10][col], slot[11][col], slot[12][col]};
-}
-
 // the caller's actions of the pair at row offset idx (even) -- layouts of include/s2d.h
 template <int MODE>
 S2D_DEV void load_action2(const void* __restrict__ actions, int kind, int64_t idx, Action4& a0, Action4& a1) {
@@ -141,7 +127,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws2_kernel(S2DHot 
       const uint64_t gid = gid0 + (uint64_t)e;
       const NextEpisode q = episode_prepare_coop<NOISE>(p_sgpr, rp, r, (uint32_t)gid, (uint32_t)(gid >> 32),
                                                         (e ? ep0.y : ep0.x) + 1u + (uint32_t)k, true, lane, scratch);
-      slot2_put(slots[k], col + e, q, first_obs(p_sgpr, q));
+      slot_put<kGroup>(slots[k], col + e, q, first_obs(p_sgpr, q));
     }
   }
 
@@ -288,6 +274,7 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws2_kernel(S2DHot 
         sc_lut[k] = make_float2(sn, cs);
       }
     }
+    const ResetStamina rst = reset_stamina(p, rp);         // what every reset leaves in the stamina words (not kept in the slots)
     __syncthreads();                                       // prepared episodes (and this wave's tables) published
     WS2_STAMP_DECL;
     auto loop = [&](auto fast_tag) {
@@ -338,9 +325,9 @@ __global__ __launch_bounds__(kWsBlock) void s2d_reach_rollout_ws2_kernel(S2DHot 
               if (nth[q] >= kSlots) {                      // more than kSlots episodes ended in this launch: prepare inline
                 const S2DRare r = *rp;
                 const NextEpisode ne = episode_prepare<NOISE>(p, rp, r, gl[q], gh[q], (uint32_t)e[q].episode + 1u);
-                slot2_put(slots[j[q]], col + q, ne, first_obs(p, ne));
+                slot_put<kGroup>(slots[j[q]], col + q, ne, first_obs(p, ne));
               }
-              episode_begin(e[q], slot2_take(slots[j[q]], col + q));
+              episode_begin(e[q], slot_take<kGroup>(slots[j[q]], col + q, rst));
               nth[q] += 1; j[q] = (j[q] + 1 == kSlots) ? 0 : j[q] + 1;
             }
           }

@@ -61,6 +61,10 @@ class HookRuntime:
         cfg = make_config(seed=seed, auto_reset=False, noise=noise, server_params=server_params, use_continuous_action=False,
                           action_space_size=16, max_steps=2000000000, min_distance_to_ball=0.0)
         self.engine = Engine(n, device, cfg=cfg)
+        # Connect state of every instance = what s2d_create leaves behind (s2d_init_kernel): a player that has just joined -- full
+        # stamina, effort / recovery / capacity at their initial values (rcssserver's state after a (recover)), at rest at the
+        # centre spot with body 0, the ball beside it.  A task whose trainer_reset_actions() omits do_recover or do_move_player
+        # is legal against rcssserver and starts from this state here (tests/test_gpu_dropin.py::test_hook_env_without_recover).
         self.n = n
         self._cmd = np.zeros((n, 4), dtype=np.float32)
         self.states = [None] * n

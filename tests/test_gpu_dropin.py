@@ -613,6 +613,36 @@ def test_reference_style_hook_env_equals_the_fused_task():
     env.close()
 
 
+def test_hook_env_without_recover():
+    """A hook task whose trainer_reset_actions() only moves the ball (no do_move_player, no do_recover) is legal against rcssserver,
+    where a player that has just connected has full stamina.  On the hook path it starts from the engine's connect state: a Dash
+    must move the player, and stamina must be spent and recovered by the stamina model."""
+    import service_pb2 as pb2
+    from hook_reach_ball import HookReachBall
+
+    class BallOnly(HookReachBall):
+        def trainer_reset_actions(self):
+            self.steps = 0
+            return [pb2.TrainerAction(do_move_ball=pb2.DoMoveBall(position=pb2.RpcVector2D(x=20.0, y=5.0),
+                                                                  velocity=pb2.RpcVector2D(x=0.0, y=0.0)))]
+
+    env = BallOnly(noise=False)
+    env.reset()
+    eng = env._hooks.engine
+    torch.cuda.synchronize()
+    sp = eng.cfg.sp
+    assert float(eng.stamina[0]) == sp.stamina_max and float(eng.effort[0]) == sp.effort_init and float(eng.recovery[0]) == sp.recover_init
+    assert float(eng.player_x[0]) == 0.0 and float(eng.player_vx[0]) == 0.0 and float(eng.ball_x[0]) == 20.0
+    obs, rew, done, info = env.step(8)                     # Dash(100, 0 deg)
+    torch.cuda.synchronize()
+    assert float(eng.player_x[0]) > 0.5 and float(eng.player_vx[0]) > 0.2          # 0.6 m, then decayed to 0.24 m per cycle
+    assert sp.stamina_max - 100.0 < float(eng.stamina[0]) < sp.stamina_max           # -100 at the command, +45 at the cycle's end
+    for _ in range(5):
+        obs, rew, done, info = env.step(8)
+    assert float(eng.player_x[0]) > 4.0 and rew > 0.5 and not done
+    env.close()
+
+
 def test_hook_vec_env_instances_keep_their_own_clocks():
     """HookVecEnv: several instances of a hook-based env on ONE engine.  An instance that resets consumes its command-less cycle
     while the others are frozen, so every instance sees exactly what it sees when it runs alone (same reset draws, same actions)."""
