@@ -58,6 +58,10 @@ MATCH_STATE_BYTES, MATCH_RECORD_BYTES = 23 * 11 * 4 + 15 * 4, 24 * 5 * 4 + 4 + 4
 VALU_PEAK_GINSTR = 256 * 4 / 1.08
 DQN_KWARGS = dict(change_ball_position=True, change_ball_velocity=True, min_distance_to_ball=5.0,
                   max_steps=200, use_continuous_action=False, action_space_size=16, use_turning=False)
+# ddpg_stable_baselines3.py:18-31 (1-D continuous actions, ball at rest at the centre spot); the 4-D turning mode = the same with use_turning
+DDPG_KWARGS = dict(change_ball_position=False, change_ball_velocity=False, ball_position_x=0, ball_position_y=0, ball_speed=0,
+                   ball_direction=0, min_distance_to_ball=5.0, max_steps=200, action_space_size=16, use_continuous_action=True,
+                   use_turning=False)
 REPEATS = 5
 
 
@@ -84,6 +88,9 @@ def parse(argv=None):
                     help='match task: spread = every match starts at its own match time (restarts do not coincide); lockstep = all at 0')
     ap.add_argument('--league-exchange', action='store_true',
                     help='configs[4]: every launch writes a slab that is all-gathered over the ranks (RCCL) on a side stream')
+    ap.add_argument('--league-payload', choices=('record', 'league'), default='record',
+                    help='what the league all-gather carries: record = all five arrays (50 B per env-step), league = action, reward, '
+                         'done, result (10 B per env-step; observations stay on the rank that trains on them)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary measurements')
     ap.add_argument('--eager', action='store_true', help='issue the timed launches eagerly from Python instead of replaying one hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -383,9 +390,9 @@ def roofline_of(alg_bytes_launch, launch_s, launch_s_events, kernel, traffic_key
 # --------------------------------------------------------------------------------------------------------------------
 # reach_ball measurements
 # --------------------------------------------------------------------------------------------------------------------
-def reach_engine(n, dev, rank, noise, variant='dqn'):
+def reach_engine(n, dev, rank, noise, variant='dqn', task_kwargs=None):
     from soccer2d_amd.engine import Engine, make_config
-    kw, sp, auto = dict(DQN_KWARGS), None, True
+    kw, sp, auto = dict(task_kwargs or DQN_KWARGS), None, True
     if variant == 'no-auto-reset':
         auto = False
     elif variant == 'never-done':
@@ -416,9 +423,10 @@ def measure_rollout(eng, T, launches, nbuf, repeats, stream, settle_ms, dist=Non
     torch.cuda.synchronize()
     g = graph_of(lambda: issue(launches))
     wall, evs = timed_regions(g.replay, repeats, stream, dist, dev, warm_regions)
-    alg = n * (2 * STATE_BYTES + T * RECORD_BYTES)
+    rec = RECORD_BYTES + (12 if (eng.cfg.task.use_continuous_action and eng.cfg.task.use_turning) else 0)   # float[4] actions
+    alg = n * (2 * STATE_BYTES + T * rec)
     return {'wall': wall, 'events': evs, 'launch_s': median_of(wall) / launches, 'launch_s_events': median_of(evs) / launches,
-            'alg_bytes_launch': alg, 'launches': launches, 'buffers': nbuf, 'bytes_in_flight': nbuf * T * n * RECORD_BYTES}
+            'alg_bytes_launch': alg, 'launches': launches, 'buffers': nbuf, 'bytes_in_flight': nbuf * T * n * rec}
 
 
 def rollout_entry(m, n, T, kernel, traffic_key):
@@ -517,13 +525,20 @@ class _EnvShim:
         self.engine, self.device = eng, eng.device
 
 
-def measure_league_exchange(eng, T, steps, warm, dist, dev, world):
+def xgmi_bound(world, n, T, bytes_sent):
+    """What the links allow: a direct all-gather sends this rank's slab once over each of its world - 1 xGMI links (all at the same
+    time), so an exchange cannot take less than bytes_sent / 153 GB/s, and the job's env-steps/s with one exchange per launch cannot
+    exceed world x N x T / that -- whatever the simulation rate."""
+    return world * n * T / (bytes_sent / (XGMI_LINK_GBS * 1e9))
+
+
+def measure_league_exchange(eng, T, steps, warm, dist, dev, world, payload='record'):
     """configs[4]: `steps` rounds of {rollout of T cycles into a slab; all-gather of that slab on the side stream, overlapped with
     the next rollout}.  Returns env-steps/s with the exchange, the exchange's own duration (side-stream HIP events) and what
     that is against the xGMI links."""
     import torch
-    from soccer2d_amd.dist import LeagueRolloutExchange
-    ex = LeagueRolloutExchange(_EnvShim(eng), T, timing=True)
+    from soccer2d_amd.dist import LEAGUE_FIELDS, LeagueRolloutExchange
+    ex = LeagueRolloutExchange(_EnvShim(eng), T, timing=True, fields=LEAGUE_FIELDS if payload == 'league' else None)
     for _ in range(warm):
         ex.step()
     ex.flush()
@@ -549,7 +564,13 @@ def measure_league_exchange(eng, T, steps, warm, dist, dev, world):
            'seconds_per_round': elapsed / steps, 'collectives_per_exchange': 1, 'backend': backend,
            'rccl_ranks': world if backend == 'nccl' else 0,
            'bytes_sent_per_rank': sent, 'bytes_received_per_rank': ex.bytes_per_exchange['received'],
-           'gather_seconds': gather_s}
+           'gather_seconds': gather_s,
+           'payload': 'action, reward, done, result (10 B per env-step)' if payload == 'league' else 'the whole record (50 B per env-step)',
+           # the link bound of the WHOLE JOB for this payload (one exchange per launch), next to the measured value; and for both
+           # payloads at this batch, so that the choice can be read off the line
+           'xgmi_bound_env_steps_s': xgmi_bound(max(world, 2), eng.num_envs, T, sent),
+           'xgmi_bound_by_payload': {'record_50B': xgmi_bound(max(world, 2), eng.num_envs, T, eng.num_envs * T * RECORD_BYTES),
+                                     'league_10B': xgmi_bound(max(world, 2), eng.num_envs, T, eng.num_envs * T * 10)}}
     if gather_s and world > 1:
         # a direct all-gather sends this rank's slab once over each of its world-1 links and receives one slab over each
         per_peer = sent / gather_s / 1e9
@@ -604,7 +625,7 @@ def run_reach(args, dev, dist, rank, world):
     elif args.mode == 'rollout':
         # configs[4]: a bench step = one rollout launch + the all-gather of its slab (side stream, overlapped with the next)
         settle(lambda c: [eng.rollout(T) for _ in range(max(1, c // T))], 16 * T, args.settle_ms)
-        league = measure_league_exchange(eng, T, K, args.warmup, dist, dev, world)
+        league = measure_league_exchange(eng, T, K, args.warmup, dist, dev, world, args.league_payload)
         wall = [league['seconds_per_round'] * K]
         m = measure_rollout(eng, T, K, 1, args.repeats, stream, 0.0, dist, dev, warm=1)     # the same launches without the exchange
         launch_s, launch_ev = league['seconds_per_round'], m['launch_s_events']
@@ -672,14 +693,18 @@ def run_reach(args, dev, dist, rank, world):
     # world > 1, default mode: the league all-gather measured beside the metric (short; RCCL on a real node), under a deadline
     if world > 1 and not args.league_exchange and not args.no_secondary and args.mode == 'rollout':
         def give_up():
+            # a collective that never completes is a finding, not a success: the line (without this measurement) is on stdout,
+            # the exit code says that the run did not finish
             if rank == 0:
                 line.setdefault('secondary', {})['league_exchange'] = {'error': 'no completion within 120 s'}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
-        try:
-            le = with_deadline(lambda: measure_league_exchange(eng, T, 6, 2, dist, dev, world), 120.0, give_up)
-        except Exception as ex:
-            le = {'error': repr(ex)}
+            os._exit(3)
+        le = {}
+        for payload in ('league', 'record'):                  # both payloads: 10 B and 50 B per env-step
+            try:
+                le[payload] = with_deadline(lambda: measure_league_exchange(eng, T, 6, 2, dist, dev, world, payload), 120.0, give_up)
+            except Exception as ex:
+                le[payload] = {'error': repr(ex)}
         if rank == 0:
             line.setdefault('secondary', {})['league_exchange'] = le
     if rank != 0:
@@ -731,6 +756,15 @@ def secondary_measurements(args, dev, stream, rank, n, T, line, out):
     line['noise_on'] = rollout_entry(m, n, T, eng.kernel_name(), None)
     line['noise_on']['config'] = 'same workload with player_rand 0.1 / ball_rand 0.05 (make_config default)'
     del eng
+    # the other action modes (the reference's default is use_continuous_action=True, reach_ball_env.py:34): the DDPG script's kwargs
+    # with 1-D continuous actions, and the same with the 4-D turning mode; uniform random policy, noise off like the headline
+    for key, over in (('continuous', {}), ('turning4', {'use_turning': True})):
+        eng = reach_engine(n, dev, rank, False, task_kwargs=dict(DDPG_KWARGS, **over))
+        m = measure_rollout(eng, T, 32, nb, R, stream, args.settle_ms)
+        out[key] = rollout_entry(m, n, T, eng.kernel_name(), None)
+        out[key]['config'] = ('kwargs of ddpg_stable_baselines3.py:18-31' + (' with use_turning=True (4-D actions, reach_ball_env.py:59-79)' if over else '') +
+                              '; record 50 B per env-step' + (' + 12 B of action' if over else ''))
+        del eng
     eng = reach_engine(n, dev, rank, False)
     # the rounds 1-2 launch shape: 64 cycles per launch, (a) into rotating buffers, (b) re-writing ONE 218.6 MB buffer, which the
     # 256 MiB Infinity Cache can hold (the rounds 1-2 headline)

@@ -282,6 +282,17 @@ S2D_DEV void action_map(const S2DHot& p, const Action4& a, float u, int& cmd, fl
   }
 }
 
+// S2D_ACT_COMMAND: the command word of a decoded body command (float[N][4], include/s2d.h) -> S2D_CMD_*.  One definition for the kernels
+// and (restated) for the CPU checker: the nearest of FREEZE (-1), NONE (0), DASH (1), TURN (2); anything else -- other numbers, NaN --
+// is no command.
+S2D_DEV int command_code(float x) {
+  int c = S2D_CMD_NONE;
+  c = (x >= -1.5f && x <= -0.5f) ? (int)S2D_CMD_FREEZE : c;
+  c = (x >= 0.5f && x < 1.5f) ? (int)S2D_CMD_DASH : c;
+  c = (x >= 1.5f && x < 2.5f) ? (int)S2D_CMD_TURN : c;
+  return c;
+}
+
 // ------------------------------------------------------------------ A3 + A4 fused
 // state_to_observation (reach_ball_env.py:87-111) and check_trainer_observation (:113-161)
 // read the same full-state truth, so the player->ball vector, its angle and the distance

@@ -816,6 +816,14 @@ __global__ void s2d_debug_eval_kernel(int op, const float* __restrict__ in, floa
   }
   if (i >= n) return;
   switch (op) {
+    case 10: {                                           // movement noise of one commanded cycle (s2d_device.h: noise_prepare)
+      const uint32_t* u = reinterpret_cast<const uint32_t*>(in) + 4 * i;   // gid_lo, gid_hi, counter k, seed_lo (seed_hi = 0)
+      S2DHot p{}; p.seed_lo = u[3]; p.seed_hi = 0u;
+      const NoiseIn nz = noise_prepare(p, u[0], u[1], u[2], S2D_ST_NOISE, false);
+      float* q = out + 6 * i;
+      q[0] = nz.pm; q[1] = nz.ps; q[2] = nz.pc; q[3] = nz.bm; q[4] = nz.bs; q[5] = nz.bc;
+      break;
+    }
     case 0: { float s, c; sincos_deg(in[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break; }
     case 1: out[i] = atan2_deg(in[2 * i], in[2 * i + 1]); break;
     case 2: out[i] = exp_spec(in[i]); break;
@@ -1338,7 +1346,7 @@ S2D_API int s2d_set_seed(S2DHandle h, uint64_t seed, void* stream) {
 }
 
 S2D_API int s2d_debug_eval(int op, const void* in_dev, void* out_dev, int64_t n, void* stream) {
-  if (!in_dev || !out_dev || n <= 0 || op < 0 || op > 9 || (op == 9 && n % 256 != 0)) return fail(S2D_EINVAL, "bad s2d_debug_eval argument");
+  if (!in_dev || !out_dev || n <= 0 || op < 0 || op > 10 || (op == 9 && n % 256 != 0)) return fail(S2D_EINVAL, "bad s2d_debug_eval argument");
   hipLaunchKernelGGL(s2d_debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), op, static_cast<const float*>(in_dev),
                      static_cast<float*>(out_dev), n);

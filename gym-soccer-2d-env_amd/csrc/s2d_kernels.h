@@ -179,7 +179,7 @@ S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int ki
                        int& cmd, float& dir) {
   if (kind == S2D_ACT_COMMAND) {                           // a decoded body command, executed as it is (wave-uniform branch)
     const float4 v = static_cast<const float4*>(actions)[idx];
-    cmd = (int)v.x; dir = v.z;
+    cmd = command_code(v.x); dir = v.z;
     return cmd_prepare(p, cmd, v.y, v.z);
   }
   Action4 a = (kind == S2D_ACT_RANDOM) ? random_action<MODE>(p, gid_lo, gid_hi, k, quad, refresh)

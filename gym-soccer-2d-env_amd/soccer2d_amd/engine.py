@@ -207,11 +207,15 @@ class Engine:
         self._keep = (keep, out)
         return out
 
-    def alloc_rollout(self, T, with_obs=True, slab=False):
-        """Caller-owned rollout buffers for `rollout(..., out=)`.  slab=True carves all five fields out of ONE contiguous
-        uint8 tensor (256-byte aligned fields; returned under the key '_slab'), so that a whole rollout record travels in a
-        single collective (dist.all_gather_rollout) without a packing copy: the kernel writes straight into the slab."""
+    def alloc_rollout(self, T, with_obs=True, slab=False, fields=None):
+        """Caller-owned rollout buffers for `rollout(..., out=)`.  slab=True carves the fields out of ONE contiguous
+        uint8 tensor (256-byte aligned fields; returned under the key '_slab'), so that a rollout record travels in a
+        single collective (dist.all_gather_rollout) without a packing copy: the kernel writes straight into the slab.
+        fields (with slab=True): the names that go into the slab -- what travels --; the others are plain local tensors."""
         n, t, dev = self.num_envs, self.cfg.task, self.device
+        slab_fields = None if fields is None else set(fields)
+        if slab_fields is not None and not slab:
+            raise ValueError('fields= selects what goes into the slab: it needs slab=True')
         act_dt, act_trail = (torch.int32, ()) if not t.use_continuous_action else (torch.float32, (4 if t.use_turning else 1,))
         fields = [('obs', torch.float32, (S2D_OBS_DIM,))] if with_obs else []
         fields += [('action', act_dt, act_trail), ('reward', torch.float32, ()), ('done', torch.uint8, ()), ('result', torch.uint8, ())]
@@ -219,8 +223,10 @@ class Engine:
             out = {name: torch.empty((T, n) + trail, dtype=dt, device=dev) for name, dt, trail in fields}
             out.setdefault('obs', None)
             return out
+        in_slab = [f for f in fields if slab_fields is None or f[0] in slab_fields]
+        local = {name: torch.empty((T, n) + trail, dtype=dt, device=dev) for name, dt, trail in fields if slab_fields is not None and name not in slab_fields}
         layout, off = [], 0
-        for name, dt, trail in fields:
+        for name, dt, trail in in_slab:
             cnt = T * n
             for d in trail:
                 cnt *= d
@@ -231,6 +237,7 @@ class Engine:
         shift = (-raw.data_ptr()) % 256
         slab_t = raw[shift:shift + off]
         out = {name: slab_t[o:o + nb].view(dt).view(shape) for name, dt, shape, o, nb in layout}
+        out.update(local)
         out.setdefault('obs', None)
         out['_slab'], out['_layout'] = slab_t, tuple(layout)
         return out

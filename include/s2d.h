@@ -70,7 +70,8 @@ enum {
    * `action_to_rpc_actions` (soccer_2d_env.py:317-325): a user-defined task env builds pb2.PlayerAction objects in Python and the
    * host mirror turns them into this array.  Accepted by s2d_step in every task mode (16-byte aligned); not by s2d_rollout.
    * (The env-step counter of the episode statistics counts every env of the launch, frozen ones included.) */
-  S2D_ACT_COMMAND = 5
+  S2D_ACT_COMMAND = 5   /* the command word is read as the nearest of -1 / 0 / 1 / 2 (S2D_CMD_*); any other number, NaN included, is
+                         * S2D_CMD_NONE */
 };
 
 /* ---- configuration -------------------------------------------------------------------- */
@@ -245,6 +246,10 @@ int s2d_set_seed(S2DHandle h, uint64_t seed, void *stream);
  *   -> out[n][3] = S2D_CMD_*, power, relative direction;
  * 8 check_trainer_observation (:113-161): in[n][12] = bx,by,px,py,body,step_number,prev_dist,prev_angle,
  *   min_distance_to_ball,max_steps,half_length,half_width -> out[n][5] = done,reward,S2D_RESULT_*,dist,angle. */
+/* 9 reset_sample_coop against reset_sample (in = uint32[n][4], n a multiple of 256; out[n][14]);
+ * 10 the movement-noise draw of one commanded cycle (one Philox word per object and cycle -- magnitude uniform
+ *   k / 65536 from its high half, direction a WHOLE degree from its low half): in = uint32[n][4] = global env id lo, hi, policy step k,
+ *   seed (low word) -> out[n][6] = player magnitude uniform, sin, cos; ball magnitude uniform, sin, cos. */
 int s2d_debug_eval(int op, const void *in_dev, void *out_dev, int64_t n, void *stream);
 
 #ifdef __cplusplus

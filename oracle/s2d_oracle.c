@@ -547,6 +547,16 @@ static void fetch_action(const S2DOEngine *h, int64_t i, const void *actions, in
 }
 
 /* A1  Soccer2DEnv.step   soccer_2d_env.py:226-269 */
+/* S2D_ACT_COMMAND: command word -> S2D_CMD_* (include/s2d.h: the nearest of FREEZE -1, NONE 0, DASH 1, TURN 2; anything else,
+ * NaN included, is no command) */
+static int command_code(float x) {
+  int c = S2D_CMD_NONE;
+  if (x >= -1.5f && x <= -0.5f) c = S2D_CMD_FREEZE;
+  if (x >= 0.5f && x < 1.5f) c = S2D_CMD_DASH;
+  if (x >= 1.5f && x < 2.5f) c = S2D_CMD_TURN;
+  return c;
+}
+
 static void step_one(S2DOEngine *h, int64_t i, const void *actions, int kind, void *rollout_action_out,
                      unsigned long long local_stats[4]) {
   const P *p = &h->p;
@@ -554,7 +564,7 @@ static void step_one(S2DOEngine *h, int64_t i, const void *actions, int kind, vo
   uint64_t gid = (uint64_t)(p->env_id_offset + i);
   REAL a[4];
   const int turning = p->use_continuous && p->use_turning;
-  if (kind == S2D_ACT_COMMAND && ((const float *)actions)[4 * i] < 0.0f) return;   /* S2D_CMD_FREEZE: not part of this cycle */
+  if (kind == S2D_ACT_COMMAND && command_code(((const float *)actions)[4 * i]) == S2D_CMD_FREEZE) return;   /* not part of this cycle */
   fetch_action(h, i, actions, kind, e->policy_step, a, rollout_action_out);
   e->step_number += 1;                                   /* reach_ball_env.py:55 */
   const uint32_t k = e->policy_step;
@@ -564,7 +574,7 @@ static void step_one(S2DOEngine *h, int64_t i, const void *actions, int kind, vo
   int cmd; REAL power, dir;
   if (kind == S2D_ACT_COMMAND) {                         /* a decoded PlayerAction body command, executed as it is (server.py:64) */
     const float *c4 = (const float *)actions + 4 * i;
-    cmd = (int)c4[0]; power = (REAL)c4[1]; dir = (REAL)c4[2];
+    cmd = command_code(c4[0]); power = (REAL)c4[1]; dir = (REAL)c4[2];
   } else
   action_map(p, a, u, &cmd, &power, &dir);               /* :238 */
   h->action_cmd[i] = (uint8_t)cmd; h->action_dir[i] = dir;

@@ -158,3 +158,40 @@ def test_ball_noise_magnitude_and_direction():
     assert seen > 100000
     check(chi_square_uniform(mag_h), 'ball noise magnitude / (ball_rand * |v|)')
     check(chi_square_uniform(dir_h), 'ball noise direction')
+
+
+def test_noise_draw_lattice():
+    """The movement-noise draw as the spec defines it (round-3 respecification, parity UNPINNED against
+    rcssserver's continuous drand pair): ONE Philox word per object and cycle -- magnitude uniform = (word >> 16) / 65536, direction
+    = the WHOLE degree ((word & 0xffff) * 360) >> 16 - 180, whose sine / cosine are sincos_deg of that degree; one block per two
+    cycles (words x, y for even k, z, w for odd k of block 0 at counter k >> 1, stream 3).  The device's draw (s2d_debug_eval op 10)
+    equals that restatement bit for bit -- so a later coarsening of the lattice cannot pass -- and the 360 direction cells and the
+    64 leading magnitude cells are uniform."""
+    from soccer2d_amd import _capi
+    lib = _capi.load_library()
+    n, seed = 1 << 16, 0x5EED
+    gid = np.arange(n, dtype=np.uint32) * 3 + 11
+    dir_h, mag_h = np.zeros(360, np.int64), np.zeros(64, np.int64)
+    for k in (0, 1, 6, 7, 1001):
+        x = torch.from_numpy(np.stack([gid, np.full(n, 7, np.uint32), np.full(n, k, np.uint32), np.full(n, seed, np.uint32)], axis=1).astype(np.int64)).to(torch.int32).cuda().contiguous()
+        y = torch.empty((n, 6), dtype=torch.float32, device='cuda:0')
+        _capi.check(lib, lib.s2d_debug_eval(10, x.data_ptr(), y.data_ptr(), n, None), 's2d_debug_eval')
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        sub = np.arange(0, n, 97)                          # the CPU restatement on a subset (ctypes Philox per draw)
+        for i in sub:
+            w = O.philox([int(gid[i]), 7, k >> 1, (3 << 16) | 0], [seed, 0])
+            wp, wb = (w[2], w[3]) if (k & 1) else (w[0], w[1])
+            exp = []
+            for word in (wp, wb):
+                s, c = O.sincos_deg(float((((word & 0xffff) * 360) >> 16) - 180))
+                exp += [np.float32((word >> 16) * 2.0 ** -16), np.float32(s), np.float32(c)]
+            assert np.array_equal(got[i].view(np.int32), np.array(exp, np.float32).view(np.int32)), (k, i, got[i], exp)
+        for m, sn, cs in ((got[:, 0], got[:, 1], got[:, 2]), (got[:, 3], got[:, 4], got[:, 5])):
+            assert np.array_equal(m * 65536.0, np.rint(m * 65536.0)) and m.min() >= 0.0 and m.max() < 1.0      # k / 65536
+            deg = np.degrees(np.arctan2(sn.astype(np.float64), cs.astype(np.float64)))
+            assert np.abs(deg - np.rint(deg)).max() < 1e-4                                                      # whole degrees
+            dir_h += np.bincount(np.rint(deg).astype(np.int64) % 360, minlength=360)
+            mag_h += np.bincount((m * 64).astype(np.int64), minlength=64)
+    check(chi_square_uniform(dir_h), 'noise direction over the 360 whole degrees')
+    check(chi_square_uniform(mag_h), 'noise magnitude uniform')

@@ -548,7 +548,9 @@ def test_command_action_kind_equals_the_oracle():
         eng.reset(); orc.reset()
         for t in range(40):
             c = np.zeros((n, 4), np.float32)
-            c[:, 0] = rs.choice([-1, 0, 1, 1, 1, 2], n)
+            # besides the four codes: values that are not codes (-0.5 and -1.4 freeze, 0.4 and 3 and NaN are no command, 1.2 dashes,
+            # 2.4 turns: command_code() of s2d_device.h, one definition for kernel and checker)
+            c[:, 0] = rs.choice([-1, 0, 1, 1, 1, 2, -0.5, -1.4, 0.4, 3.0, np.nan, 1.2, 2.4, -7.0], n)
             c[:, 1] = rs.uniform(-120, 120, n)
             c[:, 2] = rs.uniform(-200, 200, n)
             obs, rew, done, res = eng.step_commands(c)
@@ -556,6 +558,8 @@ def test_command_action_kind_equals_the_oracle():
             torch.cuda.synchronize()
             assert np.array_equal(obs.cpu().numpy().view(np.int32), o_obs.view(np.int32)), (kw, t)
             assert np.array_equal(rew.cpu().numpy().view(np.int32), o_rew.view(np.int32)), (kw, t)
+            assert np.array_equal(eng.action_cmd.cpu().numpy(), orc.action_cmd()), (kw, t)
+            assert set(np.unique(eng.action_cmd.cpu().numpy())) <= {0, 1, 2}
         for f in O.STATE_FIELDS:
             g, r = getattr(eng, f).cpu().numpy(), orc.state(f)
             assert np.array_equal(g.view(np.int32) if g.dtype == np.float32 else g, r.view(np.int32) if r.dtype == np.float32 else r), (kw, f)

@@ -118,6 +118,33 @@ def test_match_full_size_rollout_parity():
     assert torch.equal(wm['world_model.cycle'] + 0, eng.cycle) and int(wm['world_model.stoped_cycle'].max()) > 0
 
 
+@pytest.mark.parametrize('general', [False, True])
+def test_match_full_size_rollout_record_parity(general, monkeypatch):
+    """The record bench.py times at BASELINE.json configs[3] size -- 8 192 matches x 64 fused cycles, 489 B per match-step:
+    observations [T][N][24][5] (x, y, vx, vy, body of the 22 players and the ball after each cycle), mode, reward, done -- against the
+    oracle stepped cycle by cycle, every word of every step, through the stock instantiation and through the general one."""
+    if general:
+        monkeypatch.setenv('S2D_MATCH_GENERAL_KERNEL', '1')
+    n, T = 8192, 64
+    eng, orc = _pair(n)
+    assert eng.kernel_name().endswith('<general>' if general else '<stock, stock types>')
+    out = eng.rollout(T, with_obs=True)
+    torch.cuda.synchronize()
+    obs = out['obs'].cpu().numpy()
+    mode, rew, done = out['mode'].cpu().numpy(), out['reward'].cpu().numpy(), out['done'].cpu().numpy()
+    for t in range(T):
+        orc.step(None)
+        for k, f in enumerate(('x', 'y', 'vx', 'vy', 'body')):
+            c = orc.get(f)[:, :23]
+            if not np.array_equal(_bits(obs[t, :, :23, k]), _bits(c)):
+                bad = np.argwhere(_bits(obs[t, :, :23, k]) != _bits(c))
+                raise AssertionError(f'record obs.{f} at step {t}: {len(bad)} words differ; first at {tuple(bad[0])}')
+        assert np.array_equal(mode[t], orc.get('mode')), t
+        assert np.array_equal(_bits(rew[t]), _bits(orc.get('reward_left'))), t
+        assert np.array_equal(done[t], orc.get('done')), t
+    assert_match_same(eng, orc, 'full-size record')
+
+
 def test_scripted_policy_beats_idle_and_random_in_league_round():
     """The engine is a playable game: a 30-line 'chase and shoot' policy (device tensors only)
     out-scores an idle team and a random team; results feed the replicated Elo table."""

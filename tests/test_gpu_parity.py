@@ -334,6 +334,28 @@ def test_full_size_parity_and_properties(ws, monkeypatch):
     assert float(obs[..., 0].abs().max()) <= 1.0 and float(obs[..., 7].abs().max()) <= 0.5
 
 
+@pytest.mark.parametrize('name', ['noise-on', 'continuous1', 'reference-default'])
+def test_full_size_parity_other_configurations(name):
+    """BASELINE.json configs[2] size (65 536 envs x 256 cycles = bench.py's launch) for what the headline configuration does not
+    cover: noise on (the drop-in default of make_config), 1-D continuous actions (the DDPG script's), and the reference's own default
+    kwargs (use_continuous_action=True, change_ball_velocity=False: reach_ball_env.py:26-36) -- full bit-exact comparison through
+    the kernel s2d_rollout picks by default."""
+    kw = dict(use_continuous_action=True, use_turning=False) if name == 'reference-default' else dict(CONFIGS[name])
+    kw.pop('max_steps', None)                              # the reference's 200
+    n, T = 65536, 256
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    out = eng.rollout(T)
+    ref = orc.rollout(T)
+    assert eng.kernel_name().startswith('s2d_reach_rollout_ws_kernel<') and 'nt=1' in eng.kernel_name()
+    _compare_rollout(out, ref, f'full-size {name}')
+    assert_state_same(eng, orc, f'full-size {name}')
+    done = out['done'].cpu().numpy()
+    assert (eng.cycle.cpu().numpy() == T + 1 + done.sum(axis=0)).all()
+    st = eng.stats.cpu().numpy()
+    assert st[0] == n * T and st[1:4].sum() == done.sum()
+
+
 def test_errors_are_loud():
     from soccer2d_amd.engine import Engine, make_config
     with pytest.raises(ValueError):

@@ -89,9 +89,14 @@ def _worker(rank, world, port, n_global, T, q):
     full = all_gather_rollout(local, time_major=True)
     assert len(calls) == 1, 'one collective per exchange (all five fields travel in one slab)'
     raw = all_gather_rollout(local, time_major=False)
+    from soccer2d_amd.dist import LEAGUE_FIELDS
+    calls.clear()
+    small = all_gather_rollout(local, time_major=True, fields=LEAGUE_FIELDS)       # the league payload: 10 of the record's 50 bytes
+    assert len(calls) == 1 and sorted(small) == sorted(LEAGUE_FIELDS)
     dist.all_gather_into_tensor = real
     stats = all_reduce_stats(torch.from_numpy(eng.stats().astype(np.int64)))
     if rank == 0:
+        full.update({'small_' + k: v for k, v in small.items()})
         q.put(({k: v.numpy() for k, v in full.items()}, {k: tuple(v.shape) for k, v in raw.items()}, stats.numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -120,6 +125,9 @@ def test_two_rank_gloo_shards_and_all_gather():
     for k in ('obs', 'action', 'reward', 'done', 'result'):
         assert full[k].shape == ref[k].shape
         assert np.array_equal(full[k].view(np.uint8), np.ascontiguousarray(ref[k]).view(np.uint8)), k
+    for k in ('action', 'reward', 'done', 'result'):       # the subset slab (LeagueRolloutExchange(fields=LEAGUE_FIELDS)) == the same oracle
+        assert np.array_equal(full['small_' + k].view(np.uint8), np.ascontiguousarray(ref[k]).view(np.uint8)), k
+    assert 'small_obs' not in full
     assert raw_shapes['obs'] == (2, T, n_global // 2, 10)
     assert list(stats[:4]) == list(whole.stats()[:4].astype(np.int64))
 
