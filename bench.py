@@ -450,6 +450,22 @@ def measure_steps(eng, launches, repeats, stream, settle_ms, actions=None):
             'roofline': roofline_of(alg, ls, le, eng.kernel_name(), 'step', 64, n, 1)}
 
 
+def measure_step_k(eng, k, launches, repeats, stream, settle_ms):
+    """s2d_step_k: k cycles of the per-step API per launch, caller actions [k][N] (int32, resident), record written into one [k][N]
+    buffer set.  Returns us per launch and per cycle."""
+    import torch
+    n = eng.num_envs
+    acts = torch.randint(0, DQN_KWARGS['action_space_size'], (k, n), device=eng.device, dtype=torch.int32)
+    out = eng.alloc_rollout(k)
+    settle(lambda c: [eng.step_k(k, acts, out=out) for _ in range(max(1, c // k))], 2048, settle_ms)
+    g = graph_of(lambda: [eng.step_k(k, acts, out=out) for _ in range(launches)])
+    wall, evs = timed_regions(g.replay, repeats, stream, None, None)
+    ls = median_of(wall) / launches
+    return {'k': k, 'us_per_launch': ls * 1e6, 'us_per_cycle': ls * 1e6 / k, 'value': n * k / ls, 'unit': 'env-steps/s',
+            'repeats_us_per_cycle': [w / launches / k * 1e6 for w in wall], 'kernel': eng.kernel_name(),
+            'record': 'obs, action, reward, done, result of every cycle ([k][N]); caller actions int32 [k][N]'}
+
+
 def measure_match(n, dev, rank, T, launches, repeats, stream, settle_ms, noise=False, phase='spread', mode='rollout', dist=None):
     """11v11 engine: `launches` rollout launches of T cycles (or single-cycle launches in step mode) per region."""
     import torch
@@ -479,26 +495,26 @@ def measure_match(n, dev, rank, T, launches, repeats, stream, settle_ms, noise=F
     ls, le = median_of(wall) / launches, median_of(evs) / launches
     alg = n * (2 * MATCH_STATE_BYTES + (per_launch * MATCH_RECORD_BYTES if mode == 'rollout' else 5))
     st = eng.stats.cpu().tolist()
-    # instruction issue, not HBM, bounds this kernel (PMC traffic = 1.02 x algorithmic bytes at 0.1 of the HBM peak): the roofline
-    # that says something is wave-instructions per second against the SIMDs' issue peak.  Instructions per wave-cycle come from
-    # the committed PMC instruction mix of the same build (profiles/r03/pmc_match_instmix.txt; SQ_INSTS_VALU + SALU + LDS per wave).
-    instr_per_wave_cycle, src, mix = match_instr_per_wave_cycle()
+    # SURVEY 8(d) prices every kernel of the path against the HBM roofline, so that is `roofline` here too: algorithmic bytes (state
+    # round trip + the 489 B record per match-step) over the launch time against 8 TB/s.  The kernel is far from it (0.12) because
+    # it is bound by instruction issue; that is kept as a SECONDARY model (`issue_model`), counting only the VALU instructions of
+    # the committed PMC mix against the VALU issue peak of the SIMDs -- read it with `value`: the same work in fewer instructions
+    # lowers it while the rate rises.
+    valu_per_wave_cycle, src, mix = match_valu_per_wave_cycle()
     waves = -(-n // 2)
-    roof = {'bound': 'valu-issue', 'unit': 'G wave-instr/s', 'peak': VALU_PEAK_GINSTR,
-            'peak_source': 'profiles/r01/instr_rate_gfx950.txt (1.08 ns per instruction and SIMD at >= 2 waves per SIMD; 1024 SIMDs)',
-            'kernel': 's2d_match_rollout_kernel' if mode == 'rollout' else 's2d_match_step_kernel', 'launch_us': ls * 1e6, 'launch_us_events': le * 1e6,
-            'instructions_per_wave_cycle': instr_per_wave_cycle, 'instructions_source': src, 'instruction_mix': mix,
-            # the same work in fewer instructions lowers `achieved` (and `frac`) while `value` rises: read the two together
-            'kernel_variant': eng.kernel_name(),
-            'hbm': {'achieved': alg / ls / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg / ls / 1e9 / HBM_PEAK_GBS,
-                    'algorithmic_bytes_per_launch': alg, 'algorithmic_bytes_per_env_step': alg / (n * per_launch)}}
     tr, tsrc = load_traffic('match-' + mode, T, n)
-    roof['traffic'], roof['traffic_source'] = tr, tsrc or 'none for this configuration'
-    if instr_per_wave_cycle:
-        roof['achieved'] = waves * per_launch * instr_per_wave_cycle / ls / 1e9
-        roof['frac'] = roof['achieved'] / VALU_PEAK_GINSTR
-    else:
-        roof['achieved'], roof['frac'] = None, None
+    roof = {'bound': 'hbm', 'achieved': alg / ls / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg / ls / 1e9 / HBM_PEAK_GBS,
+            'traffic': tr, 'traffic_source': tsrc or 'none for this configuration',
+            'kernel': 's2d_match_rollout_kernel' if mode == 'rollout' else 's2d_match_step_kernel', 'kernel_variant': eng.kernel_name(),
+            'launch_us': ls * 1e6, 'launch_us_events': le * 1e6,
+            'algorithmic_bytes_per_launch': alg, 'algorithmic_bytes_per_env_step': alg / (n * per_launch),
+            'limiter': 'instruction issue (see issue_model): 22 players + ball per match on a half wave, ~450 VALU instructions per wave-cycle',
+            'issue_model': {'bound': 'valu-issue', 'unit': 'G VALU wave-instr/s', 'peak': VALU_PEAK_GINSTR,
+                            'peak_source': 'profiles/r01/instr_rate_gfx950.txt (1.08 ns per VALU instruction and SIMD at >= 2 waves per SIMD; 1024 SIMDs)',
+                            'valu_per_wave_cycle': valu_per_wave_cycle, 'instructions_source': src, 'instruction_mix': mix}}
+    if valu_per_wave_cycle:
+        roof['issue_model']['achieved'] = waves * per_launch * valu_per_wave_cycle / ls / 1e9
+        roof['issue_model']['frac'] = roof['issue_model']['achieved'] / VALU_PEAK_GINSTR
     return {'value': n * per_launch / ls, 'unit': 'env-steps/s', 'launches_per_region': launches, 'cycles_per_launch': per_launch,
             'phase': phase, 'repeats': [n * per_launch * launches / w for w in wall], 'wall': wall,
             'player_steps_per_s': 22 * n * per_launch / ls, 'roofline': roof,
@@ -506,17 +522,17 @@ def measure_match(n, dev, rank, T, launches, repeats, stream, settle_ms, noise=F
                        'offsides': st[6], 'ball_outs': st[7]}}
 
 
-def match_instr_per_wave_cycle():
-    for rnd in ('r03', 'r02', 'r01'):
+def match_valu_per_wave_cycle():
+    """VALU instructions per wave and cycle of the 11v11 kernel from the committed PMC mix (the newest round that has one)."""
+    for rnd in ('r04', 'r03', 'r02', 'r01'):
         f = os.path.join(ROOT, 'profiles', rnd, 'pmc_match_instmix.json')
         if os.path.exists(f):
             try:
                 d = json.load(open(f))
-                return (float(d['instructions_per_wave_cycle']), f'profiles/{rnd}/pmc_match_instmix.json',
-                        {k: d[k] for k in ('valu', 'salu', 'lds') if k in d})
+                return float(d['valu']), f'profiles/{rnd}/pmc_match_instmix.json', {k: d[k] for k in ('valu', 'salu', 'lds') if k in d}
             except Exception:
                 pass
-    return 1044.0, 'profiles/r01/pmc_match_instmix.txt (625 VALU + 351 SALU + 68 LDS; taken before the round-2 tile rewrite)', None
+    return None, 'no committed PMC mix', None
 
 
 class _EnvShim:
@@ -620,7 +636,7 @@ def run_reach(args, dev, dist, rank, world):
         m = measure_rollout(eng, T, K, nbuf, args.repeats, stream, args.settle_ms, dist, dev, warm=args.warmup)
         wall, launch_s, launch_ev = m['wall'], m['launch_s'], m['launch_s_events']
         steps_per_launch, alg = T, m['alg_bytes_launch']
-        traffic_key = 'rollout' if nbuf == 1 else 'rollout-rotate'
+        traffic_key = ('rollout' if nbuf == 1 else 'rollout-rotate') + ('-noise' if args.noise else '')
         n_launches = K
     elif args.mode == 'rollout':
         # configs[4]: a bench step = one rollout launch + the all-gather of its slab (side stream, overlapped with the next)
@@ -753,7 +769,7 @@ def secondary_measurements(args, dev, stream, rank, n, T, line, out):
     # noise on (rcssserver's stock player_rand / ball_rand), rotating buffers like the headline
     eng = reach_engine(n, dev, rank, True)
     m = measure_rollout(eng, T, 32, nb, R, stream, args.settle_ms)
-    line['noise_on'] = rollout_entry(m, n, T, eng.kernel_name(), None)
+    line['noise_on'] = rollout_entry(m, n, T, eng.kernel_name(), 'rollout-rotate-noise')
     line['noise_on']['config'] = 'same workload with player_rand 0.1 / ball_rand 0.05 (make_config default)'
     del eng
     # the other action modes (the reference's default is use_continuous_action=True, reach_ball_env.py:34): the DDPG script's kwargs
@@ -778,11 +794,13 @@ def secondary_measurements(args, dev, stream, rank, n, T, line, out):
     acts = torch.randint(0, DQN_KWARGS['action_space_size'], (n,), device=dev, dtype=torch.int32)
     out['step_api_caller_actions'] = measure_steps(eng, 2048, R, stream, args.settle_ms, actions=acts)
     out['step_api_caller_actions']['actions'] = 'int32[N] device tensor (what dqn_stable_baselines3.py hands to step())'
+    # s2d_step_k: the per-step API with k cycles per launch (a learner that holds its actions for k steps)
+    out['step_k'] = [measure_step_k(eng, k, 2048 // k, R, stream, args.settle_ms) for k in (1, 2, 4, 8)]
     del eng
     # BASELINE configs[1]: 4 096 envs (64 workgroups on 256 CUs: chain-latency-bound)
     eng = reach_engine(4096, dev, rank, False)
     m = measure_rollout(eng, T, 32, 2, R, stream, args.settle_ms)
-    out['reach_ball_4096'] = rollout_entry(m, 4096, T, eng.kernel_name(), None)
+    out['reach_ball_4096'] = rollout_entry(m, 4096, T, eng.kernel_name(), 'rollout-rotate')
     out['reach_ball_4096']['workload'] = workload_of('reach_ball', 4096, 1, False)[1]
     out['reach_ball_4096']['step_api'] = measure_steps(eng, 2048, R, stream, args.settle_ms)
     del eng

@@ -74,6 +74,25 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_reset_kernel(S2DHot p, const
   store_obs_tile(lds[wv], ob, lane, in_range, o.obs + wave_first * S2D_OBS_DIM, (int)rows * S2D_OBS_DIM);
 }
 
+// The refill workgroups of s2d_step / s2d_step_k (see StepOut::prep): episode e + 2 into slot e & 1 where it is missing -- never the
+// slot that holds episode e + 1, the only one a main wave of the same launch takes a reset from.
+template <bool NOISE>
+S2D_DEV void refill_prepared_slots(const S2DHot& p, const S2DRare* __restrict__ rp, float* __restrict__ S, int64_t stride, int64_t n,
+                                   const StepOut& o, int lane, uint32_t* scratch) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool need = false;
+  uint32_t e2 = 0u;
+  if (i < n) {
+    const uint32_t* const tags = prep_tags(o.prep, stride);
+    const uint32_t t0 = tags[i], t1 = tags[stride + i];    // both tags: no load whose address waits for another load
+    e2 = reinterpret_cast<const uint32_t*>(S + F_EPISODE * stride)[i] + 2u;
+    need = (((e2 & 1u) ? t1 : t0) & kPrepTagMask) != (e2 & kPrepTagMask);
+  }
+  if (__ballot(need) == 0ull) return;                      // wave-uniform
+  const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
+  prep_store_coop<NOISE>(p, rp, o.prep, stride, i, (uint32_t)gid, (uint32_t)(gid >> 32), e2, need, lane, scratch);   // the wave draws together
+}
+
 template <int MODE, bool NOISE>
 __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const S2DRare* __restrict__ rp,
                                                                 float* __restrict__ S, int64_t stride, int64_t n,
@@ -81,22 +100,8 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
                                                                 StepOut o, int refill_blocks) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-  if ((int)blockIdx.x < refill_blocks) {
-    // ---- refill workgroups (see StepOut::prep), the FIRST blocks of the grid so that they start first: episode e + 2 into
-    // slot e & 1 where it is missing
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    bool need = false;
-    uint32_t e2 = 0u;
-    if (i < n) {
-      const uint32_t* const tags = prep_tags(o.prep, stride);
-      const uint32_t t0 = tags[i], t1 = tags[stride + i];  // both tags: no load whose address waits for another load
-      e2 = reinterpret_cast<const uint32_t*>(S + F_EPISODE * stride)[i] + 2u;
-      need = ((e2 & 1u) ? t1 : t0) != e2;
-    }
-    if (__ballot(need) == 0ull) return;                    // wave-uniform
-    const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
-    prep_store_coop<NOISE>(p, rp, o.prep, stride, i, (uint32_t)gid, (uint32_t)(gid >> 32), e2, need, lane,
-                           reinterpret_cast<uint32_t*>(&lds[wv][0]));   // the wave draws together: bounded number of rounds
+  if ((int)blockIdx.x < refill_blocks) {                   // the FIRST blocks of the grid, so that they start first
+    refill_prepared_slots<NOISE>(p, rp, S, stride, n, o, lane, reinterpret_cast<uint32_t*>(&lds[wv][0]));
     return;
   }
   const int main_block = (int)blockIdx.x - refill_blocks;
@@ -150,8 +155,8 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
         float pw[PS_WORDS];
 #pragma unroll
         for (int w = 0; w < PS_WORDS; ++w) pw[w] = odd ? pw1[w] : pw0[w];
-        if (ptag == (uint32_t)e.episode + 1u) {            // prepared: a copy + the words that follow from it
-          const NextEpisode q = prep_episode(p, rp, pw);
+        if ((ptag & kPrepTagMask) == (((uint32_t)e.episode + 1u) & kPrepTagMask)) {   // prepared: a copy + the words that follow from it
+          const NextEpisode q = prep_episode(p, rp, pw, ptag);
           episode_begin(e, q);
           const FirstObs f = first_obs(p, q);
 #pragma unroll
@@ -178,6 +183,110 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_kernel(S2DHot p, const 
               wave_count(active && res == S2D_RESULT_OUT), wave_count(active && res == S2D_RESULT_TIMEOUT));
 }
 
+
+// s2d_step_k: K cycles of the per-step API in ONE launch (SURVEY 8b's s2d_step_k; a learner that supplies its actions for K steps --
+// action repeat, open-loop chunks -- pays the launch and the state round trip once).  The per-step kernel's shape: one wave per 64
+// envs, no prologue, resets served from the persistent prepared slots (refill workgroups in front of the grid) -- at most ONE per env
+// and launch from a slot (the slot of episode e + 2 may be rewritten by this launch's refill workgroups while it is read), later
+// ones are drawn inline.  Per-step outputs go to the caller's record [K][N] (any array may be NULL), the last step's also to the arena.
+template <int MODE, bool NOISE>
+__global__ __launch_bounds__(kBlock) void s2d_reach_step_k_kernel(S2DHot p, const S2DRare* __restrict__ rp,
+                                                                  float* __restrict__ S, int64_t stride, int64_t n, int n_steps,
+                                                                  const void* __restrict__ actions, int kind, RolloutOut ro,
+                                                                  StepOut o, int refill_blocks) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kObsTile];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if ((int)blockIdx.x < refill_blocks) {
+    refill_prepared_slots<NOISE>(p, rp, S, stride, n, o, lane, reinterpret_cast<uint32_t*>(&lds[wv][0]));
+    return;
+  }
+  const int64_t i = (int64_t)((int)blockIdx.x - refill_blocks) * kBlock + threadIdx.x;
+  const int64_t wave_first = i - lane;
+  if (wave_first >= n) return;                           // wave-uniform
+  const bool active = i < n;
+  int64_t rows = n - wave_first; if (rows > kWave) rows = kWave;
+  const int valid = (int)rows * S2D_OBS_DIM;
+  const bool use_k = uses_policy_step<MODE, NOISE>(kind);
+  uint32_t* const kplane = reinterpret_cast<uint32_t*>(S + F_POLICY * stride);
+  unsigned long long* const srow = stats_row(o.stats, wave_first);
+  const unsigned long long sold = stats_load(srow, lane);
+  Env e{};
+  uint32_t gl = 0, gh = 0, k0 = 0;
+  float pw0[PS_WORDS], pw1[PS_WORDS];
+  uint32_t ptag0 = 0u, ptag1 = 0u;
+#pragma unroll
+  for (int w = 0; w < PS_WORDS; ++w) { pw0[w] = 0.0f; pw1[w] = 0.0f; }
+  if (active) {
+    env_load(e, S, stride, i);
+    const uint64_t gid = (((uint64_t)p.gid_hi << 32) | p.gid_lo) + (uint64_t)i;
+    gl = (uint32_t)gid; gh = (uint32_t)(gid >> 32);
+    if (use_k) k0 = kplane[i];
+    if (p.auto_reset) {                                    // both slots travel with the state (see s2d_reach_step_kernel)
+      const float* src = o.prep + i;
+#pragma unroll
+      for (int w = 0; w < PS_WORDS; ++w) { pw0[w] = src[w * stride]; pw1[w] = src[(PS_WORDS + w) * stride]; }
+      ptag0 = prep_tags(o.prep, stride)[i]; ptag1 = prep_tags(o.prep, stride)[stride + i];
+    }
+  }
+  ObsOut ob;
+  U4 quad{0, 0, 0, 0}, squad{0, 0, 0, 0};
+  float reward = 0.0f, dir = 0.0f; int done = 0, cmd = 0, res = 0;
+  bool slot_used = false;
+  unsigned int c1 = 0, c2 = 0, c3 = 0;                     // wave-uniform episode counters
+  int64_t row = 0;
+  for (int t = 0; t < n_steps; ++t, row += n) {
+    res = 0;
+    if (active) {
+      const uint32_t k = k0 + (uint32_t)t;
+      const CmdPrep c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, t == 0 || (k & 3u) == 0u, quad, squad, ro.action, cmd, dir);
+      e.step_number += 1;                                  // reach_ball_env.py:55
+      NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      if (NOISE) nz = noise_prepare(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);
+      float d2 = sim_cycle<NOISE, true>(p, rp, e, cmd, c, nz);   // trainer forces PlayOn each cycle (soccer_2d_env.py:242)
+      observe_and_check(p, e, d2, ob, done, reward, res);
+      if (done && p.auto_reset) {                          // SB3 VecEnv convention
+        float* const terminal_row = o.terminal_obs + i * S2D_OBS_DIM;
+#pragma unroll
+        for (int w = 0; w < S2D_OBS_DIM; ++w) terminal_row[w] = ob.o[w];
+        const bool odd = (((uint32_t)e.episode + 1u) & 1u) != 0u;
+        const uint32_t ptag = odd ? ptag1 : ptag0;
+        // only the FIRST reset of a launch may come from a slot: it wants episode e + 1, whose slot this launch's refill workgroups
+        // leave alone; a later one wants e + 2, the slot they may be writing while it was loaded above
+        const bool first_reset = !slot_used;
+        slot_used = true;
+        if (first_reset && (ptag & kPrepTagMask) == (((uint32_t)e.episode + 1u) & kPrepTagMask)) {   // prepared: a copy
+          float pw[PS_WORDS];
+#pragma unroll
+          for (int w = 0; w < PS_WORDS; ++w) pw[w] = odd ? pw1[w] : pw0[w];
+          const NextEpisode q = prep_episode(p, rp, pw, ptag);
+          episode_begin(e, q);
+          const FirstObs f = first_obs(p, q);
+#pragma unroll
+          for (int w = 0; w < S2D_OBS_DIM; ++w) ob.o[w] = f.o[w];
+          e.prev_dist = f.dist; e.prev_angle = f.rel;      // reach_ball_env.py:166: carry seeded
+        } else {                                           // no valid slot (left): draw it here
+          d2 = env_reset<NOISE>(p, rp, e, gl, gh);
+          int dn2, r2; float w2;
+          observe_and_check(p, e, d2, ob, dn2, w2, r2);    // reach_ball_env.py:166: carry seeded, outputs dropped
+        }
+      }
+      if (ro.reward) ro.reward[row + i] = reward;
+      if (ro.done) ro.done[row + i] = (uint8_t)done;
+      if (ro.result) ro.result[row + i] = (uint8_t)res;
+    }
+    c1 += wave_count(active && res == S2D_RESULT_GOAL); c2 += wave_count(active && res == S2D_RESULT_OUT);
+    c3 += wave_count(active && res == S2D_RESULT_TIMEOUT);
+    if (ro.obs) store_obs_tile(lds[wv], ob, lane, active, ro.obs + (row + wave_first) * S2D_OBS_DIM, valid);
+  }
+  if (active) {
+    env_store(e, S, stride, i);
+    if (use_k) kplane[i] = k0 + (uint32_t)n_steps;
+    o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
+    o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
+  }
+  store_obs_tile(lds[wv], ob, lane, active, o.obs + wave_first * S2D_OBS_DIM, valid);
+  stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, c1, c2, c3);
+}
 
 template <int MODE, bool NOISE>
 __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr, const S2DRare* __restrict__ rp,
@@ -370,6 +479,17 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 #define WS_STAMP_STORE() do {} while (0)
 #endif
 
+// Work dealt by slack (round 4, in clocks: profiles/r04/ws_stamps_balance.txt).  With noise off the policy wave is the short one
+// (~650 of ~1085 clocks per iteration) and the agent and ball waves the long ones.  S2D_BALLDIR_IN_P: the policy wave computes the
+// ball's direction -- word 7 of the observation row, one atan2 -- from the snapshot, beside its own step; S2D_DR_IN_B: the ball wave,
+// which reads the snapshot's flags word anyway, derives done / result and keeps the episode counters (the agent wave keeps the reward).
+#ifndef S2D_BALLDIR_IN_P
+#define S2D_BALLDIR_IN_P 1
+#endif
+#ifndef S2D_DR_IN_B
+#define S2D_DR_IN_B 1
+#endif
+
 // REC: what the kernel knows about the record at compile time.  0: nothing (every array may be absent, `nt` is a run-time flag);
 // 1 / 2: all five arrays are there and the stores are plain / non-temporal.  The presence tests and the nt selection are
 // wave-uniform branches, eleven of them per cycle in the two waves that store -- and those are the long waves when noise is off:
@@ -393,6 +513,8 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
   __shared__ float4 act_lut[kWave];                        // decoded commands of a small discrete action space
   __shared__ float ep_lds[S2D_TAB_MAX];                    // dash-only fast path: effort * power by step number
   __shared__ float2 sc_lut[361];                           //   and (sin, cos) of the whole degrees -180 .. 180
+  constexpr bool kBallDirInP = S2D_BALLDIR_IN_P != 0 && !NOISE;   // (with noise the policy wave is the long one)
+  constexpr bool kDrInB = S2D_DR_IN_B != 0 && !NOISE;
   const int lane = threadIdx.x & (kWave - 1);
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 agent, 3 ball
   const bool nt = REC == 2 || (REC == 0 && ro.nt != 0);     // the small arrays (action, reward, done, result)
@@ -417,6 +539,9 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
 
   if (role == 0) {
     if constexpr (NOISE) __builtin_amdgcn_s_setprio(1);    // two Philox blocks per four cycles: the second-longest chain with noise
+#ifdef S2D_PRIO_P
+    else __builtin_amdgcn_s_setprio(S2D_PRIO_P);
+#endif
     // ------------------------------------------------------------------ P-wave
     const S2DHot& p = p_sgpr;
     const bool use_k = uses_policy_step<MODE, NOISE>(kind);
@@ -472,15 +597,29 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
       }
       wslot = wslot == 2 ? 0 : wslot + 1;
     };
+    float o7 = 0.0f;                                       // kBallDirInP: word 7 of the observation row of step s - 2
     for (int s = 0; s < n_iter; ++s) {                     // iteration s: step s + 1 (iteration 0: steps 0 and 1)
       if (s == 0 && n_steps > 0) policy_step(0);
       if (s + 1 < n_steps) policy_step(s + 1);
+      if constexpr (kBallDirInP) {
+        if (s >= 2 && s < n_steps + 2 && active) {         // like the ball wave: step s - 2, from the snapshot
+          const int b = s & 1;
+          const int fw = __float_as_int(snap[b][WS_FLAGS][lane]);
+          o7 = observe_ball_direction(snap[b][WS_BVX][lane], snap[b][WS_BVY][lane]);
+          if ((fw & 0xff) && p.auto_reset) {               // rare: terminal row, then the new episode's first obs
+            o.terminal_obs[i * S2D_OBS_DIM + 7] = o7;
+            o7 = slots[fw >> 8][SL_FIRST + 7][lane];
+          }
+          if (REC != 0 || ro.obs) tile[b][lane * S2D_OBS_DIM + 7] = o7;
+        }
+      }
       WS_BARRIER();
     }
     WS_STAMP_STORE();
     if (active) {
       if (use_k) kplane[i] = k0 + (uint32_t)n_steps;
       o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
+      if (kBallDirInP) o.obs[i * S2D_OBS_DIM + 7] = o7;    // last observation, this wave's word
     }
   } else if (role == 1) {
     // ------------------------------------------------------------------ S-wave
@@ -662,9 +801,11 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
             prev_dist = sl[SL_DIST][lane]; prev_angle = sl[SL_REL][lane];   // reach_ball_env.py:166 carry seeded
           }
           if (REC != 0 || ro.reward) rec_store(ro.reward + row + i, reward, nt);
-          if (REC != 0 || ro.done) rec_store(ro.done + row + i, (uint8_t)done, nt);
-          if (REC != 0 || ro.result) rec_store(ro.result + row + i, (uint8_t)res, nt);
-          cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
+          if constexpr (!kDrInB) {
+            if (REC != 0 || ro.done) rec_store(ro.done + row + i, (uint8_t)done, nt);
+            if (REC != 0 || ro.result) rec_store(ro.result + row + i, (uint8_t)res, nt);
+            cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
+          }
           if (REC != 0 || ro.obs) {                                    // this wave's four words of the row
             float* t = &tile[b][lane * S2D_OBS_DIM];
             t[0] = oa[0]; t[1] = oa[1]; t[2] = oa[2]; t[3] = oa[3];
@@ -683,24 +824,32 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
     WS_STAMP_STORE();
     if (active) {
       S[F_PREV_DIST * stride + i] = prev_dist; S[F_PREV_ANGLE * stride + i] = prev_angle;
-      o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
+      o.reward[i] = reward;
+      if (!kDrInB) { o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res; }
 #pragma unroll
       for (int k = 0; k < 4; ++k) o.obs[i * S2D_OBS_DIM + k] = oa[k];      // last observation, player half
     }
-    if (!active) { cnt1 = cnt2 = cnt3 = 0; }
+    if constexpr (!kDrInB) {
+      if (!active) { cnt1 = cnt2 = cnt3 = 0; }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      cnt1 += __shfl_xor(cnt1, off); cnt2 += __shfl_xor(cnt2, off); cnt3 += __shfl_xor(cnt3, off);
+      for (int off = 32; off > 0; off >>= 1) {
+        cnt1 += __shfl_xor(cnt1, off); cnt2 += __shfl_xor(cnt2, off); cnt3 += __shfl_xor(cnt3, off);
+      }
+      stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, cnt1, cnt2, cnt3);
     }
-    stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, cnt1, cnt2, cnt3);
   } else {
     // ------------------------------------------------------------------ B-wave (ball half, observation stream)
     if constexpr (NOISE) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(S2D_PRIO_B);
     const S2DHot p = hot_in_vgprs(p_sgpr);                 // no kernarg re-loads inside the loop
     const bool auto_reset = p_sgpr.auto_reset != 0;
-    float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here
+    float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here (without [7] if kBallDirInP)
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
+    int res = 0, done = 0;                                 // labels of the step (kDrInB), from the flags word of the snapshot
+    unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    unsigned long long* const srow = stats_row(o.stats, wave_first);
+    const unsigned long long sold = kDrInB ? stats_load(srow, lane) : 0ull;   // this group's row of the episode counters (stored after the loop)
+    int64_t row = 0;
     // every row of this group's observation stream is a whole tile at a 16-byte-aligned address when the first one is and the row
     // stride (n x 40 bytes) keeps it so
     const bool obs_all_vec = valid == kObsTile && ((n * S2D_OBS_DIM * 4) & 15) == 0 &&
@@ -713,24 +862,34 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
       constexpr bool STEADY = decltype(steady_tag)::value;
       if ((STEADY || s >= 3) && (REC != 0 || ro.obs))      // observation block of step s - 3, completed in iteration s - 1
         tile_flush(tile[(s - 1) & 1], lane, ro.obs + ((int64_t)(s - 3) * n + wave_first) * S2D_OBS_DIM, valid, nt, obs_all_vec);
-      if ((STEADY || (s >= 2 && s < n_steps + 2)) && active) {   // step s - 2
+      if (STEADY || (s >= 2 && s < n_steps + 2)) {         // step s - 2
+       res = 0;
+       if (active) {
         const int b = s & 1;
         float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
         float bvx = snap[b][WS_BVX][lane], bvy = snap[b][WS_BVY][lane];
         const int fw = __float_as_int(snap[b][WS_FLAGS][lane]);
-        observe_ball(p, bx, by, bvx, bvy, ob6);
+        if constexpr (kDrInB) {                            // reach_ball_env.py:137-150: done and the label follow from the flags alone
+          res = label_of(fw & 0xff); done = (fw & 0xff) ? 1 : 0;
+          if (REC != 0 || ro.done) rec_store(ro.done + row + i, (uint8_t)done, nt);
+          if (REC != 0 || ro.result) rec_store(ro.result + row + i, (uint8_t)res, nt);
+          cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
+        }
+        observe_ball(p, bx, by, bvx, bvy, ob6);            // (word 7 is dead code here when the policy wave computes it)
         if ((fw & 0xff) && auto_reset) {                   // rare: terminal row, then the new episode's first obs
           const float (*sl)[kWave] = slots[fw >> 8];
 #pragma unroll
-          for (int k = 4; k < S2D_OBS_DIM; ++k) term_row[k] = ob6[k];
+          for (int k = 4; k < S2D_OBS_DIM; ++k) if (!(kBallDirInP && k == 7)) term_row[k] = ob6[k];
 #pragma unroll
-          for (int k = 4; k < S2D_OBS_DIM; ++k) ob6[k] = sl[SL_FIRST + k][lane];
+          for (int k = 4; k < S2D_OBS_DIM; ++k) if (!(kBallDirInP && k == 7)) ob6[k] = sl[SL_FIRST + k][lane];
         }
         if (REC != 0 || ro.obs) {
           float* t = &tile[b][lane * S2D_OBS_DIM];
 #pragma unroll
-          for (int k = 4; k < S2D_OBS_DIM; ++k) t[k] = ob6[k];
+          for (int k = 4; k < S2D_OBS_DIM; ++k) if (!(kBallDirInP && k == 7)) t[k] = ob6[k];
         }
+       }
+       row += n;
       }
       WS_BARRIER();
     };
@@ -743,7 +902,16 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
     WS_STAMP_STORE();
     if (active) {
 #pragma unroll
-      for (int k = 4; k < S2D_OBS_DIM; ++k) o.obs[i * S2D_OBS_DIM + k] = ob6[k];   // last observation, ball half
+      for (int k = 4; k < S2D_OBS_DIM; ++k) if (!(kBallDirInP && k == 7)) o.obs[i * S2D_OBS_DIM + k] = ob6[k];   // last observation, ball half
+      if (kDrInB) { o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res; }
+    }
+    if constexpr (kDrInB) {
+      if (!active) { cnt1 = cnt2 = cnt3 = 0; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        cnt1 += __shfl_xor(cnt1, off); cnt2 += __shfl_xor(cnt2, off); cnt3 += __shfl_xor(cnt3, off);
+      }
+      stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, cnt1, cnt2, cnt3);
     }
   }
 }
@@ -1232,6 +1400,34 @@ S2D_API int s2d_step(S2DHandle h, const void* actions_dev, int action_kind, void
                      refill_blocks);
   HIP_TRY(hipGetLastError());
   h->last_kernel = "s2d_reach_step_kernel";
+  return S2D_OK;
+}
+
+S2D_API int s2d_step_k(S2DHandle h, int k, const void* actions_dev, int action_kind, const S2DRollout* out, void* stream) {
+  if (!h) return fail(S2D_EINVAL, "NULL handle");
+  if (k < 1 || k > 64) return fail(S2D_EINVAL, "s2d_step_k: k must be in [1, 64] (longer launches: s2d_rollout)");
+  if (action_kind == S2D_ACT_COMMAND) return fail(S2D_EINVAL, "S2D_ACT_COMMAND is a per-step action kind (s2d_step)");
+  int rc = check_action_kind(h, actions_dev, action_kind);
+  if (rc != S2D_OK) return rc;
+  RolloutOut ro{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  if (out) {
+    ro = RolloutOut{out->obs, out->action, out->reward, out->done, out->result, 0};
+    if (h->mode == S2D_MODE_TURN4 && (reinterpret_cast<uintptr_t>(out->action) & 15u))
+      return fail(S2D_EINVAL, "record action buffer float[K][N][4] must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(out->obs) & 3u) return fail(S2D_EINVAL, "record obs buffer must be 4-byte aligned");
+  }
+  DeviceGuard guard(h->device);
+  using StepK = void (*)(S2DHot, const S2DRare*, float*, int64_t, int64_t, int, const void*, int, RolloutOut, StepOut, int);
+  static const StepK table[3][2] = {
+      {s2d_reach_step_k_kernel<S2D_MODE_DISCRETE, false>, s2d_reach_step_k_kernel<S2D_MODE_DISCRETE, true>},
+      {s2d_reach_step_k_kernel<S2D_MODE_CONT1, false>, s2d_reach_step_k_kernel<S2D_MODE_CONT1, true>},
+      {s2d_reach_step_k_kernel<S2D_MODE_TURN4, false>, s2d_reach_step_k_kernel<S2D_MODE_TURN4, true>}};
+  const int main_blocks = grid_for(h->n), refill_blocks = h->cfg.auto_reset ? main_blocks : 0;
+  hipLaunchKernelGGL(table[h->mode][h->noise ? 1 : 0], dim3(main_blocks + refill_blocks), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), h->hot, h->rare_dev, reinterpret_cast<float*>(h->buf.player_x), h->stride, h->n,
+                     k, actions_dev, action_kind, ro, h->out, refill_blocks);
+  HIP_TRY(hipGetLastError());
+  h->last_kernel = "s2d_reach_step_k_kernel";
   return S2D_OK;
 }
 

@@ -51,6 +51,13 @@ struct StepOut {
 // rollout kernels advanced the episode counter) is ignored and the reset is drawn inline, once.
 enum { PS_PX, PS_PY, PS_BODY, PS_BX, PS_BY, PS_BVX, PS_BVY, PS_WORDS };
 S2D_DEV uint32_t* prep_tags(float* prep, int64_t stride) { return reinterpret_cast<uint32_t*>(prep + 2 * PS_WORDS * stride); }
+// A tag = the episode index the slot holds (bits 0..29) + the SIGNS of the player's post-reset velocity (bits 31, 30): the player of a
+// fresh episode is at rest, but a collision in the reset's cycle multiplies its +0 velocity by collision_vel_rate < 0 and leaves -0
+// (54 of 650 000 resets of the stock task) -- a state word the CPU checker holds bit for bit.  (Round 3 restored +0 always.)
+static constexpr uint32_t kPrepTagMask = 0x3fffffffu;
+S2D_DEV uint32_t prep_tag_of(uint32_t episode, const NextEpisode& q) {
+  return (episode & kPrepTagMask) | ((uint32_t)__float_as_int(q.vx) & 0x80000000u) | (((uint32_t)__float_as_int(q.vy) & 0x80000000u) >> 1);
+}
 
 // LDS ops of one wave execute in order, so a wave-private tile needs no s_barrier; the
 // wavefront-scope fences only stop the compiler from reordering the cross-lane accesses.
@@ -313,7 +320,7 @@ S2D_DEV void prep_store(const S2DHot& p, const S2DRare* __restrict__ rp, float* 
   const float w[PS_WORDS] = {q.px, q.py, q.body, q.bx, q.by, q.bvx, q.bvy};
 #pragma unroll
   for (int k = 0; k < PS_WORDS; ++k) d[k * stride] = w[k];
-  prep_tags(prep, stride)[(int64_t)(episode & 1u) * stride + i] = episode;
+  prep_tags(prep, stride)[(int64_t)(episode & 1u) * stride + i] = prep_tag_of(episode, q);
 }
 // the refill workgroups' form: the whole wave draws together (reset_sample_coop; `need` = this lane's slot is to be drawn)
 template <bool NOISE>
@@ -326,17 +333,18 @@ S2D_DEV void prep_store_coop(const S2DHot& p, const S2DRare* __restrict__ rp, fl
     const float w[PS_WORDS] = {q.px, q.py, q.body, q.bx, q.by, q.bvx, q.bvy};
 #pragma unroll
     for (int k = 0; k < PS_WORDS; ++k) d[k * stride] = w[k];
-    prep_tags(prep, stride)[(int64_t)(episode & 1u) * stride + i] = episode;
+    prep_tags(prep, stride)[(int64_t)(episode & 1u) * stride + i] = prep_tag_of(episode, q);
   }
 }
 // the post-reset state from a slot: the drawn words + what every reset leaves behind (reset_apply: player at rest -- its
 // velocity stays +0 through the command-less cycle, with noise on too: the noise magnitude is proportional to the speed --
 // and the stamina model one update after a recover)
-S2D_DEV NextEpisode prep_episode(const S2DHot& p, const S2DRare* __restrict__ rp, const float* w) {
+S2D_DEV NextEpisode prep_episode(const S2DHot& p, const S2DRare* __restrict__ rp, const float* w, uint32_t tag) {
   Env t{};
   t.stamina = p.stamina_max; t.recovery = rp->recover_init; t.effort = p.effort_init; t.capacity = p.stamina_capacity;
   update_stamina(p, t);
-  return NextEpisode{w[PS_PX], w[PS_PY], 0.0f, 0.0f, w[PS_BODY], t.stamina, t.effort, t.recovery, t.capacity,
+  return NextEpisode{w[PS_PX], w[PS_PY], __int_as_float((int)(tag & 0x80000000u)), __int_as_float((int)((tag << 1) & 0x80000000u)), w[PS_BODY],
+                     t.stamina, t.effort, t.recovery, t.capacity,
                      w[PS_BX], w[PS_BY], w[PS_BVX], w[PS_BVY]};
 }
 

@@ -123,6 +123,7 @@ PROTOTYPES = (
     ('s2d_reset', C.c_int, (C.c_void_p, C.c_void_p, C.c_void_p)),
     ('s2d_step', C.c_int, (C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)),
     ('s2d_rollout', C.c_int, (C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(S2DRollout), C.c_void_p)),
+    ('s2d_step_k', C.c_int, (C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(S2DRollout), C.c_void_p)),
     ('s2d_world_model', C.c_int, (C.c_void_p, C.POINTER(S2DWorldModel), C.c_void_p)),
     ('s2d_stats_reset', C.c_int, (C.c_void_p, C.c_void_p)),
     ('s2d_kernel_name', C.c_char_p, (C.c_void_p,)),

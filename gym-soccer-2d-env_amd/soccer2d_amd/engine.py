@@ -207,6 +207,25 @@ class Engine:
         self._keep = (keep, out)
         return out
 
+    def step_k(self, k, actions=None, out=None):
+        """k cycles of the per-step API in ONE launch (s2d_step_k; 1 <= k <= 64): for a learner that holds its actions for k steps
+        ahead (action repeat, open-loop chunks).  actions [k, N, ...] as for rollout() (None = in-kernel random policy); returns the
+        per-step record {obs [k,N,10], action, reward, done, result}; self.obs / reward / done / result hold the last step."""
+        k = int(k)
+        keep, ptr, kind = self._action_arg(actions, leading=k)
+        if out is None:
+            out = self.alloc_rollout(k)
+        ro = _capi.S2DRollout()
+        for name in ('obs', 'action', 'reward', 'done', 'result'):
+            v = out.get(name)
+            if v is not None:
+                if not v.is_contiguous() or v.device != self.device or v.shape[0] < k or v.shape[1] != self.num_envs:
+                    raise ValueError(f"record buffer {name!r} must be a contiguous [K>={k},{self.num_envs},...] tensor on {self.device}")
+                setattr(ro, name, v.data_ptr())
+        _capi.check(self.lib, self.lib.s2d_step_k(self._h, k, ptr, kind, C.byref(ro), self._stream()), 's2d_step_k')
+        self._keep = (keep, out)
+        return out
+
     def alloc_rollout(self, T, with_obs=True, slab=False, fields=None):
         """Caller-owned rollout buffers for `rollout(..., out=)`.  slab=True carves the fields out of ONE contiguous
         uint8 tensor (256-byte aligned fields; returned under the key '_slab'), so that a rollout record travels in a

@@ -213,6 +213,11 @@ int s2d_reset(S2DHandle h, const uint8_t *mask_dev, void *stream);
 /* one cycle for every env: decode action, dash/turn, stamina, integrate, collide, decay,
  * obs, reward/done/result, auto-reset under cfg.auto_reset. */
 int s2d_step(S2DHandle h, const void *actions_dev, int action_kind, void *stream);
+/* k cycles (1 <= k <= 64) of the per-step API in ONE launch, for callers that hold their actions for k steps ahead (action repeat,
+ * open-loop chunks): actions_dev is [k][N] in `action_kind` layout (or NULL with S2D_ACT_RANDOM); `out` (may be NULL, and any of its
+ * arrays may be NULL) receives the per-step record [k][N]; the arena's per-step outputs hold the last step.  Same results as k calls
+ * of s2d_step (soccer_2d_env.py:226-269 each); no prologue, the state makes one round trip. */
+int s2d_step_k(S2DHandle h, int k, const void *actions_dev, int action_kind, const S2DRollout *out, void *stream);
 /* n_steps cycles fused in ONE launch (state stays in registers).  actions_dev is
  * [T][N] in `action_kind` layout, or NULL with S2D_ACT_RANDOM. */
 int s2d_rollout(S2DHandle h, int n_steps, const void *actions_dev, int action_kind,

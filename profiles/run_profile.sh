@@ -3,7 +3,7 @@
 # Produces gpurun_out/<tag>/ : the default bench line, per-mode lines, rocprofv3 kernel stats of the SAME bench command as the
 # default line, PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes) and instruction-mix passes.  Copy what is to be judged
 # into profiles/<round>/ (gpurun_out/ is scratch).
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -28,6 +28,12 @@ pmc rollout64rot_fetch FETCH_SIZE --fuse 64 --steps 18 --warmup 3
 pmc rollout64rot_write WRITE_SIZE --fuse 64 --steps 18 --warmup 3
 pmc rollout64one_fetch FETCH_SIZE --fuse 64 --steps 16 --warmup 1 --rotate-buffers 1
 pmc rollout64one_write WRITE_SIZE --fuse 64 --steps 16 --warmup 1 --rotate-buffers 1
+pmc noise256_fetch FETCH_SIZE --noise --steps 8 --warmup 1
+pmc noise256_write WRITE_SIZE --noise --steps 8 --warmup 1
+pmc r4096_fetch FETCH_SIZE --envs 4096 --steps 16 --warmup 2
+pmc r4096_write WRITE_SIZE --envs 4096 --steps 16 --warmup 2
+pmc r1m_fetch FETCH_SIZE --envs 1048576 --fuse 64 --steps 4 --warmup 1
+pmc r1m_write WRITE_SIZE --envs 1048576 --fuse 64 --steps 4 --warmup 1
 pmc step_fetch FETCH_SIZE --mode step --steps 1024 --warmup 64
 pmc step_write WRITE_SIZE --mode step --steps 1024 --warmup 64
 pmc match_fetch FETCH_SIZE --task match --steps 8 --warmup 1

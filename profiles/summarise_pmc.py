@@ -26,6 +26,8 @@ def per_dispatch(tag, kern):
 rows = []
 for name, mode, fuse, envs, kern in (('rollout256', 'rollout-rotate', 256, 65536, 'rollout_'), ('rollout64rot', 'rollout-rotate', 64, 65536, 'rollout_'),
                                      ('rollout64one', 'rollout', 64, 65536, 'rollout_'), ('step', 'step', 64, 65536, 'step_kernel'),
+                                     ('noise256', 'rollout-rotate-noise', 256, 65536, 'rollout_'), ('r4096', 'rollout-rotate', 256, 4096, 'rollout_'),
+                                     ('r1m', 'rollout-rotate', 64, 1048576, 'rollout_'),
                                      ('match', 'match-rollout', 64, 8192, 'match_rollout')):
     f = per_dispatch('pmc_%s_fetch' % name, kern).get('FETCH_SIZE')
     w = per_dispatch('pmc_%s_write' % name, kern).get('WRITE_SIZE')

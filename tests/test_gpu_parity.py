@@ -356,6 +356,66 @@ def test_full_size_parity_other_configurations(name):
     assert st[0] == n * T and st[1:4].sum() == done.sum()
 
 
+@pytest.mark.parametrize('noise', [False, True])
+def test_colliding_resets_keep_the_sign_of_zero(noise):
+    """A reset whose command-less cycle ends in a player-ball collision multiplies the resting player's +0 velocity by
+    collision_vel_rate < 0 and leaves -0 in the state (54 of 650 000 resets of the stock task; here nearly all: a player as large as
+    half the pitch).  The per-step API serves resets from prepared slots that keep seven words of the post-reset state -- and the
+    two signs in the slot's tag (round 3 restored +0 and differed from the checker in that sign bit).  Every state word, step by
+    step, through the per-step API and through the rollout pipelines."""
+    kw = dict(use_continuous_action=False, action_space_size=16, change_ball_velocity=True, max_steps=3, noise=noise,
+              server=dict(player_size=25.0))
+    n = 777
+    eng, orc = _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); orc.reset()
+    minus_zero = 0
+    for t in range(40):
+        eng.step(None); orc.step(None)
+        assert_state_same(eng, orc, f't={t}')
+        vx = orc.state('player_vx')
+        minus_zero += int(((vx == 0) & np.signbit(vx)).sum())
+    assert minus_zero > 1000                               # the case really occurs
+    for T in (30, 5):
+        _compare_rollout(eng.rollout(T), orc.rollout(T), f'rollout T={T}')
+        assert_state_same(eng, orc, f'rollout T={T}')
+    for t in range(6):                                      # and again through slots that a rollout left stale
+        eng.step(None); orc.step(None)
+        assert_state_same(eng, orc, f'after rollouts t={t}')
+
+
+@pytest.mark.parametrize('name', ['dqn-discrete16', 'turning4', 'noise-on', 'no-autoreset-collide'])
+def test_step_k_equals_k_steps(name):
+    """s2d_step_k: k cycles of the per-step API in one launch == k calls of s2d_step == the oracle (every record word, the state,
+    the arena's last-step outputs, the episode counters), with caller actions and with the in-kernel policy, k = 1, 2, 4, 7;
+    episodes short enough that an env ends more than one inside a launch (the second reset is drawn inline)."""
+    kw = dict(CONFIGS[name]); kw['max_steps'] = min(kw.get('max_steps', 200), 5)
+    n = 777
+    eng, one, orc = _engine(n, **dict(kw)), _engine(n, **dict(kw)), _oracle(n, **dict(kw))
+    eng.reset(); one.reset(); orc.reset()
+    rs = np.random.RandomState(3)
+    for rep, k in enumerate([1, 2, 4, 7, 2, 4, 1, 7]):
+        if rep % 2:
+            a = np.stack([_random_actions(rs, kw, n) for _ in range(k)])
+            out, ref = eng.step_k(k, torch.as_tensor(a, device='cuda:0')), orc.rollout(k, a)
+            for t in range(k):
+                one.step(torch.as_tensor(a[t], device='cuda:0'))
+        else:
+            out, ref = eng.step_k(k), orc.rollout(k)
+            for t in range(k):
+                one.step(None)
+        assert eng.kernel_name() == 's2d_reach_step_k_kernel'
+        _compare_rollout(out, ref, f'{name} k={k} rep={rep}')
+        assert_state_same(eng, orc, f'{name} k={k} rep={rep}')
+        assert_same(eng.obs, orc.obs(), f'{name} k={k} last obs'); assert_same(eng.reward, orc.reward(), f'{name} k={k} last reward')
+        assert_same(eng.done, orc.done(), 'last done'); assert_same(eng.result, orc.result(), 'last result')
+        for f in O.STATE_FIELDS:
+            assert torch.equal(getattr(eng, f), getattr(one, f)), (name, k, f)
+        assert torch.equal(eng.obs, one.obs) and torch.equal(eng.stats, one.stats)
+    assert int(eng.stats[1:4].sum()) > n
+    with pytest.raises(ValueError):
+        eng.step_k(65)
+
+
 def test_errors_are_loud():
     from soccer2d_amd.engine import Engine, make_config
     with pytest.raises(ValueError):
