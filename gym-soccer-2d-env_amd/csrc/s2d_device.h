@@ -365,16 +365,6 @@ S2D_DEV float reward_of(float prev_dist, float prev_angle, float dist, float rel
   return r;
 }
 
-// the label alone (reach_ball_env.py:137-150: later label overwrites earlier) -- the value reward_of() returns in `result`
-S2D_DEV int label_of(int flags) {
-  int res = (flags & S2D_FLAG_GOAL) ? S2D_RESULT_GOAL : S2D_RESULT_NONE;
-  res = (flags & S2D_FLAG_OUT) ? S2D_RESULT_OUT : res;
-  res = (flags & S2D_FLAG_TIMEOUT) ? S2D_RESULT_TIMEOUT : res;
-  return res;
-}
-// o[7] of observe_ball() on its own (reach_ball_env.py:92, 105), for a wave that computes only the ball's direction
-S2D_DEV float observe_ball_direction(float bvx, float bvy) { return atan2_deg(bvy, bvx) * 0.002777777777777778f; }
-
 // d2 = |ball - player|^2 of the state in `e` (sim_cycle returns it)
 S2D_DEV void observe_and_check(const S2DHot& p, Env& e, float d2, ObsOut& ob, int& done, float& reward, int& result) {
   float rel = observe(p, e.px, e.py, e.body, e.bx, e.by, e.bvx, e.bvy, ob);

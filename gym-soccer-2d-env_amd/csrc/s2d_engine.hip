@@ -479,17 +479,9 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 #define WS_STAMP_STORE() do {} while (0)
 #endif
 
-// Work dealt by slack (round 4, in clocks: profiles/r04/ws_stamps_balance.txt).  With noise off the policy wave is the short one
-// (~650 of ~1085 clocks per iteration) and the agent and ball waves the long ones.  S2D_BALLDIR_IN_P: the policy wave computes the
-// ball's direction -- word 7 of the observation row, one atan2 -- from the snapshot, beside its own step; S2D_DR_IN_B: the ball wave,
-// which reads the snapshot's flags word anyway, derives done / result and keeps the episode counters (the agent wave keeps the reward).
-#ifndef S2D_BALLDIR_IN_P
-#define S2D_BALLDIR_IN_P 1
-#endif
-#ifndef S2D_DR_IN_B
-#define S2D_DR_IN_B 1
-#endif
-
+// (Dealing work by slack -- the ball's direction computed by the policy wave, done / result derived by the ball wave, the observation
+// block's tail streamed by the policy wave, a fifth wave for all stores -- was built and measured in round 4: the four waves of a SIMD
+// share one issue port that this mix keeps busy; profiles/r04/ws_stamps_balance.txt, ws_store_assignment.txt, ws_store_wave.txt.)
 // REC: what the kernel knows about the record at compile time.  0: nothing (every array may be absent, `nt` is a run-time flag);
 // 1 / 2: all five arrays are there and the stores are plain / non-temporal.  The presence tests and the nt selection are
 // wave-uniform branches, eleven of them per cycle in the two waves that store -- and those are the long waves when noise is off:
@@ -513,8 +505,6 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
   __shared__ float4 act_lut[kWave];                        // decoded commands of a small discrete action space
   __shared__ float ep_lds[S2D_TAB_MAX];                    // dash-only fast path: effort * power by step number
   __shared__ float2 sc_lut[361];                           //   and (sin, cos) of the whole degrees -180 .. 180
-  constexpr bool kBallDirInP = S2D_BALLDIR_IN_P != 0 && !NOISE;   // (with noise the policy wave is the long one)
-  constexpr bool kDrInB = S2D_DR_IN_B != 0 && !NOISE;
   const int lane = threadIdx.x & (kWave - 1);
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // 0 policy, 1 simulate, 2 agent, 3 ball
   const bool nt = REC == 2 || (REC == 0 && ro.nt != 0);     // the small arrays (action, reward, done, result)
@@ -539,9 +529,6 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
 
   if (role == 0) {
     if constexpr (NOISE) __builtin_amdgcn_s_setprio(1);    // two Philox blocks per four cycles: the second-longest chain with noise
-#ifdef S2D_PRIO_P
-    else __builtin_amdgcn_s_setprio(S2D_PRIO_P);
-#endif
     // ------------------------------------------------------------------ P-wave
     const S2DHot& p = p_sgpr;
     const bool use_k = uses_policy_step<MODE, NOISE>(kind);
@@ -597,29 +584,15 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
       }
       wslot = wslot == 2 ? 0 : wslot + 1;
     };
-    float o7 = 0.0f;                                       // kBallDirInP: word 7 of the observation row of step s - 2
     for (int s = 0; s < n_iter; ++s) {                     // iteration s: step s + 1 (iteration 0: steps 0 and 1)
       if (s == 0 && n_steps > 0) policy_step(0);
       if (s + 1 < n_steps) policy_step(s + 1);
-      if constexpr (kBallDirInP) {
-        if (s >= 2 && s < n_steps + 2 && active) {         // like the ball wave: step s - 2, from the snapshot
-          const int b = s & 1;
-          const int fw = __float_as_int(snap[b][WS_FLAGS][lane]);
-          o7 = observe_ball_direction(snap[b][WS_BVX][lane], snap[b][WS_BVY][lane]);
-          if ((fw & 0xff) && p.auto_reset) {               // rare: terminal row, then the new episode's first obs
-            o.terminal_obs[i * S2D_OBS_DIM + 7] = o7;
-            o7 = slots[fw >> 8][SL_FIRST + 7][lane];
-          }
-          if (REC != 0 || ro.obs) tile[b][lane * S2D_OBS_DIM + 7] = o7;
-        }
-      }
       WS_BARRIER();
     }
     WS_STAMP_STORE();
     if (active) {
       if (use_k) kplane[i] = k0 + (uint32_t)n_steps;
       o.action_dir[i] = dir; o.action_cmd[i] = (uint8_t)cmd;
-      if (kBallDirInP) o.obs[i * S2D_OBS_DIM + 7] = o7;    // last observation, this wave's word
     }
   } else if (role == 1) {
     // ------------------------------------------------------------------ S-wave
@@ -801,11 +774,9 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
             prev_dist = sl[SL_DIST][lane]; prev_angle = sl[SL_REL][lane];   // reach_ball_env.py:166 carry seeded
           }
           if (REC != 0 || ro.reward) rec_store(ro.reward + row + i, reward, nt);
-          if constexpr (!kDrInB) {
-            if (REC != 0 || ro.done) rec_store(ro.done + row + i, (uint8_t)done, nt);
-            if (REC != 0 || ro.result) rec_store(ro.result + row + i, (uint8_t)res, nt);
-            cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
-          }
+          if (REC != 0 || ro.done) rec_store(ro.done + row + i, (uint8_t)done, nt);
+          if (REC != 0 || ro.result) rec_store(ro.result + row + i, (uint8_t)res, nt);
+          cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
           if (REC != 0 || ro.obs) {                                    // this wave's four words of the row
             float* t = &tile[b][lane * S2D_OBS_DIM];
             t[0] = oa[0]; t[1] = oa[1]; t[2] = oa[2]; t[3] = oa[3];
@@ -824,32 +795,24 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
     WS_STAMP_STORE();
     if (active) {
       S[F_PREV_DIST * stride + i] = prev_dist; S[F_PREV_ANGLE * stride + i] = prev_angle;
-      o.reward[i] = reward;
-      if (!kDrInB) { o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res; }
+      o.reward[i] = reward; o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o.obs[i * S2D_OBS_DIM + k] = oa[k];      // last observation, player half
     }
-    if constexpr (!kDrInB) {
-      if (!active) { cnt1 = cnt2 = cnt3 = 0; }
+    if (!active) { cnt1 = cnt2 = cnt3 = 0; }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        cnt1 += __shfl_xor(cnt1, off); cnt2 += __shfl_xor(cnt2, off); cnt3 += __shfl_xor(cnt3, off);
-      }
-      stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, cnt1, cnt2, cnt3);
+    for (int off = 32; off > 0; off >>= 1) {
+      cnt1 += __shfl_xor(cnt1, off); cnt2 += __shfl_xor(cnt2, off); cnt3 += __shfl_xor(cnt3, off);
     }
+    stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, cnt1, cnt2, cnt3);
   } else {
     // ------------------------------------------------------------------ B-wave (ball half, observation stream)
     if constexpr (NOISE) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(S2D_PRIO_B);
     const S2DHot p = hot_in_vgprs(p_sgpr);                 // no kernarg re-loads inside the loop
     const bool auto_reset = p_sgpr.auto_reset != 0;
-    float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here (without [7] if kBallDirInP)
+    float ob6[S2D_OBS_DIM];                                // only ob6[4..9] are produced here
     float* const term_row = o.terminal_obs + i * S2D_OBS_DIM;
-    int res = 0, done = 0;                                 // labels of the step (kDrInB), from the flags word of the snapshot
-    unsigned int cnt1 = 0, cnt2 = 0, cnt3 = 0;
-    unsigned long long* const srow = stats_row(o.stats, wave_first);
-    const unsigned long long sold = kDrInB ? stats_load(srow, lane) : 0ull;   // this group's row of the episode counters (stored after the loop)
-    int64_t row = 0;
     // every row of this group's observation stream is a whole tile at a 16-byte-aligned address when the first one is and the row
     // stride (n x 40 bytes) keeps it so
     const bool obs_all_vec = valid == kObsTile && ((n * S2D_OBS_DIM * 4) & 15) == 0 &&
@@ -862,34 +825,24 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
       constexpr bool STEADY = decltype(steady_tag)::value;
       if ((STEADY || s >= 3) && (REC != 0 || ro.obs))      // observation block of step s - 3, completed in iteration s - 1
         tile_flush(tile[(s - 1) & 1], lane, ro.obs + ((int64_t)(s - 3) * n + wave_first) * S2D_OBS_DIM, valid, nt, obs_all_vec);
-      if (STEADY || (s >= 2 && s < n_steps + 2)) {         // step s - 2
-       res = 0;
-       if (active) {
+      if ((STEADY || (s >= 2 && s < n_steps + 2)) && active) {   // step s - 2
         const int b = s & 1;
         float bx = snap[b][WS_BX][lane], by = snap[b][WS_BY][lane];
         float bvx = snap[b][WS_BVX][lane], bvy = snap[b][WS_BVY][lane];
         const int fw = __float_as_int(snap[b][WS_FLAGS][lane]);
-        if constexpr (kDrInB) {                            // reach_ball_env.py:137-150: done and the label follow from the flags alone
-          res = label_of(fw & 0xff); done = (fw & 0xff) ? 1 : 0;
-          if (REC != 0 || ro.done) rec_store(ro.done + row + i, (uint8_t)done, nt);
-          if (REC != 0 || ro.result) rec_store(ro.result + row + i, (uint8_t)res, nt);
-          cnt1 += res == S2D_RESULT_GOAL; cnt2 += res == S2D_RESULT_OUT; cnt3 += res == S2D_RESULT_TIMEOUT;
-        }
-        observe_ball(p, bx, by, bvx, bvy, ob6);            // (word 7 is dead code here when the policy wave computes it)
+        observe_ball(p, bx, by, bvx, bvy, ob6);
         if ((fw & 0xff) && auto_reset) {                   // rare: terminal row, then the new episode's first obs
           const float (*sl)[kWave] = slots[fw >> 8];
 #pragma unroll
-          for (int k = 4; k < S2D_OBS_DIM; ++k) if (!(kBallDirInP && k == 7)) term_row[k] = ob6[k];
+          for (int k = 4; k < S2D_OBS_DIM; ++k) term_row[k] = ob6[k];
 #pragma unroll
-          for (int k = 4; k < S2D_OBS_DIM; ++k) if (!(kBallDirInP && k == 7)) ob6[k] = sl[SL_FIRST + k][lane];
+          for (int k = 4; k < S2D_OBS_DIM; ++k) ob6[k] = sl[SL_FIRST + k][lane];
         }
         if (REC != 0 || ro.obs) {
           float* t = &tile[b][lane * S2D_OBS_DIM];
 #pragma unroll
-          for (int k = 4; k < S2D_OBS_DIM; ++k) if (!(kBallDirInP && k == 7)) t[k] = ob6[k];
+          for (int k = 4; k < S2D_OBS_DIM; ++k) t[k] = ob6[k];
         }
-       }
-       row += n;
       }
       WS_BARRIER();
     };
@@ -902,16 +855,7 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
     WS_STAMP_STORE();
     if (active) {
 #pragma unroll
-      for (int k = 4; k < S2D_OBS_DIM; ++k) if (!(kBallDirInP && k == 7)) o.obs[i * S2D_OBS_DIM + k] = ob6[k];   // last observation, ball half
-      if (kDrInB) { o.done[i] = (uint8_t)done; o.result[i] = (uint8_t)res; }
-    }
-    if constexpr (kDrInB) {
-      if (!active) { cnt1 = cnt2 = cnt3 = 0; }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        cnt1 += __shfl_xor(cnt1, off); cnt2 += __shfl_xor(cnt2, off); cnt3 += __shfl_xor(cnt3, off);
-      }
-      stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, cnt1, cnt2, cnt3);
+      for (int k = 4; k < S2D_OBS_DIM; ++k) o.obs[i * S2D_OBS_DIM + k] = ob6[k];   // last observation, ball half
     }
   }
 }
