@@ -585,6 +585,55 @@ def test_stock_kernel_parity_scripted_policies():
     assert st[4] > 300 and (st[1] + st[2]) > 0, list(st)                        # many kicks, goals
 
 
+@pytest.mark.parametrize('general', [False, True])
+def test_long_rollout_with_fouls_and_catches(general, monkeypatch):
+    """The in-kernel random policy never sets Tackle.foul and never catches, so the big random-policy runs do not reach the card /
+    sending-off / parking, FoulCharge_ / PenaltyKick_, GoalieCatch_ / CatchFault_ paths nor the goalie's hand moves.  A seeded CALLER
+    policy that does -- a quarter of the tackles intentional fouls, goalies catching and moving, everybody crowding the ball --
+    over 512 matches x 384 cycles (half time included), through both instantiations: GPU == oracle in every word (UNPINNED against
+    rcssserver: the rules are the restatement of INTEGRATION section 5), and the rare paths really ran."""
+    if general:
+        monkeypatch.setenv('S2D_MATCH_GENERAL_KERNEL', '1')
+    n, T, chunks = 512, 64, 6
+    eng, orc = _pair(n, half_time_cycles=150)
+    assert eng.kernel_name().endswith('<general>')         # (a changed half time selects the general instantiation anyway)
+    if not general:
+        eng, orc = _pair(n)
+        assert eng.kernel_name().endswith('<stock, stock types>')
+    rs = np.random.RandomState(21)
+    seen_modes = set()
+
+    def policy():
+        """closed loop on the CHECKER's state: everybody runs at the ball; who is near it kicks, tackles (half of the tackles
+        intentional fouls) or, as a goalie, catches and moves"""
+        x, y, body = orc.get('x'), orc.get('y'), orc.get('body')
+        dx, dy = x[:, 22:23] - x[:, :22], y[:, 22:23] - y[:, :22]
+        dist = np.hypot(dx, dy)
+        rel = (np.degrees(np.arctan2(dy, dx)) - body[:, :22] + 540.0) % 360.0 - 180.0
+        a = np.zeros((n, 22, 3), dtype=np.float32)
+        near = dist < 2.0
+        u = rs.rand(n, 22)
+        cmd = np.where(near, rs.choice([3, 4, 4, 4, 2], size=(n, 22)), np.where(u < 0.8, 1, rs.choice([1, 2, 4], size=(n, 22))))
+        goalie = np.zeros((n, 22), bool); goalie[:, [0, 11]] = True
+        cmd = np.where(goalie & (dist < 2.5), rs.choice([5, 5, 6, 3], size=(n, 22)), cmd)
+        a[..., 0] = cmd
+        a[..., 1] = np.where(cmd == 1, 100.0, np.where(cmd == 2, rel, np.where(cmd == 5, rel, rs.uniform(-100, 100, (n, 22)))))
+        a[..., 2] = np.where(cmd == 1, rel, np.where(cmd == 4, (rs.rand(n, 22) < 0.5).astype(np.float32), rs.uniform(-60, 60, (n, 22))))
+        return a
+    for c in range(chunks):
+        acts = np.zeros((T, n, 22, 3), dtype=np.float32)
+        for t in range(T):                                    # the checker plays the chunk; the device replays its commands fused
+            acts[t] = policy()
+            orc.step(acts[t])
+        out = eng.rollout(T, torch.as_tensor(acts, device='cuda:0'), with_obs=False)
+        assert_match_same(eng, orc, f'chunk {c}')
+        seen_modes |= set(np.unique(out['mode'].cpu().numpy()).tolist())
+    card = eng.card.cpu().numpy()
+    assert list(eng.stats.cpu().numpy()) == list(orc.stats())
+    assert card.max() >= 1, 'no card was shown: the foul path did not run'
+    assert {14, 30} <= seen_modes, seen_modes                # FoulCharge_ and GoalieCatch_ were announced
+
+
 def test_stock_and_general_kernels_agree(monkeypatch):
     """Same configuration through both instantiations (S2D_MATCH_GENERAL_KERNEL=1 forces the run-time-parameter one): identical
     state words and rollout records at 2 048 matches x 3 x 64 fused cycles."""
