@@ -455,6 +455,21 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 // and the arbiter should prefer them by their slack.  Noise off: simulate / agent / ball / policy = 1/2/3/0 (the ball wave, which
 // streams the observations, on top); noise on: 3/2/2/1.  The sweeps behind these (in us and in clocks): profiles/r03/ws_prio_sweeps.txt.
 // Overridable for experiments.
+// noise on (simulate / agent / ball / policy) 3/2/2/1: tuned in round 3, when the simulating wave was the long one (1 482 busy clocks);
+// re-measured in round 4, when the policy wave is (1 233 against 879): still the fastest of six assignments
+// (profiles/r04/ab_noise_priorities.txt)
+#ifndef S2D_NPRIO_S
+#define S2D_NPRIO_S 3
+#endif
+#ifndef S2D_NPRIO_A
+#define S2D_NPRIO_A 2
+#endif
+#ifndef S2D_NPRIO_B
+#define S2D_NPRIO_B 2
+#endif
+#ifndef S2D_NPRIO_P
+#define S2D_NPRIO_P 1
+#endif
 #ifndef S2D_PRIO_S
 #define S2D_PRIO_S 1
 #endif
@@ -528,7 +543,7 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
   }
 
   if (role == 0) {
-    if constexpr (NOISE) __builtin_amdgcn_s_setprio(1);    // two Philox blocks per four cycles: the second-longest chain with noise
+    if constexpr (NOISE) __builtin_amdgcn_s_setprio(S2D_NPRIO_P);   // three Philox blocks per four cycles + the noise table reads
     // ------------------------------------------------------------------ P-wave
     const S2DHot& p = p_sgpr;
     const bool use_k = uses_policy_step<MODE, NOISE>(kind);
@@ -596,7 +611,7 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
     }
   } else if (role == 1) {
     // ------------------------------------------------------------------ S-wave
-    if constexpr (NOISE) __builtin_amdgcn_s_setprio(3);    // with noise it is this wave's chain that is the longest (3/2/2/1)
+    if constexpr (NOISE) __builtin_amdgcn_s_setprio(S2D_NPRIO_S);
     else __builtin_amdgcn_s_setprio(S2D_PRIO_S);
     const S2DHot p = hot_in_vgprs(p_sgpr);
     Env e;
@@ -732,7 +747,7 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
       S[F_EPISODE * stride + i] = __int_as_float(e.episode);
     }
   } else if (role == 2) {
-    __builtin_amdgcn_s_setprio(S2D_PRIO_A);                // (2 with and without noise)
+    __builtin_amdgcn_s_setprio(NOISE ? S2D_NPRIO_A : S2D_PRIO_A);
     // ------------------------------------------------------------------ A-wave (player half, reward, labels)
     const S2DHot p = hot_in_vgprs(p_sgpr);                 // no kernarg re-loads (s_load + s_waitcnt) inside the loop
     const bool auto_reset = p_sgpr.auto_reset != 0;
@@ -807,7 +822,7 @@ __global__ __launch_bounds__(kWsBlock, 4) void s2d_reach_rollout_ws_kernel(S2DHo
     stats_store(srow, lane, sold, wave_first == 0 ? (unsigned long long)n * (unsigned long long)n_steps : 0ull, cnt1, cnt2, cnt3);
   } else {
     // ------------------------------------------------------------------ B-wave (ball half, observation stream)
-    if constexpr (NOISE) __builtin_amdgcn_s_setprio(2);
+    if constexpr (NOISE) __builtin_amdgcn_s_setprio(S2D_NPRIO_B);
     else __builtin_amdgcn_s_setprio(S2D_PRIO_B);
     const S2DHot p = hot_in_vgprs(p_sgpr);                 // no kernarg re-loads inside the loop
     const bool auto_reset = p_sgpr.auto_reset != 0;
