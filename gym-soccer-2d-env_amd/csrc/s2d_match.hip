@@ -533,13 +533,13 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     }
     if (any_kick) g.last_touch = side_of(last_kicker);
     // free-kick fault / back-pass bookkeeping (oracle: match_step, same decisions from the same masks)
-    taker0 = gr.taker;
+    taker0 = gr.taker & 0xff;                                                    // (bit 8: his set play was an INDIRECT free kick)
     const uint32_t cmask2 = hballot(by_kick, half) & 0x3FFFFFu;                  // Kick-command kickers
     const uint32_t taker_bit = taker0 > 0 ? (1u << (taker0 - 1)) : 0u;
     const bool other_touch = (kmask & ~taker_bit) != 0u;
     fk_fault = p.free_kick_faults && mode0 == S2D_GM_PLAY_ON && taker0 != 0 && any_kick && !other_touch;
     if (any_kick) {
-      if (is_setplay(mode0)) gr.taker = last_kicker + 1;        // this kick puts the ball into play
+      if (is_setplay(mode0)) gr.taker = (last_kicker + 1) | (mode0 == S2D_GM_IND_FREE_KICK ? 0x100 : 0);   // this kick puts the ball into play
       else if (other_touch) gr.taker = 0;
       const int last_kick_cmd = cmask2 ? 31 - __clz(cmask2) : -1;
       gr.last_kicker = (last_kick_cmd == last_kicker) ? last_kick_cmd + 1 : 0;
@@ -655,7 +655,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
       coll_touch_side = side_of(touch_player);
       g.last_touch = coll_touch_side;
-      if (touch_player + 1 != gr.taker) gr.taker = 0;
+      if (touch_player + 1 != (gr.taker & 0xff)) gr.taker = 0;
       if (touch_player + 1 != gr.last_kicker) gr.last_kicker = 0;
     }
   }
@@ -795,12 +795,14 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
         place_ball = true; pbx = clampf(bx, -p.half_l, p.half_l); pby = clampf(by, -p.half_w, p.half_w);
         g.mode = S2D_GM_FREE_KICK_FAULT; g.mode_side = side_of(taker0 - 1); g.timer = 0; g.offside = 0;
         gr.taker = 0; gr.last_kicker = 0;
-      } else if (bx > p.half_l && fabsf(by) < p.goal_half_width) {
+      // (no goal directly from an indirect free kick: while nobody but its taker has touched the ball -- bit 8 of the taker word --, a ball
+      // in the net is a ball over the goal line: a goal kick, by the branch below)
+      } else if (!(gr.taker & 0x100) && bx > p.half_l && fabsf(by) < p.goal_half_width) {
         gr.score_l += 1; g.reward = 1.0f; if (is_ball) ev |= EV_GOAL_L;
         g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
         if (p.after_goal_wait > 0) { place_ball = true; pbx = bx; pby = by; g.mode = S2D_GM_AFTER_GOAL; g.mode_side = SIDE_LEFT; }
         else { restart_form = true; form_side = SIDE_RIGHT; g.mode = S2D_GM_KICK_OFF; g.mode_side = SIDE_RIGHT; }
-      } else if (bx < -p.half_l && fabsf(by) < p.goal_half_width) {
+      } else if (!(gr.taker & 0x100) && bx < -p.half_l && fabsf(by) < p.goal_half_width) {
         gr.score_r += 1; g.reward = -1.0f; if (is_ball) ev |= EV_GOAL_R;
         g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
         if (p.after_goal_wait > 0) { place_ball = true; pbx = bx; pby = by; g.mode = S2D_GM_AFTER_GOAL; g.mode_side = SIDE_RIGHT; }

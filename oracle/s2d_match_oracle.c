@@ -416,7 +416,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   /* 2. ball: accelerations summed in player order */
   REAL bax = R(0.0), bay = R(0.0);
   int any_kick = 0, last_kicker = -1, last_kick_cmd = -1, other_touch = 0;
-  const int taker0 = m->set_play_taker;                   /* who may not touch the ball twice in a row */
+  const int taker0 = m->set_play_taker & 0xff;            /* who may not touch the ball twice in a row (bit 8: his set play was an INDIRECT free kick) */
   for (int i = 0; i < NP; ++i) if (kicked[i]) {
     bax += kx[i]; bay += ky[i]; any_kick = 1; last_kicker = i;
     if (by_kick[i]) last_kick_cmd = i;
@@ -426,7 +426,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   /* free-kick fault (FreeKickFault_, idl/service.proto:287): the taker of a set play plays the ball again before anybody else */
   const int fk_fault = p->free_kick_faults && mode0 == S2D_GM_PLAY_ON && taker0 != 0 && any_kick && !other_touch;
   if (any_kick) {
-    if (is_setplay(mode0)) m->set_play_taker = last_kicker + 1;    /* this kick puts the ball into play */
+    if (is_setplay(mode0)) m->set_play_taker = (last_kicker + 1) | (mode0 == S2D_GM_IND_FREE_KICK ? 0x100 : 0);   /* this kick puts the ball into play */
     else if (other_touch) m->set_play_taker = 0;
     /* back-pass bookkeeping: the last Kick command counts; a tackle touch ends it */
     m->last_kicker = (last_kick_cmd == last_kicker) ? last_kick_cmd + 1 : 0;
@@ -484,7 +484,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
     coll_touch_side = side_of(touch_player);
     m->last_touch_side = coll_touch_side;
-    if (touch_player + 1 != m->set_play_taker) m->set_play_taker = 0;
+    if (touch_player + 1 != (m->set_play_taker & 0xff)) m->set_play_taker = 0;
     if (touch_player + 1 != m->last_kicker) m->last_kicker = 0;
   }
   /* 4. set play: the side that does not take it keeps free_kick_distance from the ball; during an announcement that is the
@@ -578,12 +578,14 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
         restart(m, S2D_GM_FOUL_CHARGE, side_of(foul_by), clampr(bx, -p->half_l, p->half_l), clampr(by, -p->half_w, p->half_w));
       } else if (fk_fault) {                                                 /* the taker touched the ball twice */
         restart(m, S2D_GM_FREE_KICK_FAULT, side_of(taker0 - 1), clampr(bx, -p->half_l, p->half_l), clampr(by, -p->half_w, p->half_w));
-      } else if (bx > p->half_l && R(fabs)(by) < p->goal_half_width) {       /* goal for the left team */
+      /* no goal directly from an indirect free kick (IndFreeKick_, idl/service.proto:289): while nobody but its taker has touched the
+       * ball, a ball in the net is a ball over the goal line -- a goal kick for the defenders, by the branch below */
+      } else if (!(m->set_play_taker & 0x100) && bx > p->half_l && R(fabs)(by) < p->goal_half_width) {       /* goal for the left team */
         m->score_left += 1; m->reward_left = R(1.0); st->v[1]++;
         if (p->after_goal_wait > 0) restart(m, S2D_GM_AFTER_GOAL, SIDE_LEFT, bx, by);   /* the ball rests in the net */
         else { place_formation(m, SIDE_RIGHT); restart(m, S2D_GM_KICK_OFF, SIDE_RIGHT, R(0.0), R(0.0)); }
         m->last_touch_side = SIDE_NONE;
-      } else if (bx < -p->half_l && R(fabs)(by) < p->goal_half_width) {      /* goal for the right team */
+      } else if (!(m->set_play_taker & 0x100) && bx < -p->half_l && R(fabs)(by) < p->goal_half_width) {      /* goal for the right team */
         m->score_right += 1; m->reward_left = R(-1.0); st->v[2]++;
         if (p->after_goal_wait > 0) restart(m, S2D_GM_AFTER_GOAL, SIDE_RIGHT, bx, by);
         else { place_formation(m, SIDE_LEFT); restart(m, S2D_GM_KICK_OFF, SIDE_LEFT, R(0.0), R(0.0)); }

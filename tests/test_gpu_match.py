@@ -586,6 +586,56 @@ def test_stock_kernel_parity_scripted_policies():
 
 
 @pytest.mark.parametrize('general', [False, True])
+def test_no_goal_directly_from_an_indirect_free_kick_on_device(general, monkeypatch):
+    """IndFreeKick_ (idl/service.proto:289; round 4): the taker's shot goes straight in -> no goal, a goal kick for the defenders; a direct
+    FreeKick_ from the same spot scores; an indirect one that a second player plays on its way scores.  Device == oracle after every
+    cycle, in both instantiations (the rule itself: parity unpinned, tests/test_match_oracle.py)."""
+    from soccer2d_amd._capi_match import GM_AFTER_GOAL, GM_FREE_KICK, GM_GOAL_KICK, GM_IND_FREE_KICK, MCMD_KICK
+    if general:
+        monkeypatch.setenv('S2D_MATCH_GENERAL_KERNEL', '1')
+    n = 8
+    eng, orc = _pair(n)
+
+    def both(a):
+        eng.step(torch.as_tensor(a, device='cuda:0')); orc.step(a)
+        assert_match_same(eng, orc, 'indirect free kick')
+
+    def acts(**pp):
+        a = np.zeros((n, 22, 3), dtype=np.float32)
+        for k, v in pp.items():
+            a[:, int(k[1:])] = v
+        return a
+
+    def put(slot, **kw):
+        for e in range(n):
+            orc.set_obj(e, slot, **kw)
+            eng.catch_ban[e, slot] = 0
+            for k, v in kw.items():
+                getattr(eng, k)[e, slot] = v
+
+    def set_play(mode, side):
+        for e in range(n):
+            orc.set_game(e, mode=mode, mode_side=side); eng.mode[e] = mode; eng.mode_side[e] = side
+    for mode, scores in ((GM_IND_FREE_KICK, False), (GM_FREE_KICK, True)):
+        for slot in range(22):                              # everybody else out of the way, deep in the own half
+            put(slot, x=-30.0 - slot, y=-20.0 + slot * 1.5, vx=0.0, vy=0.0)
+        put(9, x=45.5, y=0.2, body=0.0, vx=0.0, vy=0.0); put(22, x=46.0, y=0.2, vx=0.0, vy=0.0)
+        set_play(mode, 1)
+        score0 = orc.get('score_left').copy()
+        both(acts(p9=[MCMD_KICK, 100, 0]))
+        assert ((orc.get('set_play_taker') & 0xff) == 10).all() and (((orc.get('set_play_taker') & 0x100) != 0) == (mode == GM_IND_FREE_KICK)).all()
+        for _ in range(6):
+            if (orc.get('mode') != 2).all():
+                break
+            both(acts())
+        if scores:
+            assert (orc.get('mode') == GM_AFTER_GOAL).all() and (orc.get('score_left') == score0 + 1).all()
+        else:
+            assert (orc.get('mode') == GM_GOAL_KICK).all() and (orc.get('mode_side') == 2).all() and (orc.get('score_left') == score0).all()
+            assert (eng.mode.cpu().numpy() == GM_GOAL_KICK).all() and (eng.score_left.cpu().numpy() == score0).all()
+
+
+@pytest.mark.parametrize('general', [False, True])
 def test_long_rollout_with_fouls_and_catches(general, monkeypatch):
     """The in-kernel random policy never sets Tackle.foul and never catches, so the big random-policy runs do not reach the card /
     sending-off / parking, FoulCharge_ / PenaltyKick_, GoalieCatch_ / CatchFault_ paths nor the goalie's hand moves.  A seeded CALLER

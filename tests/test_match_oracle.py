@@ -433,7 +433,7 @@ def test_free_kick_fault_on_a_second_touch_by_the_taker():
     m.step(acts(p10=[MCMD_KICK, 50, 0]))                    # the offender's side cannot play it, the right team can
     assert m.get('mode')[0] == GM_IND_FREE_KICK
     m.step(acts(p15=[MCMD_KICK, 50, 0]))
-    assert m.get('mode')[0] == GM_PLAY_ON and m.get('set_play_taker')[0] == 16
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('set_play_taker')[0] == (16 | 0x100)      # taker #16 of an INDIRECT free kick
 
 
 def test_no_fault_after_another_touch_and_switch():
@@ -502,6 +502,43 @@ def _foul_scene(**kw):
     m.set_obj(0, 15, x=1.0, y=0.2, body=180.0)              # ... a right player stands 1 m in front of him with the ball at his feet
     m.set_obj(0, 22, x=0.7, y=0.1, vx=0.0, vy=0.0)
     return m
+
+
+def test_no_goal_directly_from_an_indirect_free_kick():
+    """IndFreeKick_ (idl/service.proto:289): the taker shoots straight into the goal -> no goal, a goal kick for the defenders (the ball
+    went over the goal line off an attacker); once another player has touched the ball, a goal counts.  A direct FreeKick_ scores.
+    (rcssserver's rule as we restate it: parity unpinned.)"""
+    from soccer2d_amd._capi_match import GM_AFTER_GOAL, GM_FREE_KICK, GM_GOAL_KICK, GM_IND_FREE_KICK, GM_PLAY_ON
+    for mode, scores in ((GM_IND_FREE_KICK, False), (GM_FREE_KICK, True)):
+        m = fresh(); play_on(m)
+        m.set_game(0, mode=mode, mode_side=LEFT)
+        m.set_obj(0, 9, x=45.5, y=0.2, body=0.0)             # left #10, seven metres in front of the right goal
+        m.set_obj(0, 22, x=46.0, y=0.2, vx=0.0, vy=0.0)
+        m.step(acts(p9=[MCMD_KICK, 100, 0]))
+        assert m.get('mode')[0] == GM_PLAY_ON and (m.get('set_play_taker')[0] & 0xff) == 10
+        assert bool(m.get('set_play_taker')[0] & 0x100) == (mode == GM_IND_FREE_KICK)
+        for _ in range(6):
+            if m.get('mode')[0] != GM_PLAY_ON:
+                break
+            m.step(acts())
+        if scores:
+            assert m.get('mode')[0] == GM_AFTER_GOAL and m.get('score_left')[0] == 1
+        else:
+            assert m.get('mode')[0] == GM_GOAL_KICK and m.get('mode_side')[0] == RIGHT and m.get('score_left')[0] == 0
+            assert m.get('set_play_taker')[0] == 0
+    # an indirect free kick that a team mate deflects in: the second touch clears the flag, the goal counts
+    m = fresh(use_offside=0); play_on(m)                    # (the team mate in front of the goal would be offside)
+    m.set_game(0, mode=GM_IND_FREE_KICK, mode_side=LEFT)
+    m.set_obj(0, 9, x=44.0, y=0.2, body=0.0)
+    m.set_obj(0, 22, x=44.5, y=0.2, vx=0.0, vy=0.0)
+    m.set_obj(0, 10, x=48.0, y=0.2, body=0.0)                # left #11 waits on the way
+    m.step(acts(p9=[MCMD_KICK, 40, 0]))
+    assert m.get('set_play_taker')[0] == (10 | 0x100)
+    for _ in range(12):
+        m.step(acts(p10=[MCMD_KICK, 100, 0]))
+        if m.get('mode')[0] != GM_PLAY_ON:
+            break
+    assert m.get('mode')[0] == GM_AFTER_GOAL and m.get('score_left')[0] == 1
 
 
 def test_intentional_foul_brings_the_victim_down_and_may_be_carded():
