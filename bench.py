@@ -17,8 +17,9 @@ dqn_stable_baselines3.py:18-31, uniform random policy drawn in-kernel, reset dis
 reach_ball_env.py:170-218), --envs 4096 = configs[1], --task match (8 192 matches) = configs[3],
 --gpus N --league-exchange = configs[4].  Every other size is named "custom".
 
-Protocol: settle phase, W untimed steps, graph capture, 3 untimed replays (the capture
-leaves the device idle; its clock ramps up again during them), then R = 5 timed regions of EXACTLY
+Protocol: settle phase, W untimed steps, graph capture, >= 3 and >= 100 ms of untimed replays
+(the first capture of a process leaves the device idle for ~25 ms and its clock takes ~25 ms of load to come
+back: profiles/r04/clock_trajectory.txt), then R = 5 timed regions of EXACTLY
 K steps each (one hipGraph replay per region, bracketed by barrier + synchronize on both sides, max
 over ranks); `value` is the MEDIAN region, the five figures are kept in `repeats`.  The default record
 is written into ROTATING buffers (> 512 MiB in flight, so no line of it can live in the 256 MiB
@@ -313,6 +314,7 @@ def graph_of(issue):
 
 
 WARM_REGIONS = 3
+WARM_MS = 100.0
 
 
 def timed_regions(run, repeats, stream, dist, dev, warm_regions=WARM_REGIONS):
@@ -323,9 +325,15 @@ def timed_regions(run, repeats, stream, dist, dev, warm_regions=WARM_REGIONS):
     first two were that ramp, not the kernel."""
     import torch
     wall, evs = [], []
-    for _ in range(max(0, warm_regions)):
-        run()
-    torch.cuda.synchronize()
+    if warm_regions > 0:
+        # ... and with short regions (the driver's --steps 20 = 3.3 ms) three of them are not enough: the ramp lasts ~25 ms
+        # (profiles/r04/clock_trajectory.txt: 88 78 88 92 95 100 100 101 then 104 +- 3 G for seconds, the same after every idle
+        # gap of >= 50 ms; the first graph capture of a process is such a gap, 24 ms).  So: at least WARM_MS of untimed replays.
+        t0, done = time.perf_counter(), 0
+        while done < warm_regions or (time.perf_counter() - t0) * 1e3 < WARM_MS:
+            run()
+            torch.cuda.synchronize()
+            done += 1
     for _ in range(repeats):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if dist is not None:
