@@ -481,13 +481,14 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_rollout_kernel(S2DHot p_sgpr
 #endif
 
 // experiment build (-DS2D_STAMPS): per role wave, the busy clocks (barrier release -> arrival at the next barrier), the clocks of its
-// whole loop and the 100 MHz real-time stamps of its begin and end, written by lane 0 into terminal_obs row wave_first + 2 * role
+// whole loop, the 100 MHz real-time stamps of its begin and end, and its HW_ID / XCC_ID words (where it ran), written by lane 0 into terminal_obs row wave_first + 2 * role
 #ifdef S2D_STAMPS
 #define WS_STAMP_DECL uint64_t st_busy = 0, st_t0 = __builtin_amdgcn_s_memtime(); const uint64_t st_begin = st_t0, st_rt0 = __builtin_amdgcn_s_memrealtime()
 #define WS_BARRIER() do { st_busy += __builtin_amdgcn_s_memtime() - st_t0; __syncthreads(); st_t0 = __builtin_amdgcn_s_memtime(); } while (0)
 #define WS_STAMP_STORE() do { if (lane == 0) { float* q_ = o.terminal_obs + (wave_first + 2 * role) * S2D_OBS_DIM; \
     q_[0] = (float)st_busy; q_[1] = (float)(__builtin_amdgcn_s_memtime() - st_begin); q_[2] = (float)(st_rt0 & 0xffffff); \
-    q_[3] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffff); } } while (0)
+    q_[3] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffff); \
+    q_[4] = __int_as_float((int)__builtin_amdgcn_s_getreg((31 << 11) | 4)); q_[5] = __int_as_float((int)__builtin_amdgcn_s_getreg((31 << 11) | 20)); } } while (0)
 #else
 #define WS_STAMP_DECL do {} while (0)
 #define WS_BARRIER() __syncthreads()
