@@ -68,6 +68,8 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
   int tackle_cycles, half_time_cycles, nr_normal_halfs, drop_ball_time, use_offside, catch_ban_cycle, goalie_max_moves;
   int after_goal_wait, kick_off_wait, back_passes, free_kick_faults;
   int stopped_clock, announce_wait, foul_cycles; float foul_detect_probability;
+  int nr_extra_halfs, extra_half_cycles, golden_goal;
+  int total_cycles, end_cycles;   // derived: end of the normal time, end of the last period (= total_cycles without extra halves)
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
 };
@@ -78,6 +80,9 @@ typedef float PTab[kHalf];   // one row of the per-slot table
 // are used) and once over MStock, where every use is an immediate -- no LDS reads or waits for them, dead branches (no dash-angle
 // quantisation off, no unlimited stamina capacity, ...) compiled out.  m_is_stock() compares an engine's derived MParams with
 // these bit for bit; anything else runs the general instantiation.  Per-engine words (seed, env ids, switches) stay variables.
+#ifndef S2D_STOCK_EXTRA_HALFS
+#define S2D_STOCK_EXTRA_HALFS 2   // rcssserver's nr_extra_halfs
+#endif
 struct MStock {
   static constexpr float half_l = (float)52.5, half_w = (float)34.0, ball_size = (float)0.085, player_rand = (float)0.1, ball_rand = (float)0.05;
   static constexpr float player_accel_max = (float)1.0, player_accel_max2 = player_accel_max * player_accel_max;
@@ -103,6 +108,8 @@ struct MStock {
   static constexpr int goalie_max_moves = 2, after_goal_wait = 50, kick_off_wait = 0, back_passes = 1, free_kick_faults = 1;
   static constexpr int stopped_clock = 1, announce_wait = 30, foul_cycles = 5;
   static constexpr float foul_detect_probability = (float)0.5;
+  static constexpr int nr_extra_halfs = S2D_STOCK_EXTRA_HALFS, extra_half_cycles = 1000, golden_goal = 0;
+  static constexpr int total_cycles = half_time_cycles * nr_normal_halfs, end_cycles = total_cycles + extra_half_cycles * nr_extra_halfs;
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
 };
@@ -115,9 +122,10 @@ struct MStock {
   X(goal_half_width) X(offside_area2) X(free_kick_distance) X(inv_speed_decay) X(catch_half_w) X(catch_probability) \
   X(max_catch_angle) X(min_catch_angle) X(pen_x) X(pen_half_w) X(foul_detect_probability)
 #define M_CONFIG_INTS(X) X(tackle_cycles) X(half_time_cycles) X(nr_normal_halfs) X(drop_ball_time) X(use_offside) X(catch_ban_cycle) \
-  X(goalie_max_moves) X(after_goal_wait) X(kick_off_wait) X(back_passes) X(free_kick_faults) X(stopped_clock) X(announce_wait) X(foul_cycles)
+  X(goalie_max_moves) X(after_goal_wait) X(kick_off_wait) X(back_passes) X(free_kick_faults) X(stopped_clock) X(announce_wait) X(foul_cycles) \
+  X(nr_extra_halfs) X(extra_half_cycles) X(golden_goal) X(total_cycles) X(end_cycles)
 // every configuration word of MParams is in one of the two lists (the remaining six are the per-engine words)
-static_assert(sizeof(MParams) == 4 * (53 + 14 + 6), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
+static_assert(sizeof(MParams) == 4 * (53 + 19 + 6), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
 
 // The per-slot table of an engine whose 22 players are all of the stock PlayerType (the default: s2d_match_default_config), with the
 // same spelling as the LDS table -- types[ROW][lane] -- but every entry an immediate: a cycle reads about ten of them per lane, each
@@ -168,6 +176,13 @@ S2D_DEV int cycles_to_half(int cycle, int h) {
   const int rem = cycle % h;                             // C remainder: negative for a clock that has wrapped
   return rem < 0 ? -rem : h - rem;
 }
+// ... and to the end of the period the clock is in: a normal half, or (from the end of the normal time on, when extra halves
+// exist) an extra half
+template <class P> S2D_DEV int cycles_to_period_end(const P& p, int cycle) {
+  const int total = p.total_cycles;
+  if (p.nr_extra_halfs > 0 && cycle >= total) return cycles_to_half(cycle - total, p.extra_half_cycles);
+  return cycles_to_half(cycle, p.half_time_cycles);
+}
 
 __constant__ float kFormX[11] = {-50.0f, -35.0f, -35.0f, -35.0f, -35.0f, -20.0f, -20.0f, -20.0f, -20.0f, -10.5f, -10.5f};
 __constant__ float kFormY[11] = {0.0f, -20.0f, -7.0f, 7.0f, 20.0f, -22.0f, -8.0f, 8.0f, 22.0f, -6.0f, 6.0f};
@@ -188,16 +203,18 @@ S2D_DEV bool is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D
 constexpr uint32_t kAnnounceModes = (1u << S2D_GM_OFF_SIDE) | (1u << S2D_GM_BACK_PASS) | (1u << S2D_GM_FREE_KICK_FAULT) |
                                     (1u << S2D_GM_CATCH_FAULT) | (1u << S2D_GM_FOUL_CHARGE);
 // modes in which nobody may play the ball
+constexpr uint32_t kPeriodEndModes = (1u << S2D_GM_FIRST_HALF_OVER) | (1u << S2D_GM_EXTEND_HALF);   // "half_time", "time_extended"
 constexpr uint32_t kDeadBallModes = kAnnounceModes | (1u << S2D_GM_AFTER_GOAL) | (1u << S2D_GM_BEFORE_KICK_OFF) |
-                                    (1u << S2D_GM_FIRST_HALF_OVER) | (1u << S2D_GM_GOALIE_CATCH);
+                                    kPeriodEndModes | (1u << S2D_GM_GOALIE_CATCH);
 // modes in which the clock stands still (with stopped_clock): WorldModel.cycle keeps its value, stoped_cycle counts
 constexpr uint32_t kClockStandsModes = kAnnounceModes | (1u << S2D_GM_BEFORE_KICK_OFF) | (1u << S2D_GM_AFTER_GOAL) |
-                                       (1u << S2D_GM_FIRST_HALF_OVER) | (1u << S2D_GM_TIME_OVER);
-static_assert(S2D_GM_GOALIE_CATCH < 32, "mode masks are 32 bits wide");
+                                       kPeriodEndModes | (1u << S2D_GM_TIME_OVER);
+static_assert(S2D_GM_EXTEND_HALF < 32, "mode masks are 32 bits wide");
 S2D_DEV bool in_modes(int mode, uint32_t mask) { return ((mask >> (mode & 31)) & 1u) != 0u; }
 S2D_DEV bool is_announcement(int mode) { return in_modes(mode, kAnnounceModes); }
 S2D_DEV bool ball_dead(int mode) { return in_modes(mode, kDeadBallModes); }
 S2D_DEV bool clock_stands(int mode) { return in_modes(mode, kClockStandsModes); }
+S2D_DEV bool is_period_end(int mode) { return in_modes(mode, kPeriodEndModes); }
 S2D_DEV float hbcast(float v, int src) { return __shfl(v, src, kHalf); }
 S2D_DEV int hbcasti(int v, int src) { return __shfl(v, src, kHalf); }
 // The same broadcast from a lane known at compile time (the ball's): two v_readlane and a select -- a few cycles -- where the
@@ -665,7 +682,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     const float bxn = bx, byn = by;
     // the side that does not take the set play keeps its distance; during an announcement that is the offending side (side0)
     const int kept_away = is_announcement(mode0) ? side0 : other_side(side0);
-    if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_FIRST_HALF_OVER && is_player &&
+    if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && !is_period_end(mode0) && is_player &&
         side_of(l) == kept_away && o.card < S2D_CARD_RED) {
       float dx = o.x - bxn, dy = o.y - byn, d = hypot2(dx, dy);
       if (d < p.free_kick_distance) {
@@ -689,9 +706,9 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   // nothing else is due -- and it waits for tens of cycles on end, so a wave holding such a match would take the referee's full
   // pass in every cycle of a launch and finish long after the others (the launch lasts as long as its slowest wave: 305 us against
   // 215 us for a batch in which nothing happens, profiles/r03/match_quiet_rate.txt, with 95 % of all wave-cycles quiet).
-  const int total_cycles = p.half_time_cycles * p.nr_normal_halfs;
+  const int total_cycles = p.total_cycles, end_cycles = p.end_cycles;      // end of the normal time, end of the last period
   const bool calm = !(any_kick || caught_by >= 0 || hold_move >= 0 || foul_call != 0) && g.offside == 0 &&
-                    !(advanced && (g.cycle >= total_cycles || g.to_half == 1));
+                    !(advanced && (g.cycle >= end_cycles || g.to_half == 1));
   bool idle = mode0 == S2D_GM_PLAY_ON && fabsf(bx) <= p.half_l && fabsf(by) <= p.half_w;   // play goes on, the ball is on the pitch
   if (!PLAY && mode0 != S2D_GM_PLAY_ON) {
     if (mode0 == S2D_GM_TIME_OVER) {
@@ -733,7 +750,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     } else if (mode0 == S2D_GM_BEFORE_KICK_OFF) {          // nobody plays the ball, players may Move
       g.timer += 1;
       if (g.timer >= p.kick_off_wait) { g.mode = S2D_GM_KICK_OFF; g.timer = 0; }
-    } else if (mode0 == S2D_GM_FIRST_HALF_OVER) {          // one cycle of "half time", then the next half's kick-off
+    } else if (is_period_end(mode0)) {                     // one cycle of "half time" / "time extended", then the next kick-off
       g.mode = p.kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF; g.timer = 0;
     } else if (mode0 == S2D_GM_GOALIE_CATCH) {             // one cycle of "goalie_catch_ball", then his free kick
       g.mode = S2D_GM_FREE_KICK; g.timer = 0;
@@ -836,18 +853,26 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
         }
       }
     }
-    if (advanced && g.cycle >= total_cycles) {           // half time / time over: only when the clock has just moved
+    // half time / extra time / time over (ServerParam.nr_extra_halfs, extra_half_time, golden_goal: idl/service.proto:1601, 1622, 1635):
+    // decided when the clock has just moved.  A draw at the end of the normal time is extended by nr_extra_halfs halves of
+    // extra_half_cycles, played in full unless golden_goal; the periods alternate the kick-off side.  (No penalty shoot-out.)
+    bool at_half = false;                                  // the clock has just reached the end of a period
+    if (advanced) { const int left = g.to_half - 1; at_half = left == 0; g.to_half = left; }
+    const bool extra = p.nr_extra_halfs > 0;
+    bool over = advanced && g.cycle >= end_cycles;
+    if (extra && advanced && g.cycle == total_cycles) over = gr.score_l != gr.score_r;      // a draw is extended
+    if (extra && p.golden_goal && g.cycle > total_cycles && g.reward != 0.0f) over = true;   // a goal (this cycle) in extra time
+    if (over) {
       g.mode = S2D_GM_TIME_OVER; g.mode_side = SIDE_NONE; g.done = 1; if (g.offside > 0) g.offside = 0; if (is_ball) ev |= EV_FINISHED;
-    }
-    bool at_half = false;                                  // the clock has just reached a multiple of half_time_cycles
-    if (advanced) { const int left = g.to_half - 1; at_half = left == 0; g.to_half = at_half ? p.half_time_cycles : left; }
-    if (g.mode == S2D_GM_TIME_OVER && g.done) {
     } else if (at_half) {
-      int k = g.cycle / p.half_time_cycles;
-      int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
+      const bool in_extra = extra && g.cycle >= total_cycles;
+      const int k = in_extra ? p.nr_normal_halfs + (g.cycle - total_cycles) / p.extra_half_cycles : g.cycle / p.half_time_cycles;
+      const int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
       recover_half = true; restart_form = true; form_side = ks; place_ball = false;
-      g.mode = S2D_GM_FIRST_HALF_OVER; g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+      g.mode = g.cycle == total_cycles ? S2D_GM_EXTEND_HALF : S2D_GM_FIRST_HALF_OVER;
+      g.mode_side = ks; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
     }
+    if (at_half) g.to_half = (extra && g.cycle >= total_cycles) ? p.extra_half_cycles : p.half_time_cycles;
     if (place_ball || restart_form) { gr.taker = 0; gr.last_kicker = 0; }   // every restart ends the double-touch / back-pass bookkeeping
     if (g.mode != S2D_GM_FREE_KICK && g.mode != S2D_GM_GOALIE_CATCH) { gr.holder = 0; gr.moves = 0; }   // nobody holds the ball any more
   }
@@ -953,7 +978,7 @@ S2D_DEV void m_load(const MPtrs& q, int64_t e, int l, MObj& o, MGame& g, MRare& 
   r.taker = q.env[ME_TAKER * q.env_stride + e]; r.last_kicker = q.env[ME_LAST_KICKER * q.env_stride + e];
   r.stopped = q.env[ME_STOPPED * q.env_stride + e]; g.tick = q.env[ME_TICK * q.env_stride + e];
 }
-template <class P> S2D_DEV void m_derive(const P& p, MGame& g) { g.to_half = cycles_to_half(g.cycle, p.half_time_cycles); }
+template <class P> S2D_DEV void m_derive(const P& p, MGame& g) { g.to_half = cycles_to_period_end(p, g.cycle); }
 S2D_DEV void m_store(const MPtrs& q, int64_t e, int l, const MObj& o, const MGame& g, const MRare& r) {
   if (l < SLOTS) {
     int64_t k = e * SLOTS + l;
@@ -1297,6 +1322,7 @@ S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
   m.goalie_max_moves = 2; m.after_goal_wait = 50;
   m.kick_off_wait = 0; m.back_passes = 1; m.free_kick_faults = 1;
   m.stopped_clock = 1; m.announce_wait = 30; m.foul_cycles = 5; m.foul_detect_probability = 0.5;
+  m.nr_extra_halfs = S2D_STOCK_EXTRA_HALFS; m.extra_half_cycles = 1000; m.golden_goal = 0;
   c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
   for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) c->player_types[t] = m_default_type(c->sp, m);   // homogeneous
 }
@@ -1317,6 +1343,8 @@ S2D_API int s2d_match_validate_config(const S2DMatchConfig* c) {
     return mfail(S2D_EINVAL, "catch_ban_cycle must be >= 0, catch_area_w and catchable_area_l > 0");
   if (c->mp.announce_wait < 0 || c->mp.foul_cycles < 0 || !(c->mp.foul_detect_probability >= 0 && c->mp.foul_detect_probability <= 1))
     return mfail(S2D_EINVAL, "announce_wait / foul_cycles must be >= 0, foul_detect_probability in [0, 1]");
+  if (c->mp.nr_extra_halfs < 0 || (c->mp.nr_extra_halfs > 0 && c->mp.extra_half_cycles < 1))
+    return mfail(S2D_EINVAL, "nr_extra_halfs must be >= 0 and extra_half_cycles >= 1 when extra halves are played");
   for (int i = 0; i < S2D_MATCH_PLAYERS; ++i)
     if (c->player_type_id[i] < 0 || c->player_type_id[i] >= S2D_MATCH_PLAYER_TYPES)
       return mfail(S2D_EINVAL, "player_type_id entries must be in [0, 18)");
@@ -1372,6 +1400,9 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   p.kick_off_wait = m.kick_off_wait; p.back_passes = m.back_passes; p.free_kick_faults = m.free_kick_faults;
   p.stopped_clock = m.stopped_clock; p.announce_wait = m.announce_wait; p.foul_cycles = m.foul_cycles;
   p.foul_detect_probability = (float)m.foul_detect_probability;
+  p.nr_extra_halfs = m.nr_extra_halfs; p.extra_half_cycles = m.extra_half_cycles; p.golden_goal = m.golden_goal != 0;
+  p.total_cycles = m.half_time_cycles * m.nr_normal_halfs;
+  p.end_cycles = p.total_cycles + (m.nr_extra_halfs > 0 ? m.extra_half_cycles * m.nr_extra_halfs : 0);
   p.auto_reset = c.auto_reset; p.noise = c.noise;
   p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32);
   p.gid_lo = (uint32_t)(uint64_t)c.env_id_offset; p.gid_hi = (uint32_t)((uint64_t)c.env_id_offset >> 32);

@@ -11,7 +11,7 @@ The product path has no CPU fallback: if the HIP library is missing or does not 
 import ctypes as C
 import os
 
-S2D_ABI_VERSION = 3
+S2D_ABI_VERSION = 4
 S2D_OBS_DIM = 10
 
 # error codes

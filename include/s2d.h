@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define S2D_ABI_VERSION 3
+#define S2D_ABI_VERSION 4
 
 /* ---- error codes (0 = ok, negative = failure; text via s2d_last_error()) ------------ */
 enum {

@@ -45,7 +45,7 @@ enum {
   S2D_GM_BEFORE_KICK_OFF = 0, S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4,
   S2D_GM_FREE_KICK = 5, S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_AFTER_GOAL = 8, S2D_GM_OFF_SIDE = 9,
   S2D_GM_PENALTY_KICK = 10, S2D_GM_FIRST_HALF_OVER = 11, S2D_GM_FOUL_CHARGE = 14, S2D_GM_BACK_PASS = 18, S2D_GM_FREE_KICK_FAULT = 19,
-  S2D_GM_CATCH_FAULT = 20, S2D_GM_IND_FREE_KICK = 21, S2D_GM_GOALIE_CATCH = 30
+  S2D_GM_CATCH_FAULT = 20, S2D_GM_IND_FREE_KICK = 21, S2D_GM_GOALIE_CATCH = 30, S2D_GM_EXTEND_HALF = 31
 };
 /* cards (rcssserver's yellow_card / red_card referee messages; no field of the proto's Player carries them) */
 enum { S2D_CARD_NONE = 0, S2D_CARD_YELLOW = 1, S2D_CARD_RED = 2 /* sent off: parked beside the pitch, commands ignored */ };
@@ -79,8 +79,14 @@ typedef struct S2DMatchParams {
   int32_t announce_wait;                  /* 30: cycles an announcement (OffSide_, BackPass_, FreeKickFault_, CatchFault_,
                                              FoulCharge_) lasts before the restart it awards (rcssserver's AFTER_*_WAIT) */
   int32_t foul_cycles;                    /* 5: cycles a fouled player stays down (ServerParam.foul_cycles, :1633) */
-  int32_t reserved_mp;
+  int32_t nr_extra_halfs;                 /* 2: extra halves played when the normal time ends in a draw (ServerParam.nr_extra_halfs,
+                                             idl/service.proto:1601): one stopped cycle of ExtendHalf (:299, rcssserver's
+                                             "time_extended"), then a kick-off; 0 = the match ends with the normal time */
   double foul_detect_probability;         /* .5: chance that the referee sees an intentional foul (:1632) */
+  int32_t extra_half_cycles;              /* 1000: length of an extra half (ServerParam.extra_half_time :1622, 100 s of 10 cycles);
+                                             FirstHalfOver between extra halves, TimeOver after the last one whatever the score --
+                                             the penalty shoot-out (penalty_shoot_outs :1602) is not built */
+  int32_t golden_goal;                    /* 0: a goal in extra time ends the match at once (ServerParam.golden_goal :1635) */
 } S2DMatchParams;
 
 /* PlayerType (idl/service.proto:1697-1732): the members that enter the dynamics.  Type 0 is the

@@ -41,6 +41,7 @@ typedef struct MP {
   int after_goal_wait;
   int kick_off_wait, back_passes, free_kick_faults;
   int stopped_clock, announce_wait, foul_cycles; REAL foul_detect_probability;
+  int nr_extra_halfs, extra_half_cycles, golden_goal;
   REAL catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
   /* heterogeneous players: the parameters of every player slot's PlayerType (idl/service.proto:1697-1732) */
@@ -96,6 +97,7 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   p->kick_off_wait = m->kick_off_wait; p->back_passes = m->back_passes; p->free_kick_faults = m->free_kick_faults;
   p->stopped_clock = m->stopped_clock; p->announce_wait = m->announce_wait; p->foul_cycles = m->foul_cycles;
   p->foul_detect_probability = (REAL)m->foul_detect_probability;
+  p->nr_extra_halfs = m->nr_extra_halfs; p->extra_half_cycles = m->extra_half_cycles; p->golden_goal = m->golden_goal;
   p->catch_half_w = (REAL)(m->catch_area_w * 0.5); p->catch_probability = (REAL)m->catch_probability;
   p->max_catch_angle = (REAL)m->max_catch_angle; p->min_catch_angle = (REAL)m->min_catch_angle;
   p->pen_x = (REAL)(s->pitch_half_length - m->penalty_area_length); p->pen_half_w = (REAL)m->penalty_area_half_width;
@@ -141,13 +143,14 @@ static int is_announcement(int mode) {
          mode == S2D_GM_FOUL_CHARGE;
 }
 /* modes in which nobody may play the ball */
+static int is_period_end(int mode) { return mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_EXTEND_HALF; }   /* "half_time", "time_extended" */
 static int ball_dead(int mode) {
-  return mode == S2D_GM_AFTER_GOAL || mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_GOALIE_CATCH ||
+  return mode == S2D_GM_AFTER_GOAL || mode == S2D_GM_BEFORE_KICK_OFF || is_period_end(mode) || mode == S2D_GM_GOALIE_CATCH ||
          is_announcement(mode);
 }
 /* modes in which the clock stands still (with stopped_clock): WorldModel.cycle keeps its value, stoped_cycle counts */
 static int clock_stands(int mode) {
-  return mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_AFTER_GOAL || mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_TIME_OVER ||
+  return mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_AFTER_GOAL || is_period_end(mode) || mode == S2D_GM_TIME_OVER ||
          is_announcement(mode);
 }
 /* where a sent-off player waits: beside the halfway line, outside the pitch, one spot per uniform number */
@@ -489,7 +492,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   }
   /* 4. set play: the side that does not take it keeps free_kick_distance from the ball; during an announcement that is the
    * offending side, the one the mode is named after (the restart will be the other side's) */
-  if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && mode0 != S2D_GM_FIRST_HALF_OVER) {
+  if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && !is_period_end(mode0)) {
     const int kept_away = is_announcement(mode0) ? side0 : other_side(side0);
     for (int i = 0; i < NP; ++i) if (side_of(i) == kept_away && m->o[i].card < S2D_CARD_RED) {
       Obj *o = &m->o[i];
@@ -517,7 +520,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     } else if (mode0 == S2D_GM_BEFORE_KICK_OFF) {        /* BeforeKickOff (idl/service.proto:268): nobody plays the ball, players may Move */
       m->setplay_timer += 1;
       if (m->setplay_timer >= p->kick_off_wait) { m->mode = S2D_GM_KICK_OFF; m->setplay_timer = 0; }
-    } else if (mode0 == S2D_GM_FIRST_HALF_OVER) {        /* one cycle of "half time" (idl/service.proto:279), then the next half's kick-off */
+    } else if (is_period_end(mode0)) {                   /* one cycle of "half time" / "time extended" (idl/service.proto:279, 299), then the next kick-off */
       m->mode = p->kick_off_wait > 0 ? S2D_GM_BEFORE_KICK_OFF : S2D_GM_KICK_OFF; m->setplay_timer = 0;
     } else if (mode0 == S2D_GM_GOALIE_CATCH) {           /* one cycle of "goalie_catch_ball" (:298), then his free kick */
       m->mode = S2D_GM_FREE_KICK; m->setplay_timer = 0;
@@ -612,16 +615,30 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
         }
       }
     }
-    /* half time / time over: only when the clock has just moved */
-    int total = p->half_time_cycles * p->nr_normal_halfs;
-    if (advanced && m->cycle >= total) {
+    /* half time / extra time / time over (rcssserver's TimeReferee; ServerParam.nr_extra_halfs, extra_half_time, golden_goal:
+     * idl/service.proto:1601, 1622, 1635): decided only when the clock has just moved.  Normal time = nr_normal_halfs halves; a
+     * draw at its end is extended by nr_extra_halfs halves of extra_half_cycles, played in full unless golden_goal; the periods
+     * alternate the kick-off side.  (penalty_shoot_outs, :1602, is not built: a draw after extra time stands.) */
+    const int total = p->half_time_cycles * p->nr_normal_halfs;
+    const int ext_total = total + p->extra_half_cycles * p->nr_extra_halfs;
+    const int tied = m->score_left == m->score_right;
+    int over = 0, period = -1;                           /* period = index of the period that starts now (kick-off side by parity) */
+    if (p->nr_extra_halfs <= 0) over = advanced && m->cycle >= total;
+    else if (advanced && m->cycle == total) over = !tied;
+    else if (advanced && m->cycle >= ext_total) over = 1;
+    if (p->golden_goal && p->nr_extra_halfs > 0 && m->cycle > total && m->reward_left != R(0.0)) over = 1;   /* a goal (this cycle) in extra time */
+    if (over) {
       m->mode = S2D_GM_TIME_OVER; m->mode_side = SIDE_NONE; m->done = 1; m->offside_mask = 0; st->v[3]++;
-    } else if (advanced && p->half_time_cycles > 0 && m->cycle % p->half_time_cycles == 0) {
-      int k = m->cycle / p->half_time_cycles;
-      int ks = (k & 1) ? SIDE_RIGHT : SIDE_LEFT;
+    } else if (advanced && m->cycle < total) {
+      if (p->half_time_cycles > 0 && m->cycle % p->half_time_cycles == 0) period = m->cycle / p->half_time_cycles;
+    } else if (advanced && p->nr_extra_halfs > 0) {
+      if ((m->cycle - total) % p->extra_half_cycles == 0) period = p->nr_normal_halfs + (m->cycle - total) / p->extra_half_cycles;
+    }
+    if (period >= 0) {
+      int ks = (period & 1) ? SIDE_RIGHT : SIDE_LEFT;
       recover_all(p, m, 0);
       place_formation(m, ks);
-      restart(m, S2D_GM_FIRST_HALF_OVER, ks, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
+      restart(m, m->cycle == total ? S2D_GM_EXTEND_HALF : S2D_GM_FIRST_HALF_OVER, ks, R(0.0), R(0.0)); m->last_touch_side = SIDE_NONE;
     }
     if (m->mode != S2D_GM_FREE_KICK && m->mode != S2D_GM_GOALIE_CATCH) { m->ball_holder = 0; m->goalie_moves = 0; }   /* nobody holds the ball any more */
   }

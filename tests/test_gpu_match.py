@@ -57,15 +57,15 @@ def test_match_reset_parity(n):
 
 
 @pytest.mark.parametrize('name,kw', [
-    ('default', dict(half_time_cycles=150)),
-    ('noise', dict(half_time_cycles=120, noise=True)),
-    ('no-offside-no-autoreset', dict(half_time_cycles=100, use_offside=0, auto_reset=False)),
-    ('short-drop', dict(half_time_cycles=200, drop_ball_time=3, tackle_cycles=2)),
-    ('before-kick-off', dict(half_time_cycles=110, kick_off_wait=7, drop_ball_time=20)),
-    ('no-fault-rules', dict(half_time_cycles=130, back_passes=0, free_kick_faults=0)),
+    ('default', dict(half_time_cycles=100, extra_half_cycles=20)),
+    ('noise', dict(half_time_cycles=120, noise=True, nr_extra_halfs=1, extra_half_cycles=30)),
+    ('no-offside-no-autoreset', dict(half_time_cycles=100, use_offside=0, auto_reset=False, extra_half_cycles=25)),
+    ('short-drop', dict(half_time_cycles=150, drop_ball_time=3, tackle_cycles=2, nr_extra_halfs=0)),
+    ('before-kick-off', dict(half_time_cycles=110, kick_off_wait=7, drop_ball_time=20, extra_half_cycles=15, golden_goal=1)),
+    ('no-fault-rules', dict(half_time_cycles=130, back_passes=0, free_kick_faults=0, nr_extra_halfs=0)),
 ])
 def test_match_step_parity_random_policy(name, kw):
-    """In-kernel Philox policy, per-step launches, 330 cycles (kick-offs, restarts, half time,
+    """In-kernel Philox policy, per-step launches, 330 cycles (kick-offs, restarts, half time, extra time after a draw,
     time over + auto-reset all occur): every word equal after every cycle."""
     n = 37
     eng, orc = _pair(n, **dict(kw))
@@ -76,7 +76,7 @@ def test_match_step_parity_random_policy(name, kw):
     assert_match_same(eng, orc, name)
     st = eng.stats.cpu().numpy()
     assert list(st) == list(orc.stats())
-    assert st[0] == 330 * n and st[4] > 0 and st[5] > 0
+    assert st[0] == 330 * n and st[4] > 0 and st[5] > 0 and st[3] > 0      # (st[3]: matches that reached TimeOver)
 
 
 def test_match_caller_actions_and_rollout():
@@ -167,8 +167,8 @@ def test_scripted_policy_beats_idle_and_random_in_league_round():
 
 def test_match_vec_env_surface():
     from soccer2d_amd.match import Soccer2DMatchVecEnv
-    env = Soccer2DMatchVecEnv(32, half_time_cycles=30)
-    orc = MO.MatchOracle(MO.make_match_config(half_time_cycles=30), 32)
+    env = Soccer2DMatchVecEnv(32, half_time_cycles=30, nr_extra_halfs=0)
+    orc = MO.MatchOracle(MO.make_match_config(half_time_cycles=30, nr_extra_halfs=0), 32)
     obs = env.reset()
     assert obs.shape == (32, 23, 5) and env.action_space.shape == (22, 3) and env.observation_space.shape == (23, 5)
     rs = np.random.RandomState(4)
@@ -537,9 +537,12 @@ def _stock_pair(n, **kw):
     cyc = np.zeros(n, dtype=np.int32)
     cyc[: n // 3] = 2960 + 2 * (np.arange(n // 3) % 15)                      # the first half ends within the test
     cyc[n // 3: 2 * (n // 3)] = 5950 + 2 * (np.arange(n // 3) % 20)          # ... and so does the match
-    eng.cycle.copy_(torch.as_tensor(cyc, device='cuda:0'))
+    lead = np.zeros(n, dtype=np.int32)
+    lead[n // 3: 2 * (n // 3): 2] = 1                                        # every other one of those is decided (TimeOver), the rest
+    eng.cycle.copy_(torch.as_tensor(cyc, device='cuda:0'))                   # are draws: ExtendHalf and a kick-off for extra time
+    eng.score_left.copy_(torch.as_tensor(lead, device='cuda:0'))
     for e in range(n):
-        orc.set_game(e, cycle=int(cyc[e]))
+        orc.set_game(e, cycle=int(cyc[e]), score_left=int(lead[e]))
     return eng, orc
 
 
@@ -557,8 +560,8 @@ def test_stock_kernel_parity_random_policy(noise):
         modes.update(int(m) for m in orc.get('mode'))
     assert_match_same(eng, orc, 'stock final')
     assert list(eng.stats.cpu().numpy()) == list(orc.stats())
-    from soccer2d_amd._capi_match import GM_FIRST_HALF_OVER
-    assert GM_FIRST_HALF_OVER in modes and int(orc.stats()[3]) >= n // 3      # half time was called, matches finished
+    from soccer2d_amd._capi_match import GM_EXTEND_HALF, GM_FIRST_HALF_OVER
+    assert GM_FIRST_HALF_OVER in modes and GM_EXTEND_HALF in modes and int(orc.stats()[3]) >= n // 6   # half time, extra time, matches finished
 
 
 def test_stock_kernel_parity_scripted_policies():
@@ -633,6 +636,44 @@ def test_no_goal_directly_from_an_indirect_free_kick_on_device(general, monkeypa
         else:
             assert (orc.get('mode') == GM_GOAL_KICK).all() and (orc.get('mode_side') == 2).all() and (orc.get('score_left') == score0).all()
             assert (eng.mode.cpu().numpy() == GM_GOAL_KICK).all() and (eng.score_left.cpu().numpy() == score0).all()
+
+
+@pytest.mark.parametrize('golden', [0, 1])
+def test_extra_time_on_device(golden):
+    """ExtendHalf (idl/service.proto:299) and the extra halves (ServerParam.nr_extra_halfs / extra_half_time / golden_goal): the scenario
+    of tests/test_match_oracle.py::test_extra_time_after_a_draw on the device, every word equal to the oracle's after every cycle --
+    draws are extended, decided matches end with the normal time, a goal in extra time ends the match only with golden_goal.  (The stock
+    instantiation meets ExtendHalf in test_stock_kernel_parity_random_policy.)  Rules restated: parity unpinned."""
+    from soccer2d_amd._capi_match import GM_AFTER_GOAL, GM_EXTEND_HALF, GM_FIRST_HALF_OVER, GM_TIME_OVER
+    n = 6
+    eng, orc = _pair(n, half_time_cycles=10, extra_half_cycles=6, auto_reset=0, after_goal_wait=2, golden_goal=golden)
+    lead = np.array([0, 0, 0, 1, 0, 2], dtype=np.int32)                # matches 3 and 5 are decided before the end of the normal time
+    eng.score_left.copy_(torch.as_tensor(lead, device='cuda:0'))
+    for e in range(n):
+        orc.set_game(e, score_left=int(lead[e]))
+    a = np.zeros((n, 22, 3), dtype=np.float32)
+    seen = [set() for _ in range(n)]
+
+    def both(k):
+        for _ in range(k):
+            eng.step(torch.as_tensor(a, device='cuda:0')); orc.step(a)
+            assert_match_same(eng, orc, 'extra time')
+            for e in range(n):
+                seen[e].add((int(orc.get('cycle')[e]), int(orc.get('mode')[e])))
+    both(23)                                                           # 10 + FirstHalfOver + 10 + ExtendHalf + the kick-off cycle
+    assert all((20, GM_EXTEND_HALF) in seen[e] and orc.get('cycle')[e] == 21 for e in (0, 1, 2, 4))
+    assert all((20, GM_TIME_OVER) in seen[e] and orc.get('done')[e] == 0 and orc.get('mode')[e] == GM_TIME_OVER for e in (3, 5))
+    for e in (1, 2):                                                   # a goal in extra time: the ball rolls over the right goal line
+        orc.set_game(e, mode=2); eng.mode[e] = 2
+        orc.set_obj(e, 22, x=52.0, y=0.0, vx=2.0, vy=0.0)
+        for f, v in (('x', 52.0), ('y', 0.0), ('vx', 2.0), ('vy', 0.0)):
+            getattr(eng, f)[e, 22] = v
+    both(1)
+    assert (orc.get('score_left')[[1, 2]] == 1).all() and (orc.get('mode')[[1, 2]] == (GM_TIME_OVER if golden else GM_AFTER_GOAL)).all()
+    both(16)
+    assert (orc.get('mode') == GM_TIME_OVER).all() and (eng.mode.cpu().numpy() == GM_TIME_OVER).all()
+    assert all((26, GM_FIRST_HALF_OVER) in seen[e] and (32, GM_TIME_OVER) in seen[e] for e in (0, 4))
+    assert all(((32, GM_TIME_OVER) in seen[e]) == (not golden) for e in (1, 2))
 
 
 @pytest.mark.parametrize('general', [False, True])

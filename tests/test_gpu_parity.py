@@ -334,10 +334,11 @@ def test_full_size_parity_and_properties(ws, monkeypatch):
     assert float(obs[..., 0].abs().max()) <= 1.0 and float(obs[..., 7].abs().max()) <= 0.5
 
 
-@pytest.mark.parametrize('name', ['noise-on', 'continuous1', 'reference-default'])
+@pytest.mark.parametrize('name', ['noise-on', 'continuous1', 'turning4', 'reference-default'])
 def test_full_size_parity_other_configurations(name):
     """BASELINE.json configs[2] size (65 536 envs x 256 cycles = bench.py's launch) for what the headline configuration does not
-    cover: noise on (the drop-in default of make_config), 1-D continuous actions (the DDPG script's), and the reference's own default
+    cover: noise on (the drop-in default of make_config), 1-D continuous actions (the DDPG script's), the 4-D turning mode
+    (reach_ball_env.py:59-79; bench.py's `turning4` line), and the reference's own default
     kwargs (use_continuous_action=True, change_ball_velocity=False: reach_ball_env.py:26-36) -- full bit-exact comparison through
     the kernel s2d_rollout picks by default."""
     kw = dict(use_continuous_action=True, use_turning=False) if name == 'reference-default' else dict(CONFIGS[name])

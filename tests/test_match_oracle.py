@@ -211,7 +211,7 @@ def test_offside_is_called():
 
 
 def test_half_time_and_time_over():
-    m = fresh(half_time_cycles=20, auto_reset=0)
+    m = fresh(half_time_cycles=20, auto_reset=0, nr_extra_halfs=0)     # (extra time: test_extra_time_after_a_draw)
     play_on(m)
     for _ in range(19):
         m.step(acts(p3=[MCMD_DASH, 100, 0]))
@@ -229,7 +229,7 @@ def test_half_time_and_time_over():
     m.step(acts(p3=[MCMD_DASH, 100, 0]))
     assert m.get('done')[0] == 0 and m.get('vx')[0][3] == 0            # time over: commands ignored
     assert m.get('cycle')[0] == 40 and m.get('stopped_cycle')[0] == 1  # ... and the clock stands
-    m = fresh(half_time_cycles=5, auto_reset=1)
+    m = fresh(half_time_cycles=5, auto_reset=1, nr_extra_halfs=0)
     for _ in range(11):                                                 # 5 + FirstHalfOver + 5
         m.step(acts())
     assert m.get('done')[0] == 1 and m.get('cycle')[0] == 0 and m.get('mode')[0] == GM_KICK_OFF and m.stats()[3] == 1
@@ -241,9 +241,52 @@ def test_half_time_and_time_over():
     assert m.get('cycle')[0] == 22 and m.get('stopped_cycle')[0] == 0 and m.get('mode')[0] == GM_KICK_OFF
 
 
+def test_extra_time_after_a_draw():
+    """ServerParam.nr_extra_halfs / extra_half_time / golden_goal (idl/service.proto:1601, 1622, 1635) and GameModeType.ExtendHalf
+    (:299; rcssserver's "time_extended"): a draw after the normal time is extended by nr_extra_halfs halves -- one stopped cycle
+    of ExtendHalf, a kick-off for the side that started the match, FirstHalfOver between the extra halves, TimeOver after the last
+    one whatever the score (no shoot-out); a decided match ends with the normal time.  Rules restated: parity unpinned."""
+    from soccer2d_amd._capi_match import GM_EXTEND_HALF, GM_FIRST_HALF_OVER, GM_AFTER_GOAL
+    m = fresh(half_time_cycles=10, extra_half_cycles=6, auto_reset=0)  # stock nr_extra_halfs = 2
+    seen = []
+    for _ in range(60):
+        m.step(acts())
+        seen.append((int(m.get('cycle')[0]), int(m.get('mode')[0]), int(m.get('mode_side')[0])))
+        if m.get('done')[0]:
+            break
+    ends = [(c, md, sd) for c, md, sd in seen if md in (GM_FIRST_HALF_OVER, GM_EXTEND_HALF, GM_TIME_OVER)]
+    assert ends == [(10, GM_FIRST_HALF_OVER, RIGHT), (20, GM_EXTEND_HALF, LEFT), (26, GM_FIRST_HALF_OVER, RIGHT), (32, GM_TIME_OVER, 0)]
+    assert seen[seen.index((20, GM_EXTEND_HALF, LEFT)) + 1] == (20, GM_KICK_OFF, LEFT)        # one stopped cycle, then the kick-off
+    # a decided match ends with the normal time
+    m = fresh(half_time_cycles=10, extra_half_cycles=6, auto_reset=0); m.set_game(0, score_left=1)
+    for _ in range(21):                                                  # 10 + FirstHalfOver + 10
+        m.step(acts())
+    assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1 and m.get('cycle')[0] == 20
+    # extra halves are played in full: a goal in extra time does not end the match ...
+    def goal_in_extra_time(**kw):
+        m = fresh(half_time_cycles=10, extra_half_cycles=6, auto_reset=0, after_goal_wait=2, **kw)
+        for _ in range(23):                                              # ... 20, ExtendHalf, kick-off cycle -> cycle 21
+            m.step(acts())
+        assert m.get('cycle')[0] == 21 and m.get('mode')[0] in (GM_KICK_OFF, GM_PLAY_ON)
+        play_on(m)
+        m.set_obj(0, 22, x=52.0, y=0.0, vx=2.0, vy=0.0)                  # the ball rolls over the right goal line
+        m.step(acts())
+        return m
+    m = goal_in_extra_time()
+    assert m.get('score_left')[0] == 1 and m.get('mode')[0] == GM_AFTER_GOAL and m.get('done')[0] == 0
+    for _ in range(40):
+        m.step(acts())
+        if m.get('done')[0]:
+            break
+    assert m.get('mode')[0] == GM_TIME_OVER and m.get('cycle')[0] == 32
+    # ... unless golden_goal
+    m = goal_in_extra_time(golden_goal=1)
+    assert m.get('score_left')[0] == 1 and m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1 and m.get('cycle')[0] == 22
+
+
 def test_random_matches_are_deterministic_and_eventful():
     n = 64
-    a, b = fresh(n, half_time_cycles=400), fresh(n, half_time_cycles=400)
+    a, b = fresh(n, half_time_cycles=400, extra_half_cycles=50), fresh(n, half_time_cycles=400, extra_half_cycles=50)
     for _ in range(1300):                                  # 800 cycles of play + the stopped ones (after goals, offside calls, half time)
         a.step(None); b.step(None)
     for f in MO.OBJ_FIELDS + MO.ENV_FIELDS:
