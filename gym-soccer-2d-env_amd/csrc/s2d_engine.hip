@@ -234,15 +234,11 @@ __global__ __launch_bounds__(kBlock) void s2d_reach_step_k_kernel(S2DHot p, cons
   bool slot_used = false;
   unsigned int c1 = 0, c2 = 0, c3 = 0;                     // wave-uniform episode counters
   int64_t row = 0;
-  float4 raw_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the caller's action of the next cycle, in flight while this one is computed
-  if (active && n_steps > 0) raw_next = load_raw_action<MODE>(actions, kind, i);
   for (int t = 0; t < n_steps; ++t, row += n) {
     res = 0;
     if (active) {
       const uint32_t k = k0 + (uint32_t)t;
-      const float4 raw = raw_next;
-      if (t + 1 < n_steps) raw_next = load_raw_action<MODE>(actions, kind, row + n + i);
-      const CmdPrep c = decide_loaded<MODE>(p, raw, kind, row + i, gl, gh, k, t == 0 || (k & 3u) == 0u, quad, squad, ro.action, cmd, dir);
+      const CmdPrep c = decide<MODE>(p, actions, kind, row + i, gl, gh, k, t == 0 || (k & 3u) == 0u, quad, squad, ro.action, cmd, dir);
       e.step_number += 1;                                  // reach_ball_env.py:55
       NoiseIn nz{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       if (NOISE) nz = noise_prepare(p, gl, gh, k, S2D_ST_NOISE, cmd == S2D_CMD_TURN);

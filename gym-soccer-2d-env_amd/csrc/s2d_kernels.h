@@ -180,25 +180,17 @@ S2D_DEV void store_rollout_action(void* __restrict__ dst, int64_t idx, const Act
 // action of one env for the step at policy step k -> decoded command (A2, reach_ball_env.py:53-85)
 // with the command-only part of the dash already evaluated.  `quad` / `squad` cache the POLICY /
 // SELECT blocks across the four steps they serve.
-// the words a caller supplied for env-step idx, as they lie in memory (nothing for the in-engine policy): the load half of decide(),
-// so that a kernel that runs several cycles can fetch the next cycle's action while it computes this one
 template <int MODE>
-S2D_DEV float4 load_raw_action(const void* __restrict__ actions, int kind, int64_t idx) {
-  if (kind == S2D_ACT_COMMAND) return static_cast<const float4*>(actions)[idx];
-  if (kind == S2D_ACT_RANDOM) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  const Action4 a = load_action<MODE>(actions, kind, idx);
-  return make_float4(a.a0, a.a1, a.a2, a.a3);
-}
-template <int MODE>
-S2D_DEV CmdPrep decide_loaded(const S2DHot& p, const float4& raw, int kind, int64_t idx, uint32_t gid_lo,
-                              uint32_t gid_hi, uint32_t k, bool refresh, U4& quad, U4& squad, void* __restrict__ action_out,
-                              int& cmd, float& dir) {
+S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int kind, int64_t idx, uint32_t gid_lo,
+                       uint32_t gid_hi, uint32_t k, bool refresh, U4& quad, U4& squad, void* __restrict__ action_out,
+                       int& cmd, float& dir) {
   if (kind == S2D_ACT_COMMAND) {                           // a decoded body command, executed as it is (wave-uniform branch)
-    cmd = command_code(raw.x); dir = raw.z;
-    return cmd_prepare(p, cmd, raw.y, raw.z);
+    const float4 v = static_cast<const float4*>(actions)[idx];
+    cmd = command_code(v.x); dir = v.z;
+    return cmd_prepare(p, cmd, v.y, v.z);
   }
   Action4 a = (kind == S2D_ACT_RANDOM) ? random_action<MODE>(p, gid_lo, gid_hi, k, quad, refresh)
-                                       : Action4{raw.x, raw.y, raw.z, raw.w};
+                                       : load_action<MODE>(actions, kind, idx);
   if (action_out) store_rollout_action<MODE>(action_out, idx, a);
   float u = 0.0f;
   if (MODE == S2D_MODE_TURN4) {                          // reach_ball_env.py:71
@@ -208,13 +200,6 @@ S2D_DEV CmdPrep decide_loaded(const S2DHot& p, const float4& raw, int kind, int6
   float power;
   action_map<MODE>(p, a, u, cmd, power, dir);
   return cmd_prepare(p, cmd, power, dir);
-}
-template <int MODE>
-S2D_DEV CmdPrep decide(const S2DHot& p, const void* __restrict__ actions, int kind, int64_t idx, uint32_t gid_lo,
-                       uint32_t gid_hi, uint32_t k, bool refresh, U4& quad, U4& squad, void* __restrict__ action_out,
-                       int& cmd, float& dir) {
-  return decide_loaded<MODE>(p, load_raw_action<MODE>(actions, kind, idx), kind, idx, gid_lo, gid_hi, k, refresh, quad, squad,
-                             action_out, cmd, dir);
 }
 
 // action -> decoded command with the command-only half of the dash (decide() without the load and the store: for callers that
