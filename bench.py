@@ -458,6 +458,29 @@ def measure_steps(eng, launches, repeats, stream, settle_ms, actions=None):
             'roofline': roofline_of(alg, ls, le, eng.kernel_name(), 'step', 64, n, 1)}
 
 
+def measure_steps_with_policy(eng, launches, repeats, stream, settle_ms):
+    """BASELINE configs[2] read literally -- "obs as PyTorch-ROCm tensors into dqn_stable_baselines3": every step a Q-network of
+    SB3's DQN MlpPolicy shape (10-64-64-16, ReLU; random weights, fp32, plain torch ops) reads the engine's observation tensor,
+    its greedy action (int64 [N]) goes back into s2d_step; one hipGraph of `launches` such steps per region.  The network is torch's,
+    not this repo's: the figure says what the per-step API costs NEXT TO a learner's forward pass."""
+    import torch
+    n = eng.num_envs
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(10, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                              torch.nn.Linear(64, DQN_KWARGS['action_space_size'])).to(eng.device)
+
+    def one():
+        with torch.no_grad():
+            eng.step(net(eng.obs).argmax(dim=1))
+    settle(lambda c: [one() for _ in range(c)], 256, settle_ms)
+    g = graph_of(lambda: [one() for _ in range(launches)])
+    wall, evs = timed_regions(g.replay, repeats, stream, None, None)
+    per = median_of(wall) / launches
+    return {'value': n / per, 'unit': 'env-steps/s', 'us_per_step': per * 1e6, 'launches_per_region': launches,
+            'repeats': [n * launches / w for w in wall],
+            'policy': 'greedy Q-network 10-64-64-16 (SB3 DQN MlpPolicy shape), torch fp32 ops in the same hipGraph'}
+
+
 def measure_step_k(eng, k, launches, repeats, stream, settle_ms):
     """s2d_step_k: k cycles of the per-step API per launch, caller actions [k][N] (int32, resident), record written into one [k][N]
     buffer set.  Returns us per launch and per cycle."""
@@ -802,6 +825,7 @@ def secondary_measurements(args, dev, stream, rank, n, T, line, out):
     acts = torch.randint(0, DQN_KWARGS['action_space_size'], (n,), device=dev, dtype=torch.int32)
     out['step_api_caller_actions'] = measure_steps(eng, 2048, R, stream, args.settle_ms, actions=acts)
     out['step_api_caller_actions']['actions'] = 'int32[N] device tensor (what dqn_stable_baselines3.py hands to step())'
+    out['step_api_dqn_policy'] = measure_steps_with_policy(eng, 256, R, stream, args.settle_ms)
     # s2d_step_k: the per-step API with k cycles per launch (a learner that holds its actions for k steps)
     out['step_k'] = [measure_step_k(eng, k, 2048 // k, R, stream, args.settle_ms) for k in (1, 2, 4, 8)]
     del eng
