@@ -497,11 +497,12 @@ def measure_step_k(eng, k, launches, repeats, stream, settle_ms):
             'record': 'obs, action, reward, done, result of every cycle ([k][N]); caller actions int32 [k][N]'}
 
 
-def measure_match(n, dev, rank, T, launches, repeats, stream, settle_ms, noise=False, phase='spread', mode='rollout', dist=None):
+def measure_match(n, dev, rank, T, launches, repeats, stream, settle_ms, noise=False, phase='spread', mode='rollout', dist=None, match_kw=None):
     """11v11 engine: `launches` rollout launches of T cycles (or single-cycle launches in step mode) per region."""
     import torch
     from soccer2d_amd.match import MatchEngine, make_match_config
-    extra = json.loads(os.environ.get('S2D_MATCH_KW', '{}'))            # experiments: match parameter overrides
+    extra = dict(match_kw or {})
+    extra.update(json.loads(os.environ.get('S2D_MATCH_KW', '{}')))      # experiments: match parameter overrides
     eng = MatchEngine(n, dev, cfg=make_match_config(env_id_offset=rank * n, noise=noise, **extra))
     eng.reset()
     if phase == 'spread':
@@ -840,7 +841,14 @@ def secondary_measurements(args, dev, stream, rank, n, T, line, out):
     mm = measure_match(8192, dev, rank, 64, 16, R, stream, args.settle_ms, phase='spread')
     mm.pop('wall', None)
     mm['workload'] = workload_of('match', 8192, 1, False)[1]
+    mm['rules'] = ('rcssserver stock: 2 x 3 000 cycles, a draw is extended by 2 x 1 000 and then goes to the penalty shoot-out -- under the '
+                   'uniform random policy nearly every match is a 0-0 draw and a fifth of all match-cycles are shoot-out cycles')
     out['match_8192'] = mm
+    # the same without the shoot-out (a per-engine word of the stock instantiation): what rounds 1-4 measured before the shoot-out existed
+    m2 = measure_match(8192, dev, rank, 64, 16, R, stream, args.settle_ms, phase='spread', match_kw={'penalty_shoot_outs': 0})
+    m2.pop('wall', None)
+    m2['rules'] = 'penalty_shoot_outs = 0: a draw after extra time stands (TimeOver at cycle 8 000)'
+    out['match_8192_no_shoot_out'] = m2
 
 
 def run_match(args, dev, dist, rank, world):

@@ -69,6 +69,7 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
   int after_goal_wait, kick_off_wait, back_passes, free_kick_faults;
   int stopped_clock, announce_wait, foul_cycles; float foul_detect_probability;
   int nr_extra_halfs, extra_half_cycles, golden_goal;
+  int penalty_shoot_outs, pen_before_setup_wait, pen_ready_wait, pen_taken_wait, pen_nr_kicks, pen_max_extra_kicks; float pen_spot_x;
   int total_cycles, end_cycles;   // derived: end of the normal time, end of the last period (= total_cycles without extra halves)
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
@@ -80,6 +81,9 @@ typedef float PTab[kHalf];   // one row of the per-slot table
 // are used) and once over MStock, where every use is an immediate -- no LDS reads or waits for them, dead branches (no dash-angle
 // quantisation off, no unlimited stamina capacity, ...) compiled out.  m_is_stock() compares an engine's derived MParams with
 // these bit for bit; anything else runs the general instantiation.  Per-engine words (seed, env ids, switches) stay variables.
+#ifndef S2D_STOCK_SHOOT_OUTS
+#define S2D_STOCK_SHOOT_OUTS 1   // rcssserver's penalty_shoot_outs (experiment builds: 0)
+#endif
 #ifndef S2D_STOCK_EXTRA_HALFS
 #define S2D_STOCK_EXTRA_HALFS 2   // rcssserver's nr_extra_halfs
 #endif
@@ -109,8 +113,11 @@ struct MStock {
   static constexpr int stopped_clock = 1, announce_wait = 30, foul_cycles = 5;
   static constexpr float foul_detect_probability = (float)0.5;
   static constexpr int nr_extra_halfs = S2D_STOCK_EXTRA_HALFS, extra_half_cycles = 1000, golden_goal = 0;
+  static constexpr int pen_before_setup_wait = 10, pen_ready_wait = 10, pen_taken_wait = 150, pen_nr_kicks = 5, pen_max_extra_kicks = 5;
+  static constexpr float pen_spot_x = (float)(52.5 - 42.5);
   static constexpr int total_cycles = half_time_cycles * nr_normal_halfs, end_cycles = total_cycles + extra_half_cycles * nr_extra_halfs;
   int auto_reset, noise;
+  int penalty_shoot_outs;   // per engine like the two above: an engine that differs from the stock rules only in this word keeps this kernel
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
 };
 #define M_CONFIG_FLOATS(X) X(half_l) X(half_w) X(ball_size) X(player_rand) X(ball_rand) X(player_accel_max) X(player_accel_max2) \
@@ -120,12 +127,13 @@ struct MStock {
   X(back_dash_rate) X(max_moment) X(min_moment) X(collision_vel_rate) X(max_power) X(min_power) X(inv_max_power) X(tackle_dist) \
   X(tackle_back_dist) X(tackle_width) X(tackle_power_rate) X(max_tackle_power) X(max_back_tackle_power) X(tackle_reach2) \
   X(goal_half_width) X(offside_area2) X(free_kick_distance) X(inv_speed_decay) X(catch_half_w) X(catch_probability) \
-  X(max_catch_angle) X(min_catch_angle) X(pen_x) X(pen_half_w) X(foul_detect_probability)
+  X(max_catch_angle) X(min_catch_angle) X(pen_x) X(pen_half_w) X(foul_detect_probability) X(pen_spot_x)
 #define M_CONFIG_INTS(X) X(tackle_cycles) X(half_time_cycles) X(nr_normal_halfs) X(drop_ball_time) X(use_offside) X(catch_ban_cycle) \
   X(goalie_max_moves) X(after_goal_wait) X(kick_off_wait) X(back_passes) X(free_kick_faults) X(stopped_clock) X(announce_wait) X(foul_cycles) \
-  X(nr_extra_halfs) X(extra_half_cycles) X(golden_goal) X(total_cycles) X(end_cycles)
-// every configuration word of MParams is in one of the two lists (the remaining six are the per-engine words)
-static_assert(sizeof(MParams) == 4 * (53 + 19 + 6), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
+  X(nr_extra_halfs) X(extra_half_cycles) X(golden_goal) X(total_cycles) X(end_cycles) X(pen_before_setup_wait) \
+  X(pen_ready_wait) X(pen_taken_wait) X(pen_nr_kicks) X(pen_max_extra_kicks)
+// every configuration word of MParams is in one of the two lists (the remaining seven are the per-engine words)
+static_assert(sizeof(MParams) == 4 * (54 + 24 + 7), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
 
 // The per-slot table of an engine whose 22 players are all of the stock PlayerType (the default: s2d_match_default_config), with the
 // same spelling as the LDS table -- types[ROW][lane] -- but every entry an immediate: a cycle reads about ten of them per lane, each
@@ -204,17 +212,43 @@ constexpr uint32_t kAnnounceModes = (1u << S2D_GM_OFF_SIDE) | (1u << S2D_GM_BACK
                                     (1u << S2D_GM_CATCH_FAULT) | (1u << S2D_GM_FOUL_CHARGE);
 // modes in which nobody may play the ball
 constexpr uint32_t kPeriodEndModes = (1u << S2D_GM_FIRST_HALF_OVER) | (1u << S2D_GM_EXTEND_HALF);   // "half_time", "time_extended"
+// the shoot-out's modes (idl/service.proto:290-297)
+constexpr uint32_t kPenaltyModes = (1u << S2D_GM_PENALTY_SETUP) | (1u << S2D_GM_PENALTY_READY) | (1u << S2D_GM_PENALTY_TAKEN) |
+                                   (1u << S2D_GM_PENALTY_MISS) | (1u << S2D_GM_PENALTY_SCORE) | (1u << S2D_GM_PENALTY_ONFIELD);
 constexpr uint32_t kDeadBallModes = kAnnounceModes | (1u << S2D_GM_AFTER_GOAL) | (1u << S2D_GM_BEFORE_KICK_OFF) |
-                                    kPeriodEndModes | (1u << S2D_GM_GOALIE_CATCH);
+                                    kPeriodEndModes | (1u << S2D_GM_GOALIE_CATCH) |
+                                    (kPenaltyModes & ~((1u << S2D_GM_PENALTY_READY) | (1u << S2D_GM_PENALTY_TAKEN)));
 // modes in which the clock stands still (with stopped_clock): WorldModel.cycle keeps its value, stoped_cycle counts
 constexpr uint32_t kClockStandsModes = kAnnounceModes | (1u << S2D_GM_BEFORE_KICK_OFF) | (1u << S2D_GM_AFTER_GOAL) |
-                                       kPeriodEndModes | (1u << S2D_GM_TIME_OVER);
+                                       kPeriodEndModes | (1u << S2D_GM_TIME_OVER) | kPenaltyModes;
 static_assert(S2D_GM_EXTEND_HALF < 32, "mode masks are 32 bits wide");
 S2D_DEV bool in_modes(int mode, uint32_t mask) { return ((mask >> (mode & 31)) & 1u) != 0u; }
 S2D_DEV bool is_announcement(int mode) { return in_modes(mode, kAnnounceModes); }
 S2D_DEV bool ball_dead(int mode) { return in_modes(mode, kDeadBallModes); }
 S2D_DEV bool clock_stands(int mode) { return in_modes(mode, kClockStandsModes); }
 S2D_DEV bool is_period_end(int mode) { return in_modes(mode, kPeriodEndModes); }
+#ifdef S2D_NO_SHOOTOUT   // experiment builds: the cycle without the shoot-out's code (the mode is never entered)
+S2D_DEV bool is_penalty(int) { return false; }
+constexpr bool kShootOut = false;
+#else
+S2D_DEV bool is_penalty(int mode) { return in_modes(mode, kPenaltyModes); }
+constexpr bool kShootOut = true;
+#endif
+// the shoot-out's state in the set-play word (include/s2d_match.h): kicks taken / goals of a side
+S2D_DEV int pen_kicks(int w, int side) { return (w >> (side == SIDE_LEFT ? 12 : 16)) & 15; }
+S2D_DEV int pen_goals(int w, int side) { return (w >> (side == SIDE_LEFT ? 20 : 24)) & 15; }
+// is the shoot-out decided (or used up) after the kicks counted in w?  (oracle: pen_over)
+template <class P> S2D_DEV bool pen_over(const P& p, int w) {
+  const int kl = pen_kicks(w, SIDE_LEFT), kr = pen_kicks(w, SIDE_RIGHT), gl = pen_goals(w, SIDE_LEFT), gr = pen_goals(w, SIDE_RIGHT);
+  const int nr = p.pen_nr_kicks;
+  if (kl <= nr && kr <= nr) {                            // the regular kicks: over as soon as one side cannot catch up
+    if (gl > gr + (nr - kr) || gr > gl + (nr - kl)) return true;
+    if (kl == nr && kr == nr) return gl != gr || p.pen_max_extra_kicks <= 0;
+    return false;
+  }
+  if (kl == kr) return gl != gr || kl >= nr + p.pen_max_extra_kicks;   // pairs of extra kicks
+  return false;
+}
 S2D_DEV float hbcast(float v, int src) { return __shfl(v, src, kHalf); }
 S2D_DEV int hbcasti(int v, int src) { return __shfl(v, src, kHalf); }
 // The same broadcast from a lane known at compile time (the ball's): two v_readlane and a select -- a few cycles -- where the
@@ -429,18 +463,27 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   float ax = 0.0f, ay = 0.0f, kx = 0.0f, ky = 0.0f;
   bool kicked = false, by_kick = false;                    // by_kick: the impulse came from a Kick command (not a tackle)
   if (!is_player || o.tackle > 0 || mode0 == S2D_GM_TIME_OVER || o.card >= S2D_CARD_RED) cmd = S2D_MCMD_NONE;
+  // the shoot-out: the taker acts once the kick is ready, the defending goalie once it is taken, nobody else at all
+  const bool pen = is_penalty(mode0);                      // (uniform per match)
+  int pen_goalie = -1;
+  if (pen) {
+    const int pen_taker = (gr.taker & 0xff) - 1;
+    pen_goalie = side0 == SIDE_LEFT ? S2D_MATCH_GOALIE_RIGHT : S2D_MATCH_GOALIE_LEFT;
+    if (!((l == pen_taker && (mode0 == S2D_GM_PENALTY_READY || mode0 == S2D_GM_PENALTY_TAKEN)) ||
+          (l == pen_goalie && mode0 == S2D_GM_PENALTY_TAKEN))) cmd = S2D_MCMD_NONE;
+  }
   // one noise block per object and cycle: x, y = movement noise; z, w = the command's own noise (a player sends ONE body
   // command per cycle: Turn uses z, Kick uses z and w)
   U4 nz{0, 0, 0, 0};
   if (p.noise) nz = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, (uint32_t)l);
-  const bool may_touch = !is_setplay(mode0) || (side_of(l) == side0 && !ball_dead(mode0));   // announcements, after a goal, before the kick-off: the ball is dead
+  const bool may_touch = !is_setplay(mode0) || (side_of(l) == side0 && !ball_dead(mode0)) || (mode0 == S2D_GM_PENALTY_TAKEN && l == pen_goalie);   // announcements, after a goal, before the kick-off: the ball is dead
   bool foul_try = false, foul_seen_l = false;              // this lane's intentional tackle succeeded; the referee would see a foul of his
   bool caught = false, hold_moved = false;
   if (cmd == S2D_MCMD_DASH) m_dash(p, pt, l, o, a, bb, ax, ay);
   else if (cmd == S2D_MCMD_TURN) m_turn(p, pt[PT_INERTIA][l], o, a, rnd_u01(nz.z));
   else if (cmd == S2D_MCMD_CATCH) {
     // goalies only, play_on only, not while banned; every attempt starts the ban
-    if ((l == S2D_MATCH_GOALIE_LEFT || l == S2D_MATCH_GOALIE_RIGHT) && mode0 == S2D_GM_PLAY_ON && o.catch_ban == 0) {
+    if ((l == S2D_MATCH_GOALIE_LEFT || l == S2D_MATCH_GOALIE_RIGHT) && (mode0 == S2D_GM_PLAY_ON || mode0 == S2D_GM_PENALTY_TAKEN) && o.catch_ban == 0) {
       float u = 0.0f;
       if (p.catch_probability < 1.0f) u = rnd_u01(m_draw(p, gl, gh, cyc, S2D_ST_CATCH, (uint32_t)l).x);
       o.catch_ban = p.catch_ban_cycle + 1;
@@ -556,13 +599,14 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     const bool other_touch = (kmask & ~taker_bit) != 0u;
     fk_fault = p.free_kick_faults && mode0 == S2D_GM_PLAY_ON && taker0 != 0 && any_kick && !other_touch;
     if (any_kick) {
-      if (is_setplay(mode0)) gr.taker = (last_kicker + 1) | (mode0 == S2D_GM_IND_FREE_KICK ? 0x100 : 0);   // this kick puts the ball into play
+      if (is_penalty(mode0)) { /* the word carries the shoot-out's state */ }
+      else if (is_setplay(mode0)) gr.taker = (last_kicker + 1) | (mode0 == S2D_GM_IND_FREE_KICK ? 0x100 : 0);   // this kick puts the ball into play
       else if (other_touch) gr.taker = 0;
       const int last_kick_cmd = cmask2 ? 31 - __clz(cmask2) : -1;
       gr.last_kicker = (last_kick_cmd == last_kicker) ? last_kick_cmd + 1 : 0;
     }
   }
-  const bool ball_live = !is_setplay(mode0) || any_kick;
+  const bool ball_live = !is_setplay(mode0) || any_kick || mode0 == S2D_GM_PENALTY_TAKEN;
   if (caught_by >= 0) {                                   // held: the ball rests where it was caught
     g.last_touch = side_of(caught_by);
     if (is_ball) { o.vx = 0.0f; o.vy = 0.0f; }
@@ -672,7 +716,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
       coll_touch_side = side_of(touch_player);
       g.last_touch = coll_touch_side;
-      if (touch_player + 1 != (gr.taker & 0xff)) gr.taker = 0;
+      if (!is_penalty(mode0) && touch_player + 1 != (gr.taker & 0xff)) gr.taker = 0;
       if (touch_player + 1 != gr.last_kicker) gr.last_kicker = 0;
     }
   }
@@ -682,7 +726,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     const float bxn = bx, byn = by;
     // the side that does not take the set play keeps its distance; during an announcement that is the offending side (side0)
     const int kept_away = is_announcement(mode0) ? side0 : other_side(side0);
-    if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && !is_period_end(mode0) && is_player &&
+    if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && !is_period_end(mode0) && !is_penalty(mode0) && is_player &&
         side_of(l) == kept_away && o.card < S2D_CARD_RED) {
       float dx = o.x - bxn, dy = o.y - byn, d = hypot2(dx, dy);
       if (d < p.free_kick_distance) {
@@ -714,9 +758,11 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     if (mode0 == S2D_GM_TIME_OVER) {
       idle = true;
     } else {                                               // the value the timer has to stay below after this cycle's increment
-      const int limit = !ball_dead(mode0) ? p.drop_ball_time + 1 : mode0 == S2D_GM_AFTER_GOAL ? p.after_goal_wait :
+      const int pen_limit = mode0 == S2D_GM_PENALTY_READY ? p.pen_ready_wait : mode0 == S2D_GM_PENALTY_TAKEN ? p.pen_taken_wait + 1 :
+                            mode0 == S2D_GM_PENALTY_SETUP ? 0 : p.pen_before_setup_wait;
+      const int limit = is_penalty(mode0) ? pen_limit : !ball_dead(mode0) ? p.drop_ball_time + 1 : mode0 == S2D_GM_AFTER_GOAL ? p.after_goal_wait :
                         is_announcement(mode0) ? p.announce_wait : mode0 == S2D_GM_BEFORE_KICK_OFF ? p.kick_off_wait : 0;
-      idle = g.timer + 1 < limit;
+      idle = g.timer + 1 < limit && (mode0 != S2D_GM_PENALTY_TAKEN || (fabsf(bx) <= p.half_l && fabsf(by) <= p.half_w));
     }
   }
   const bool busy = !(calm && idle);
@@ -766,6 +812,36 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
           g.mode = S2D_GM_PENALTY_KICK; g.offside = 0;
           place_ball = true; pbx = (side0 == SIDE_LEFT ? -1.0f : 1.0f) * (p.half_l - 11.0f); pby = 0.0f;
         }
+      }
+    } else if (is_penalty(mode0)) {                        // the shoot-out's own sequence (oracle: match_step, same order)
+      int result = -1;                                     // 0 / 1: this cycle ends the kick with a miss / a goal
+      if (mode0 == S2D_GM_PENALTY_ONFIELD) {
+        g.timer += 1;
+        if (g.timer >= p.pen_before_setup_wait) { g.mode = S2D_GM_PENALTY_SETUP; g.mode_side = SIDE_LEFT; }   // the left team kicks first (placed below)
+      } else if (mode0 == S2D_GM_PENALTY_SETUP) {          // one cycle: everybody was placed on entering it
+        g.mode = S2D_GM_PENALTY_READY; g.timer = 0;
+      } else if (mode0 == S2D_GM_PENALTY_READY) {
+        if (any_kick) { g.mode = S2D_GM_PENALTY_TAKEN; g.timer = 0; }
+        else { g.timer += 1; if (g.timer >= p.pen_ready_wait) result = 0; }
+      } else if (mode0 == S2D_GM_PENALTY_TAKEN) {
+        if (caught_by >= 0) result = 0;
+        else if (bx > p.half_l && fabsf(by) < p.goal_half_width) result = 1;
+        else if (fabsf(bx) > p.half_l || fabsf(by) > p.half_w) result = 0;
+        else { g.timer += 1; if (g.timer > p.pen_taken_wait) result = 0; }
+      } else {                                             // PenaltyScore_ / PenaltyMiss_: the verdict stands for a while
+        g.timer += 1;
+        if (g.timer >= p.pen_before_setup_wait) {
+          if (pen_over(p, gr.taker)) {
+            g.mode = S2D_GM_TIME_OVER; g.mode_side = SIDE_NONE; g.done = 1; if (is_ball) ev |= EV_FINISHED;
+          } else { g.mode = S2D_GM_PENALTY_SETUP; g.mode_side = other_side(side0); }
+        }
+      }
+      if (result >= 0) {                                   // counted, announced; the ball is dead
+        int w = gr.taker + (1 << (side0 == SIDE_LEFT ? 12 : 16));
+        if (result) { w += 1 << (side0 == SIDE_LEFT ? 20 : 24); g.reward = side0 == SIDE_LEFT ? 1.0f : -1.0f; }
+        gr.taker = w;
+        g.mode = result ? S2D_GM_PENALTY_SCORE : S2D_GM_PENALTY_MISS; g.timer = 0;
+        if (is_ball) { o.vx = 0.0f; o.vy = 0.0f; }
       }
     } else if (is_setplay(mode0)) {
       if (any_kick) { g.mode = S2D_GM_PLAY_ON; g.timer = 0; }
@@ -862,7 +938,13 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     bool over = advanced && g.cycle >= end_cycles;
     if (extra && advanced && g.cycle == total_cycles) over = gr.score_l != gr.score_r;      // a draw is extended
     if (extra && p.golden_goal && g.cycle > total_cycles && g.reward != 0.0f) over = true;   // a goal (this cycle) in extra time
-    if (over) {
+    if (is_penalty(mode0)) { over = false; at_half = false; }   // (the shoot-out ends by its own count; its clock stands)
+    if (kShootOut && over && advanced && g.cycle == end_cycles && p.penalty_shoot_outs && gr.score_l == gr.score_r) {
+      // a draw after the last period: PenaltyOnfield_, named after the half the kicks are taken in (the right one)
+      g.mode = S2D_GM_PENALTY_ONFIELD; g.mode_side = SIDE_RIGHT; g.timer = 0; g.offside = 0; g.last_touch = SIDE_NONE;
+      gr.taker = 0; gr.last_kicker = 0;
+      if (is_ball) { o.vx = 0.0f; o.vy = 0.0f; }
+    } else if (over) {
       g.mode = S2D_GM_TIME_OVER; g.mode_side = SIDE_NONE; g.done = 1; if (g.offside > 0) g.offside = 0; if (is_ball) ev |= EV_FINISHED;
     } else if (at_half) {
       const bool in_extra = extra && g.cycle >= total_cycles;
@@ -886,6 +968,21 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     }
   }
   if (recover_half && is_player) m_recover(p, pt[PT_EFFORT_MAX][l], o, false);
+  if (g.mode == S2D_GM_PENALTY_SETUP && mode0 != S2D_GM_PENALTY_SETUP) {   // entering PenaltySetup_: the referee places everybody (oracle: pen_setup)
+    const int pen_next = g.mode_side;
+    const int w = gr.taker;
+    const int taker = (pen_next == SIDE_LEFT ? 0 : 11) + 10 - pen_kicks(w, pen_next) % 11;
+    const int goalie = pen_next == SIDE_LEFT ? S2D_MATCH_GOALIE_RIGHT : S2D_MATCH_GOALIE_LEFT;
+    if (is_player && o.card < S2D_CARD_RED) {              // (sent off: stays parked; a kick that falls to him is missed)
+      if (l == taker) { o.x = p.pen_spot_x - 0.7f; o.y = 0.0f; o.body = 0.0f; }
+      else if (l == goalie) { o.x = p.half_l - 1.0f; o.y = 0.0f; o.body = 180.0f; }
+      else { o.x = l < 11 ? -3.0f : 3.0f; o.y = -7.5f + 1.5f * (float)(l % 11); }
+      o.vx = 0.0f; o.vy = 0.0f;
+    }
+    if (is_ball) { o.x = p.pen_spot_x; o.y = 0.0f; o.vx = 0.0f; o.vy = 0.0f; }
+    g.timer = 0; g.offside = 0;
+    gr.last_kicker = 0; gr.taker = (w & ~0xff) | (taker + 1);
+  }
   if (restart_form) m_place(o, l, form_side);
   else if (place_ball && is_ball) { o.x = pbx; o.y = pby; o.vx = 0.0f; o.vy = 0.0f; }
   }                                                        // busy
@@ -1139,7 +1236,7 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
   if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0u;
   if constexpr (STOCK) {
     __syncthreads();
-    const MStock p{p_arg.auto_reset, p_arg.noise, p_arg.seed_lo, p_arg.seed_hi, p_arg.gid_lo, p_arg.gid_hi};
+    const MStock p{p_arg.auto_reset, p_arg.noise, p_arg.penalty_shoot_outs, p_arg.seed_lo, p_arg.seed_hi, p_arg.gid_lo, p_arg.gid_hi};
     if constexpr (STOCK_TYPES) {
       const MStockTypes types{__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q.ptab[PT_KICKABLE_AREA2 * kHalf])))};
       match_rollout_body(p, types, sh, q, n, n_steps, actions, ro);
@@ -1323,6 +1420,8 @@ S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
   m.kick_off_wait = 0; m.back_passes = 1; m.free_kick_faults = 1;
   m.stopped_clock = 1; m.announce_wait = 30; m.foul_cycles = 5; m.foul_detect_probability = 0.5;
   m.nr_extra_halfs = S2D_STOCK_EXTRA_HALFS; m.extra_half_cycles = 1000; m.golden_goal = 0;
+  m.penalty_shoot_outs = S2D_STOCK_SHOOT_OUTS; m.pen_before_setup_wait = 10; m.pen_ready_wait = 10; m.pen_taken_wait = 150; m.pen_nr_kicks = 5;
+  m.pen_max_extra_kicks = 5; m.pen_dist_x = 42.5;
   c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
   for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) c->player_types[t] = m_default_type(c->sp, m);   // homogeneous
 }
@@ -1345,6 +1444,9 @@ S2D_API int s2d_match_validate_config(const S2DMatchConfig* c) {
     return mfail(S2D_EINVAL, "announce_wait / foul_cycles must be >= 0, foul_detect_probability in [0, 1]");
   if (c->mp.nr_extra_halfs < 0 || (c->mp.nr_extra_halfs > 0 && c->mp.extra_half_cycles < 1))
     return mfail(S2D_EINVAL, "nr_extra_halfs must be >= 0 and extra_half_cycles >= 1 when extra halves are played");
+  if (c->mp.pen_before_setup_wait < 0 || c->mp.pen_ready_wait < 0 || c->mp.pen_taken_wait < 0 || c->mp.pen_nr_kicks < 1 ||
+      c->mp.pen_max_extra_kicks < 0 || c->mp.pen_nr_kicks + c->mp.pen_max_extra_kicks > 15)
+    return mfail(S2D_EINVAL, "pen_*_wait must be >= 0, pen_nr_kicks >= 1, pen_max_extra_kicks >= 0 and their sum <= 15");
   for (int i = 0; i < S2D_MATCH_PLAYERS; ++i)
     if (c->player_type_id[i] < 0 || c->player_type_id[i] >= S2D_MATCH_PLAYER_TYPES)
       return mfail(S2D_EINVAL, "player_type_id entries must be in [0, 18)");
@@ -1401,6 +1503,9 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   p.stopped_clock = m.stopped_clock; p.announce_wait = m.announce_wait; p.foul_cycles = m.foul_cycles;
   p.foul_detect_probability = (float)m.foul_detect_probability;
   p.nr_extra_halfs = m.nr_extra_halfs; p.extra_half_cycles = m.extra_half_cycles; p.golden_goal = m.golden_goal != 0;
+  p.penalty_shoot_outs = m.penalty_shoot_outs != 0; p.pen_before_setup_wait = m.pen_before_setup_wait; p.pen_ready_wait = m.pen_ready_wait;
+  p.pen_taken_wait = m.pen_taken_wait; p.pen_nr_kicks = m.pen_nr_kicks; p.pen_max_extra_kicks = m.pen_max_extra_kicks;
+  p.pen_spot_x = (float)(s.pitch_half_length - m.pen_dist_x);
   p.total_cycles = m.half_time_cycles * m.nr_normal_halfs;
   p.end_cycles = p.total_cycles + (m.nr_extra_halfs > 0 ? m.extra_half_cycles * m.nr_extra_halfs : 0);
   p.auto_reset = c.auto_reset; p.noise = c.noise;

@@ -45,8 +45,20 @@ enum {
   S2D_GM_BEFORE_KICK_OFF = 0, S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4,
   S2D_GM_FREE_KICK = 5, S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_AFTER_GOAL = 8, S2D_GM_OFF_SIDE = 9,
   S2D_GM_PENALTY_KICK = 10, S2D_GM_FIRST_HALF_OVER = 11, S2D_GM_FOUL_CHARGE = 14, S2D_GM_BACK_PASS = 18, S2D_GM_FREE_KICK_FAULT = 19,
-  S2D_GM_CATCH_FAULT = 20, S2D_GM_IND_FREE_KICK = 21, S2D_GM_GOALIE_CATCH = 30, S2D_GM_EXTEND_HALF = 31
+  S2D_GM_CATCH_FAULT = 20, S2D_GM_IND_FREE_KICK = 21, S2D_GM_GOALIE_CATCH = 30, S2D_GM_EXTEND_HALF = 31,
+  /* the penalty shoot-out after a drawn extra time (idl/service.proto:290-297; PenaltyFoul_ = 29 is not called: the defending
+   * goalie stands still until the kick, the kicker may play the ball more than once -- rcssserver's pen_allow_mult_kicks) */
+  S2D_GM_PENALTY_SETUP = 22, S2D_GM_PENALTY_READY = 23, S2D_GM_PENALTY_TAKEN = 24, S2D_GM_PENALTY_MISS = 25,
+  S2D_GM_PENALTY_SCORE = 26, S2D_GM_PENALTY_ONFIELD = 28
 };
+/* During the shoot-out the set-play word (S2DMatchBuffers.set_play_taker) carries its state -- PenaltyKickState of the proto
+ * (idl/service.proto:130-138): bits 0-7 = 1 + index of the current taker, 12-15 / 16-19 = kicks taken by the left / right team,
+ * 20-23 / 24-27 = their shoot-out goals; the mode side is the current taker's team. */
+#define S2D_PEN_TAKER(w) (((w) & 0xff) - 1)
+#define S2D_PEN_KICKS_LEFT(w) (((w) >> 12) & 15)
+#define S2D_PEN_KICKS_RIGHT(w) (((w) >> 16) & 15)
+#define S2D_PEN_SCORE_LEFT(w) (((w) >> 20) & 15)
+#define S2D_PEN_SCORE_RIGHT(w) (((w) >> 24) & 15)
 /* cards (rcssserver's yellow_card / red_card referee messages; no field of the proto's Player carries them) */
 enum { S2D_CARD_NONE = 0, S2D_CARD_YELLOW = 1, S2D_CARD_RED = 2 /* sent off: parked beside the pitch, commands ignored */ };
 
@@ -84,9 +96,21 @@ typedef struct S2DMatchParams {
                                              "time_extended"), then a kick-off; 0 = the match ends with the normal time */
   double foul_detect_probability;         /* .5: chance that the referee sees an intentional foul (:1632) */
   int32_t extra_half_cycles;              /* 1000: length of an extra half (ServerParam.extra_half_time :1622, 100 s of 10 cycles);
-                                             FirstHalfOver between extra halves, TimeOver after the last one whatever the score --
-                                             the penalty shoot-out (penalty_shoot_outs :1602) is not built */
+                                             FirstHalfOver between extra halves; after the last one a draw goes to the shoot-out below */
   int32_t golden_goal;                    /* 0: a goal in extra time ends the match at once (ServerParam.golden_goal :1635) */
+  /* The penalty shoot-out (ServerParam.penalty_shoot_outs, pen_*: idl/service.proto:1602-1613) after a draw that the last period
+   * leaves: PenaltyOnfield_ (side = the half the kicks are taken in: the right one) for pen_before_setup_wait cycles; then per
+   * kick PenaltySetup_ (one cycle: the ball on the spot pen_dist_x from the right goal line, the taker behind it, the other team's
+   * goalie on the line, everybody else inside the centre circle, all placed by the referee = pen_coach_moves_players), PenaltyReady_
+   * (the taker has pen_ready_wait cycles to play the ball), PenaltyTaken_ (taker against goalie, at most pen_taken_wait cycles:
+   * ball in the goal = PenaltyScore_; out, caught or out of time = PenaltyMiss_), the verdict for pen_before_setup_wait cycles.
+   * The left team kicks first, takers from index 10 downwards; pen_nr_kicks each (decided early when one side cannot catch up),
+   * then pairs of kicks until one pair decides or pen_max_extra_kicks more are used up (then the draw stands: pen_random_winner
+   * is not built).  The clock stands throughout. */
+  int32_t penalty_shoot_outs;             /* 1 */
+  int32_t pen_before_setup_wait, pen_ready_wait, pen_taken_wait;   /* 10 10 150 */
+  int32_t pen_nr_kicks, pen_max_extra_kicks;                       /* 5 5 (their sum <= 15) */
+  double pen_dist_x;                      /* 42.5 */
 } S2DMatchParams;
 
 /* PlayerType (idl/service.proto:1697-1732): the members that enter the dynamics.  Type 0 is the

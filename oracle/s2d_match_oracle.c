@@ -42,6 +42,7 @@ typedef struct MP {
   int kick_off_wait, back_passes, free_kick_faults;
   int stopped_clock, announce_wait, foul_cycles; REAL foul_detect_probability;
   int nr_extra_halfs, extra_half_cycles, golden_goal;
+  int penalty_shoot_outs, pen_before_setup_wait, pen_ready_wait, pen_taken_wait, pen_nr_kicks, pen_max_extra_kicks; REAL pen_spot_x;
   REAL catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
   /* heterogeneous players: the parameters of every player slot's PlayerType (idl/service.proto:1697-1732) */
@@ -98,6 +99,9 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   p->stopped_clock = m->stopped_clock; p->announce_wait = m->announce_wait; p->foul_cycles = m->foul_cycles;
   p->foul_detect_probability = (REAL)m->foul_detect_probability;
   p->nr_extra_halfs = m->nr_extra_halfs; p->extra_half_cycles = m->extra_half_cycles; p->golden_goal = m->golden_goal;
+  p->penalty_shoot_outs = m->penalty_shoot_outs; p->pen_before_setup_wait = m->pen_before_setup_wait; p->pen_ready_wait = m->pen_ready_wait;
+  p->pen_taken_wait = m->pen_taken_wait; p->pen_nr_kicks = m->pen_nr_kicks; p->pen_max_extra_kicks = m->pen_max_extra_kicks;
+  p->pen_spot_x = (REAL)(s->pitch_half_length - m->pen_dist_x);
   p->catch_half_w = (REAL)(m->catch_area_w * 0.5); p->catch_probability = (REAL)m->catch_probability;
   p->max_catch_angle = (REAL)m->max_catch_angle; p->min_catch_angle = (REAL)m->min_catch_angle;
   p->pen_x = (REAL)(s->pitch_half_length - m->penalty_area_length); p->pen_half_w = (REAL)m->penalty_area_half_width;
@@ -143,15 +147,20 @@ static int is_announcement(int mode) {
          mode == S2D_GM_FOUL_CHARGE;
 }
 /* modes in which nobody may play the ball */
+/* the shoot-out's modes (idl/service.proto:290-297) */
+static int is_penalty(int mode) {
+  return mode == S2D_GM_PENALTY_SETUP || mode == S2D_GM_PENALTY_READY || mode == S2D_GM_PENALTY_TAKEN || mode == S2D_GM_PENALTY_MISS ||
+         mode == S2D_GM_PENALTY_SCORE || mode == S2D_GM_PENALTY_ONFIELD;
+}
 static int is_period_end(int mode) { return mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_EXTEND_HALF; }   /* "half_time", "time_extended" */
 static int ball_dead(int mode) {
   return mode == S2D_GM_AFTER_GOAL || mode == S2D_GM_BEFORE_KICK_OFF || is_period_end(mode) || mode == S2D_GM_GOALIE_CATCH ||
-         is_announcement(mode);
+         is_announcement(mode) || (is_penalty(mode) && mode != S2D_GM_PENALTY_READY && mode != S2D_GM_PENALTY_TAKEN);
 }
 /* modes in which the clock stands still (with stopped_clock): WorldModel.cycle keeps its value, stoped_cycle counts */
 static int clock_stands(int mode) {
   return mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_AFTER_GOAL || is_period_end(mode) || mode == S2D_GM_TIME_OVER ||
-         is_announcement(mode);
+         is_announcement(mode) || is_penalty(mode);
 }
 /* where a sent-off player waits: beside the halfway line, outside the pitch, one spot per uniform number */
 static void park_sent_off(const MP *p, Obj *o, int i) {
@@ -318,6 +327,50 @@ static void restart(Match *m, int mode, int side, REAL bx, REAL by) {
   m->set_play_taker = 0; m->last_kicker = 0;
 }
 
+/* ---- the penalty shoot-out (rcssserver's PenaltyRef restated; ServerParam.pen_*: idl/service.proto:1602-1613).  Its state lives in
+ * the set-play word: bits 0-7 = 1 + taker, 12-15 / 16-19 kicks taken left / right, 20-23 / 24-27 goals left / right (include/s2d_match.h). */
+static int pen_kicks(int w, int side) { return (w >> (side == SIDE_LEFT ? 12 : 16)) & 15; }
+static int pen_goals(int w, int side) { return (w >> (side == SIDE_LEFT ? 20 : 24)) & 15; }
+/* PenaltySetup_ for `side`: the referee places everybody (pen_coach_moves_players): the ball on the spot, the taker (index 10 downwards,
+ * by the kicks his team has taken) 0.7 m behind it, the other team's goalie on the right goal line, the rest inside the centre circle */
+static void pen_setup(const MP *p, Match *m, int side) {
+  const int w = m->set_play_taker;
+  const int taker = (side == SIDE_LEFT ? 0 : 11) + 10 - pen_kicks(w, side) % 11;
+  const int goalie = side == SIDE_LEFT ? S2D_MATCH_GOALIE_RIGHT : S2D_MATCH_GOALIE_LEFT;
+  for (int i = 0; i < NP; ++i) {
+    Obj *o = &m->o[i];
+    if (o->card >= S2D_CARD_RED) continue;               /* sent off: stays parked (a kick that falls to him is missed) */
+    if (i == taker) { o->x = p->pen_spot_x - R(0.7); o->y = R(0.0); o->body = R(0.0); }
+    else if (i == goalie) { o->x = p->half_l - R(1.0); o->y = R(0.0); o->body = R(180.0); }
+    else { o->x = i < 11 ? R(-3.0) : R(3.0); o->y = R(-7.5) + R(1.5) * (REAL)(i % 11); }
+    o->vx = R(0.0); o->vy = R(0.0);
+  }
+  Obj *b = &m->o[BALL]; b->x = p->pen_spot_x; b->y = R(0.0); b->vx = R(0.0); b->vy = R(0.0);
+  m->mode = S2D_GM_PENALTY_SETUP; m->mode_side = side; m->setplay_timer = 0; m->offside_mask = 0; m->last_kicker = 0;
+  m->set_play_taker = (w & ~0xff) | (taker + 1);
+}
+/* the kick of `side` is over: counted, announced (PenaltyScore_ / PenaltyMiss_), the ball is dead */
+static void pen_result(Match *m, int side, int scored) {
+  int w = m->set_play_taker;
+  w += 1 << (side == SIDE_LEFT ? 12 : 16);
+  if (scored) { w += 1 << (side == SIDE_LEFT ? 20 : 24); m->reward_left = side == SIDE_LEFT ? R(1.0) : R(-1.0); }
+  m->set_play_taker = w;
+  m->mode = scored ? S2D_GM_PENALTY_SCORE : S2D_GM_PENALTY_MISS; m->setplay_timer = 0;
+  m->o[BALL].vx = R(0.0); m->o[BALL].vy = R(0.0);
+}
+/* is the shoot-out decided (or used up) after the kicks counted in w? */
+static int pen_over(const MP *p, int w) {
+  const int kl = pen_kicks(w, SIDE_LEFT), kr = pen_kicks(w, SIDE_RIGHT), gl = pen_goals(w, SIDE_LEFT), gr = pen_goals(w, SIDE_RIGHT);
+  const int nr = p->pen_nr_kicks;
+  if (kl <= nr && kr <= nr) {                            /* the regular kicks: over as soon as one side cannot catch up */
+    if (gl > gr + (nr - kr) || gr > gl + (nr - kl)) return 1;
+    if (kl == nr && kr == nr) return gl != gr || p->pen_max_extra_kicks <= 0;
+    return 0;
+  }
+  if (kl == kr) return gl != gr || kl >= nr + p->pen_max_extra_kicks;   /* pairs of extra kicks */
+  return 0;
+}
+
 typedef struct MatchStats { unsigned long long v[8]; } MatchStats;
 
 /* one cycle of one match; act = [22][3] {cmd, a, b} */
@@ -329,6 +382,9 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   for (int i = 0; i < NOBJ; ++i) { x0[i] = m->o[i].x; y0[i] = m->o[i].y; }
   m->reward_left = R(0.0); m->done = 0;
   int foul_by = -1, foul_victim = -1, foul_seen = 0;      /* an intentional foul of this cycle: tackler, victim, seen by the referee */
+  const int pen = is_penalty(mode0);
+  const int pen_taker = pen ? (m->set_play_taker & 0xff) - 1 : -1;
+  const int pen_goalie = !pen ? -1 : side0 == SIDE_LEFT ? S2D_MATCH_GOALIE_RIGHT : S2D_MATCH_GOALIE_LEFT;
 
   /* 1. commands */
   REAL ax[NP], ay[NP], kx[NP], ky[NP];
@@ -343,15 +399,18 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     int cmd = (int)act[i * 3 + 0];
     REAL a = (REAL)act[i * 3 + 1], bb = (REAL)act[i * 3 + 2];
     if (o->tackle > 0 || mode0 == S2D_GM_TIME_OVER || o->card >= S2D_CARD_RED) cmd = S2D_MCMD_NONE;
+    /* the shoot-out: the taker acts once the kick is ready, the defending goalie once it is taken, nobody else at all */
+    if (pen && !((i == pen_taker && (mode0 == S2D_GM_PENALTY_READY || mode0 == S2D_GM_PENALTY_TAKEN)) ||
+                 (i == pen_goalie && mode0 == S2D_GM_PENALTY_TAKEN))) cmd = S2D_MCMD_NONE;
     uint32_t nz[4] = {0, 0, 0, 0};                       /* x, y: movement noise; z, w: the command's noise (Turn: z; Kick: z, w) */
     if (p->noise) draw(p->seed, gid, cyc, ST_NOISE, (uint32_t)i, nz);
     /* set play: only the taking side plays the ball; after a goal nobody does */
-    int may_touch = !is_setplay(mode0) || (side_of(i) == side0 && !ball_dead(mode0));
+    int may_touch = !is_setplay(mode0) || (side_of(i) == side0 && !ball_dead(mode0)) || (mode0 == S2D_GM_PENALTY_TAKEN && i == pen_goalie);
     if (cmd == S2D_MCMD_DASH) m_dash(p, t, o, a, bb, &ax[i], &ay[i]);
     else if (cmd == S2D_MCMD_TURN) m_turn(p, t, o, a, rnd_u01(nz[2]));
     else if (cmd == S2D_MCMD_CATCH) {
       /* goalies only, play_on only, not while banned; every attempt starts the ban */
-      if ((i == S2D_MATCH_GOALIE_LEFT || i == S2D_MATCH_GOALIE_RIGHT) && mode0 == S2D_GM_PLAY_ON && o->catch_ban == 0) {
+      if ((i == S2D_MATCH_GOALIE_LEFT || i == S2D_MATCH_GOALIE_RIGHT) && (mode0 == S2D_GM_PLAY_ON || mode0 == S2D_GM_PENALTY_TAKEN) && o->catch_ban == 0) {
         REAL u = R(0.0);
         if (p->catch_probability < R(1.0)) { uint32_t w[4]; draw(p->seed, gid, cyc, ST_CATCH, (uint32_t)i, w); u = rnd_u01(w[0]); }
         o->catch_ban = p->catch_ban_cycle + 1;
@@ -429,12 +488,13 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   /* free-kick fault (FreeKickFault_, idl/service.proto:287): the taker of a set play plays the ball again before anybody else */
   const int fk_fault = p->free_kick_faults && mode0 == S2D_GM_PLAY_ON && taker0 != 0 && any_kick && !other_touch;
   if (any_kick) {
-    if (is_setplay(mode0)) m->set_play_taker = (last_kicker + 1) | (mode0 == S2D_GM_IND_FREE_KICK ? 0x100 : 0);   /* this kick puts the ball into play */
+    if (pen) { /* the word carries the shoot-out's state */ }
+    else if (is_setplay(mode0)) m->set_play_taker = (last_kicker + 1) | (mode0 == S2D_GM_IND_FREE_KICK ? 0x100 : 0);   /* this kick puts the ball into play */
     else if (other_touch) m->set_play_taker = 0;
     /* back-pass bookkeeping: the last Kick command counts; a tackle touch ends it */
     m->last_kicker = (last_kick_cmd == last_kicker) ? last_kick_cmd + 1 : 0;
   }
-  const int ball_live = !is_setplay(mode0) || any_kick;
+  const int ball_live = !is_setplay(mode0) || any_kick || mode0 == S2D_GM_PENALTY_TAKEN;
   if (caught_by >= 0) {                                   /* held: the ball rests where it was caught */
     b->vx = R(0.0); b->vy = R(0.0); m->last_touch_side = side_of(caught_by);
   } else if (hold_move >= 0) {                            /* the holding goalie moved: the ball goes with him, in front of his body */
@@ -487,12 +547,12 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   if (touch_player >= 0 && (!is_setplay(mode0) || side_of(touch_player) == side0)) {
     coll_touch_side = side_of(touch_player);
     m->last_touch_side = coll_touch_side;
-    if (touch_player + 1 != (m->set_play_taker & 0xff)) m->set_play_taker = 0;
+    if (!pen && touch_player + 1 != (m->set_play_taker & 0xff)) m->set_play_taker = 0;
     if (touch_player + 1 != m->last_kicker) m->last_kicker = 0;
   }
   /* 4. set play: the side that does not take it keeps free_kick_distance from the ball; during an announcement that is the
    * offending side, the one the mode is named after (the restart will be the other side's) */
-  if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && !is_period_end(mode0)) {
+  if (is_setplay(mode0) && mode0 != S2D_GM_AFTER_GOAL && !is_period_end(mode0) && !pen) {
     const int kept_away = is_announcement(mode0) ? side0 : other_side(side0);
     for (int i = 0; i < NP; ++i) if (side_of(i) == kept_away && m->o[i].card < S2D_CARD_RED) {
       Obj *o = &m->o[i];
@@ -534,6 +594,29 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
         const int own_area = R(fabs)(b->y) <= p->pen_half_w && (side0 == SIDE_LEFT ? b->x <= -p->pen_x : b->x >= p->pen_x);
         if (mode0 == S2D_GM_FOUL_CHARGE && own_area)
           restart(m, S2D_GM_PENALTY_KICK, other_side(side0), (side0 == SIDE_LEFT ? R(-1.0) : R(1.0)) * (p->half_l - R(11.0)), R(0.0));
+      }
+    } else if (pen) {                                    /* the shoot-out's own sequence */
+      if (mode0 == S2D_GM_PENALTY_ONFIELD) {
+        m->setplay_timer += 1;
+        if (m->setplay_timer >= p->pen_before_setup_wait) pen_setup(p, m, SIDE_LEFT);          /* the left team kicks first */
+      } else if (mode0 == S2D_GM_PENALTY_SETUP) {          /* one cycle: everybody was placed on entering it */
+        m->mode = S2D_GM_PENALTY_READY; m->setplay_timer = 0;
+      } else if (mode0 == S2D_GM_PENALTY_READY) {
+        if (any_kick) { m->mode = S2D_GM_PENALTY_TAKEN; m->setplay_timer = 0; }
+        else { m->setplay_timer += 1; if (m->setplay_timer >= p->pen_ready_wait) pen_result(m, side0, 0); }
+      } else if (mode0 == S2D_GM_PENALTY_TAKEN) {
+        const REAL bx = b->x, by = b->y;
+        if (caught_by >= 0) pen_result(m, side0, 0);
+        else if (bx > p->half_l && R(fabs)(by) < p->goal_half_width) pen_result(m, side0, 1);
+        else if (R(fabs)(bx) > p->half_l || R(fabs)(by) > p->half_w) pen_result(m, side0, 0);
+        else { m->setplay_timer += 1; if (m->setplay_timer > p->pen_taken_wait) pen_result(m, side0, 0); }
+      } else {                                             /* PenaltyScore_ / PenaltyMiss_: the verdict stands for a while */
+        m->setplay_timer += 1;
+        if (m->setplay_timer >= p->pen_before_setup_wait) {
+          if (pen_over(p, m->set_play_taker)) {
+            m->mode = S2D_GM_TIME_OVER; m->mode_side = SIDE_NONE; m->done = 1; st->v[3]++;
+          } else pen_setup(p, m, other_side(side0));
+        }
       }
     } else if (is_setplay(mode0)) {
       if (any_kick) { m->mode = S2D_GM_PLAY_ON; m->setplay_timer = 0; }
@@ -618,7 +701,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     /* half time / extra time / time over (rcssserver's TimeReferee; ServerParam.nr_extra_halfs, extra_half_time, golden_goal:
      * idl/service.proto:1601, 1622, 1635): decided only when the clock has just moved.  Normal time = nr_normal_halfs halves; a
      * draw at its end is extended by nr_extra_halfs halves of extra_half_cycles, played in full unless golden_goal; the periods
-     * alternate the kick-off side.  (penalty_shoot_outs, :1602, is not built: a draw after extra time stands.) */
+     * alternate the kick-off side; a draw after the last period goes to the penalty shoot-out (penalty_shoot_outs, :1602). */
     const int total = p->half_time_cycles * p->nr_normal_halfs;
     const int ext_total = total + p->extra_half_cycles * p->nr_extra_halfs;
     const int tied = m->score_left == m->score_right;
@@ -627,8 +710,14 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     else if (advanced && m->cycle == total) over = !tied;
     else if (advanced && m->cycle >= ext_total) over = 1;
     if (p->golden_goal && p->nr_extra_halfs > 0 && m->cycle > total && m->reward_left != R(0.0)) over = 1;   /* a goal (this cycle) in extra time */
-    if (over) {
+    if (pen) over = 0;                                   /* (the shoot-out ends by its own count; its clock stands) */
+    const int last_end = advanced && m->cycle == ext_total;       /* (= total without extra halves) */
+    if (over && last_end && tied && p->penalty_shoot_outs && mode0 != S2D_GM_TIME_OVER) {
+      /* a draw after the last period: PenaltyOnfield_, named after the half the kicks are taken in (the right one) */
+      restart(m, S2D_GM_PENALTY_ONFIELD, SIDE_RIGHT, b->x, b->y); m->last_touch_side = SIDE_NONE;
+    } else if (over) {
       m->mode = S2D_GM_TIME_OVER; m->mode_side = SIDE_NONE; m->done = 1; m->offside_mask = 0; st->v[3]++;
+    } else if (pen) {
     } else if (advanced && m->cycle < total) {
       if (p->half_time_cycles > 0 && m->cycle % p->half_time_cycles == 0) period = m->cycle / p->half_time_cycles;
     } else if (advanced && p->nr_extra_halfs > 0) {

@@ -17,7 +17,9 @@ MATCH_DEFAULTS = dict(
     catchable_area_l=1.2, catch_area_w=1.0, catch_probability=1.0, max_catch_angle=90.0, min_catch_angle=-90.0,
     penalty_area_length=16.5, penalty_area_half_width=20.16, goalie_max_moves=2, after_goal_wait=50,
     kick_off_wait=0, back_passes=1, free_kick_faults=1, stopped_clock=1, announce_wait=30, foul_cycles=5,
-    foul_detect_probability=0.5, nr_extra_halfs=2, extra_half_cycles=1000, golden_goal=0)
+    foul_detect_probability=0.5, nr_extra_halfs=2, extra_half_cycles=1000, golden_goal=0,
+    penalty_shoot_outs=1, pen_before_setup_wait=10, pen_ready_wait=10, pen_taken_wait=150, pen_nr_kicks=5, pen_max_extra_kicks=5,
+    pen_dist_x=42.5)
 
 
 def default_player_type(sp, mp):

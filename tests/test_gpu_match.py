@@ -57,12 +57,15 @@ def test_match_reset_parity(n):
 
 
 @pytest.mark.parametrize('name,kw', [
-    ('default', dict(half_time_cycles=100, extra_half_cycles=20)),
-    ('noise', dict(half_time_cycles=120, noise=True, nr_extra_halfs=1, extra_half_cycles=30)),
-    ('no-offside-no-autoreset', dict(half_time_cycles=100, use_offside=0, auto_reset=False, extra_half_cycles=25)),
-    ('short-drop', dict(half_time_cycles=150, drop_ball_time=3, tackle_cycles=2, nr_extra_halfs=0)),
-    ('before-kick-off', dict(half_time_cycles=110, kick_off_wait=7, drop_ball_time=20, extra_half_cycles=15, golden_goal=1)),
-    ('no-fault-rules', dict(half_time_cycles=130, back_passes=0, free_kick_faults=0, nr_extra_halfs=0)),
+    ('default', dict(half_time_cycles=100, extra_half_cycles=20, pen_before_setup_wait=1, pen_ready_wait=2, pen_taken_wait=8, pen_nr_kicks=1,
+                     pen_max_extra_kicks=0)),
+    ('noise', dict(half_time_cycles=120, noise=True, nr_extra_halfs=1, extra_half_cycles=30, penalty_shoot_outs=0)),
+    ('no-offside-no-autoreset', dict(half_time_cycles=100, use_offside=0, auto_reset=False, extra_half_cycles=25, pen_before_setup_wait=2,
+                                     pen_ready_wait=3, pen_taken_wait=10, pen_nr_kicks=1, pen_max_extra_kicks=1)),
+    ('short-drop', dict(half_time_cycles=150, drop_ball_time=3, tackle_cycles=2, nr_extra_halfs=0, penalty_shoot_outs=0)),
+    ('before-kick-off', dict(half_time_cycles=110, kick_off_wait=7, drop_ball_time=20, extra_half_cycles=15, golden_goal=1, penalty_shoot_outs=0)),
+    ('no-fault-rules', dict(half_time_cycles=130, back_passes=0, free_kick_faults=0, nr_extra_halfs=0, pen_before_setup_wait=1, pen_ready_wait=2,
+                            pen_taken_wait=6, pen_nr_kicks=1, pen_max_extra_kicks=0)),
 ])
 def test_match_step_parity_random_policy(name, kw):
     """In-kernel Philox policy, per-step launches, 330 cycles (kick-offs, restarts, half time, extra time after a draw,
@@ -167,8 +170,8 @@ def test_scripted_policy_beats_idle_and_random_in_league_round():
 
 def test_match_vec_env_surface():
     from soccer2d_amd.match import Soccer2DMatchVecEnv
-    env = Soccer2DMatchVecEnv(32, half_time_cycles=30, nr_extra_halfs=0)
-    orc = MO.MatchOracle(MO.make_match_config(half_time_cycles=30, nr_extra_halfs=0), 32)
+    env = Soccer2DMatchVecEnv(32, half_time_cycles=30, nr_extra_halfs=0, penalty_shoot_outs=0)
+    orc = MO.MatchOracle(MO.make_match_config(half_time_cycles=30, nr_extra_halfs=0, penalty_shoot_outs=0), 32)
     obs = env.reset()
     assert obs.shape == (32, 23, 5) and env.action_space.shape == (22, 3) and env.observation_space.shape == (23, 5)
     rs = np.random.RandomState(4)
@@ -646,7 +649,7 @@ def test_extra_time_on_device(golden):
     instantiation meets ExtendHalf in test_stock_kernel_parity_random_policy.)  Rules restated: parity unpinned."""
     from soccer2d_amd._capi_match import GM_AFTER_GOAL, GM_EXTEND_HALF, GM_FIRST_HALF_OVER, GM_TIME_OVER
     n = 6
-    eng, orc = _pair(n, half_time_cycles=10, extra_half_cycles=6, auto_reset=0, after_goal_wait=2, golden_goal=golden)
+    eng, orc = _pair(n, half_time_cycles=10, extra_half_cycles=6, auto_reset=0, after_goal_wait=2, golden_goal=golden, penalty_shoot_outs=0)
     lead = np.array([0, 0, 0, 1, 0, 2], dtype=np.int32)                # matches 3 and 5 are decided before the end of the normal time
     eng.score_left.copy_(torch.as_tensor(lead, device='cuda:0'))
     for e in range(n):
@@ -674,6 +677,107 @@ def test_extra_time_on_device(golden):
     assert (orc.get('mode') == GM_TIME_OVER).all() and (eng.mode.cpu().numpy() == GM_TIME_OVER).all()
     assert all((26, GM_FIRST_HALF_OVER) in seen[e] and (32, GM_TIME_OVER) in seen[e] for e in (0, 4))
     assert all(((32, GM_TIME_OVER) in seen[e]) == (not golden) for e in (1, 2))
+
+
+def test_shoot_out_switch_keeps_the_stock_kernel():
+    """penalty_shoot_outs is a per-engine word of the stock instantiation (like auto_reset and noise): switching it off does not send an
+    engine to the general kernel; any other rule word does."""
+    from soccer2d_amd.match import MatchEngine
+    assert MatchEngine(8, 'cuda:0', penalty_shoot_outs=0).kernel_name().endswith('<stock, stock types>')
+    assert MatchEngine(8, 'cuda:0', pen_taken_wait=100).kernel_name().endswith('<general>')
+    assert MatchEngine(8, 'cuda:0', nr_extra_halfs=0).kernel_name().endswith('<general>')
+
+
+def test_penalty_shoot_out_on_device():
+    """The shoot-out (idl/service.proto:290-297, 1602-1613) on the device, every word equal to the oracle's after every cycle: scripted
+    kicks (a goal, a miss by waiting, a ball over the side line, a catch, a kick that runs out of time; decided early in some matches,
+    used up in others), then the in-kernel random policy through whole shoot-outs.  Rules restated: parity unpinned."""
+    from soccer2d_amd._capi_match import (GM_PENALTY_MISS, GM_PENALTY_ONFIELD, GM_PENALTY_READY, GM_PENALTY_SCORE, GM_PENALTY_SETUP,
+                                          GM_PENALTY_TAKEN, GM_TIME_OVER, MCMD_CATCH, MCMD_DASH, MCMD_KICK)
+    n = 4
+    kw = dict(half_time_cycles=6, nr_extra_halfs=0, auto_reset=0, pen_before_setup_wait=2, pen_ready_wait=3, pen_taken_wait=12,
+              pen_nr_kicks=2, pen_max_extra_kicks=1)
+    eng, orc = _pair(n, **kw)                              # (kicks that run out of time: the random-policy part below)
+
+    def both(a):
+        eng.step(torch.as_tensor(a, device='cuda:0')); orc.step(a)
+        assert_match_same(eng, orc, 'shoot-out')
+
+    def acts(**pp):
+        a = np.zeros((n, 22, 3), dtype=np.float32)
+        a[:, 3] = [MCMD_DASH, 100, 0]                      # somebody who has no part in it keeps trying to run
+        for k, v in pp.items():
+            a[:, int(k[1:])] = v
+        return a
+
+    def put_ball(envs, **kv):
+        for e in envs:
+            orc.set_obj(e, 22, **kv)
+            for f, v in kv.items():
+                getattr(eng, f)[e, 22] = v
+
+    def modes():
+        return [int(v) for v in orc.get('mode')]
+    for _ in range(13):                                    # 6 + FirstHalfOver + 6: 0-0 everywhere
+        both(acts())
+    assert modes() == [GM_PENALTY_ONFIELD] * n
+    seen = set()
+    taker = {1: 10, 2: 21}
+    kicks = {1: 0, 2: 0}
+    for rnd in range(8):
+        for _ in range(12):                                # verdict, PenaltySetup_: until every match is ready for its next kick or over
+            if all(m in (GM_PENALTY_READY, GM_TIME_OVER) for m in modes()):
+                break
+            both(acts()); seen.update(modes())
+        assert all(m in (GM_PENALTY_READY, GM_TIME_OVER) for m in modes()), modes()
+        live = [e for e in range(n) if modes()[e] == GM_PENALTY_READY]
+        if not live:
+            break
+        side = int(orc.get('mode_side')[live[0]])
+        t = (0 if side == 1 else 11) + 10 - kicks[side] % 11
+        kicks[side] += 1
+        g = 11 if side == 1 else 0
+        assert all((int(orc.get('set_play_taker')[e]) & 0xff) - 1 == t for e in live)
+        if rnd % 4 == 1:                                   # nobody kicks: PenaltyMiss_ when pen_ready_wait is over
+            for _ in range(3):
+                both(acts())
+            assert all(modes()[e] == GM_PENALTY_MISS for e in live)
+            continue
+        both(acts(**{f'p{t}': [MCMD_KICK, 100, 0]}))
+        assert all(modes()[e] == GM_PENALTY_TAKEN for e in live)
+        # match 0: a goal; 1: over the side line; 2: in front of the goalie, who catches it; 3: over the goal line beside the goal
+        put_ball([e for e in live if e == 0], x=52.0, y=1.0, vx=2.0, vy=0.0)
+        put_ball([e for e in live if e == 1], x=30.0, y=33.9, vx=0.0, vy=1.0)
+        put_ball([e for e in live if e == 2], x=50.9, y=0.0, vx=0.0, vy=0.0)
+        put_ball([e for e in live if e == 3], x=52.0, y=20.0, vx=2.0, vy=0.0)
+        both(acts(**{f'p{g}': [MCMD_CATCH, 0, 0]}))
+        for e in live:
+            assert modes()[e] == (GM_PENALTY_SCORE if e == 0 else GM_PENALTY_MISS), (rnd, e, modes())
+        seen.update(modes())
+    assert all(m == GM_TIME_OVER for m in modes()) and {GM_PENALTY_SETUP, GM_PENALTY_READY, GM_PENALTY_SCORE, GM_PENALTY_MISS} <= seen
+    w = [int(v) for v in orc.get('set_play_taker')]
+    assert ((w[0] >> 20) & 15) + ((w[0] >> 24) & 15) >= 2 and all(((x >> 20) & 15) == ((x >> 24) & 15) == 0 for x in w[1:])   # match 0 scored, the others never
+    # whole shoot-outs under the in-kernel random policy (takers that kick or do not, goalies that dive): both instantiations see them
+    for general in (False, True):
+        n2 = 24
+        kw2 = dict(half_time_cycles=8, nr_extra_halfs=1, extra_half_cycles=4, pen_before_setup_wait=2, pen_ready_wait=4, pen_taken_wait=15,
+                   pen_nr_kicks=2, pen_max_extra_kicks=2) if general else {}
+        eng, orc = _pair(n2, **kw2)
+        if not general:                                    # the stock rules: clocks moved to the end of the extra time, scores level
+            assert eng.kernel_name().endswith('<stock, stock types>')
+            cyc = (7990 + np.arange(n2) % 8).astype(np.int32)
+            eng.cycle.copy_(torch.as_tensor(cyc, device='cuda:0'))
+            for e in range(n2):
+                orc.set_game(e, cycle=int(cyc[e]))
+        seen = set()
+        for t in range(700 if general else 900):
+            eng.step(None); orc.step(None)
+            if t % 7 == 0 or t < 30:
+                assert_match_same(eng, orc, f'random shoot-out general={general} t={t}')
+            seen.update(int(v) for v in orc.get('mode'))
+        assert_match_same(eng, orc, 'random shoot-out, end')
+        assert {GM_PENALTY_ONFIELD, GM_PENALTY_SETUP, GM_PENALTY_READY, GM_PENALTY_MISS} <= seen
+        assert list(eng.stats.cpu().numpy()) == list(orc.stats())
 
 
 @pytest.mark.parametrize('general', [False, True])

@@ -211,7 +211,7 @@ def test_offside_is_called():
 
 
 def test_half_time_and_time_over():
-    m = fresh(half_time_cycles=20, auto_reset=0, nr_extra_halfs=0)     # (extra time: test_extra_time_after_a_draw)
+    m = fresh(half_time_cycles=20, auto_reset=0, nr_extra_halfs=0, penalty_shoot_outs=0)     # (test_extra_time_after_a_draw, test_penalty_shoot_out)
     play_on(m)
     for _ in range(19):
         m.step(acts(p3=[MCMD_DASH, 100, 0]))
@@ -229,7 +229,7 @@ def test_half_time_and_time_over():
     m.step(acts(p3=[MCMD_DASH, 100, 0]))
     assert m.get('done')[0] == 0 and m.get('vx')[0][3] == 0            # time over: commands ignored
     assert m.get('cycle')[0] == 40 and m.get('stopped_cycle')[0] == 1  # ... and the clock stands
-    m = fresh(half_time_cycles=5, auto_reset=1, nr_extra_halfs=0)
+    m = fresh(half_time_cycles=5, auto_reset=1, nr_extra_halfs=0, penalty_shoot_outs=0)
     for _ in range(11):                                                 # 5 + FirstHalfOver + 5
         m.step(acts())
     assert m.get('done')[0] == 1 and m.get('cycle')[0] == 0 and m.get('mode')[0] == GM_KICK_OFF and m.stats()[3] == 1
@@ -247,7 +247,7 @@ def test_extra_time_after_a_draw():
     of ExtendHalf, a kick-off for the side that started the match, FirstHalfOver between the extra halves, TimeOver after the last
     one whatever the score (no shoot-out); a decided match ends with the normal time.  Rules restated: parity unpinned."""
     from soccer2d_amd._capi_match import GM_EXTEND_HALF, GM_FIRST_HALF_OVER, GM_AFTER_GOAL
-    m = fresh(half_time_cycles=10, extra_half_cycles=6, auto_reset=0)  # stock nr_extra_halfs = 2
+    m = fresh(half_time_cycles=10, extra_half_cycles=6, auto_reset=0, penalty_shoot_outs=0)  # stock nr_extra_halfs = 2; no shoot-out here
     seen = []
     for _ in range(60):
         m.step(acts())
@@ -284,9 +284,96 @@ def test_extra_time_after_a_draw():
     assert m.get('score_left')[0] == 1 and m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1 and m.get('cycle')[0] == 22
 
 
+def _pen_word(m, e=0):
+    w = int(m.get('set_play_taker')[e])
+    return dict(taker=(w & 0xff) - 1, kicks=((w >> 12) & 15, (w >> 16) & 15), goals=((w >> 20) & 15, (w >> 24) & 15))
+
+
+def test_penalty_shoot_out():
+    """ServerParam.penalty_shoot_outs / pen_* (idl/service.proto:1602-1613), GameModeType PenaltySetup_ ... PenaltyOnfield_ (:290-297),
+    PenaltyKickState (:130-138): a draw after the last period goes to the shoot-out -- PenaltyOnfield_, then per kick PenaltySetup_
+    (everybody placed by the referee), PenaltyReady_, PenaltyTaken_ (taker against goalie; nobody else moves), PenaltyScore_ /
+    PenaltyMiss_; the left team first, takers from index 10 downwards, pen_nr_kicks each, decided early when one side cannot catch
+    up, then pairs of extra kicks; the state is in the set-play word.  rcssserver's PenaltyRef restated: parity unpinned."""
+    from soccer2d_amd._capi_match import (GM_PENALTY_MISS, GM_PENALTY_ONFIELD, GM_PENALTY_READY, GM_PENALTY_SCORE, GM_PENALTY_SETUP,
+                                          GM_PENALTY_TAKEN, MCMD_CATCH)
+    kw = dict(half_time_cycles=6, nr_extra_halfs=0, auto_reset=0, pen_before_setup_wait=2, pen_ready_wait=3, pen_taken_wait=30,
+              pen_nr_kicks=2, pen_max_extra_kicks=1)
+
+    def to_ready(m, side, taker):
+        """from the verdict (or PenaltyOnfield_) through PenaltySetup_ to PenaltyReady_"""
+        for _ in range(2):
+            m.step(acts(p3=[MCMD_DASH, 100, 0]))
+        assert m.get('mode')[0] == GM_PENALTY_SETUP and m.get('mode_side')[0] == side and _pen_word(m)['taker'] == taker
+        goalie = 11 if side == LEFT else 0
+        x, y, body = m.get('x')[0], m.get('y')[0], m.get('body')[0]
+        assert (x[22], y[22]) == (10.0, 0.0) and x[taker] == np.float32(10.0 - 0.7) and y[taker] == 0 and body[taker] == 0
+        assert (x[goalie], y[goalie], body[goalie]) == (51.5, 0.0, 180.0)
+        rest = [i for i in range(22) if i not in (taker, goalie)]
+        assert (np.hypot(x[rest], y[rest]) < 9.15).all() and (m.get('vx')[0][:23] == 0).all()
+        m.step(acts(p3=[MCMD_DASH, 100, 0], **{f'p{goalie}': [MCMD_DASH, 100, 0]}))
+        assert m.get('mode')[0] == GM_PENALTY_READY and m.get('vx')[0][3] == 0 and m.get('vx')[0][goalie] == 0   # nobody but the taker acts
+
+    def kick_and(m, taker, ball, expect):
+        m.step(acts(**{f'p{taker}': [MCMD_KICK, 100, 0]}))
+        assert m.get('mode')[0] == GM_PENALTY_TAKEN and m.get('vx')[0][22] > 1.0
+        m.set_obj(0, 22, **ball)
+        m.step(acts(p3=[MCMD_DASH, 100, 0]))
+        assert m.get('mode')[0] == expect and m.get('vx')[0][3] == 0 and m.get('vx')[0][22] == 0
+
+    m = fresh(**kw)
+    for _ in range(13):                                                 # 6 + FirstHalfOver + 6: 0-0
+        m.step(acts())
+    assert m.get('mode')[0] == GM_PENALTY_ONFIELD and m.get('mode_side')[0] == RIGHT and m.get('done')[0] == 0 and m.get('cycle')[0] == 12
+    to_ready(m, LEFT, 10)
+    kick_and(m, 10, dict(x=52.0, y=1.0, vx=2.0, vy=0.0), GM_PENALTY_SCORE)
+    assert _pen_word(m) == dict(taker=10, kicks=(1, 0), goals=(1, 0)) and m.get('reward_left')[0] == 1 and m.get('score_left')[0] == 0
+    to_ready(m, RIGHT, 21)
+    for _ in range(3):                                                  # the taker lets pen_ready_wait pass
+        m.step(acts())
+    assert m.get('mode')[0] == GM_PENALTY_MISS and _pen_word(m)['kicks'] == (1, 1)
+    to_ready(m, LEFT, 9)
+    kick_and(m, 9, dict(x=30.0, y=33.9, vx=0.0, vy=1.0), GM_PENALTY_MISS)             # over the side line
+    to_ready(m, RIGHT, 20)
+    kick_and(m, 20, dict(x=52.4, y=-6.9, vx=1.0, vy=0.0), GM_PENALTY_SCORE)
+    assert _pen_word(m) == dict(taker=20, kicks=(2, 2), goals=(1, 1)) and m.get('reward_left')[0] == -1
+    to_ready(m, LEFT, 8)                                                # 1-1 after the regular kicks: one pair of extra kicks
+    m.step(acts(p8=[MCMD_KICK, 30, 0]))
+    assert m.get('mode')[0] == GM_PENALTY_TAKEN
+    m.set_obj(0, 22, x=50.9, y=0.0, vx=0.0, vy=0.0)                      # in front of the goalie, who catches it
+    m.step(acts(p11=[MCMD_CATCH, 0, 0]))
+    assert m.get('mode')[0] == GM_PENALTY_MISS
+    to_ready(m, RIGHT, 19)
+    m.step(acts(p19=[MCMD_KICK, 100, 0]))
+    for _ in range(31):                                                 # ... and this one runs out of time
+        assert m.get('mode')[0] == GM_PENALTY_TAKEN
+        m.set_obj(0, 22, x=20.0, y=0.0, vx=0.0, vy=0.0)
+        m.step(acts())
+    assert m.get('mode')[0] == GM_PENALTY_MISS and _pen_word(m)['kicks'] == (3, 3) and m.get('cycle')[0] == 12   # the clock stood
+    for _ in range(2):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1 and _pen_word(m)['goals'] == (1, 1)      # used up: the draw stands
+    # decided early: 2-0 after three kicks
+    m = fresh(**kw)
+    for _ in range(13):
+        m.step(acts())
+    to_ready(m, LEFT, 10); kick_and(m, 10, dict(x=52.0, y=0.0, vx=2.0, vy=0.0), GM_PENALTY_SCORE)
+    to_ready(m, RIGHT, 21); kick_and(m, 21, dict(x=52.0, y=20.0, vx=2.0, vy=0.0), GM_PENALTY_MISS)   # over the goal line, beside the goal
+    to_ready(m, LEFT, 9); kick_and(m, 9, dict(x=52.0, y=0.0, vx=2.0, vy=0.0), GM_PENALTY_SCORE)
+    for _ in range(2):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1 and _pen_word(m) == dict(taker=9, kicks=(2, 1), goals=(2, 0))
+    # penalty_shoot_outs = 0: the draw stands at once
+    m = fresh(penalty_shoot_outs=0, **{k: v for k, v in kw.items()})
+    for _ in range(13):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1
+
+
 def test_random_matches_are_deterministic_and_eventful():
     n = 64
-    a, b = fresh(n, half_time_cycles=400, extra_half_cycles=50), fresh(n, half_time_cycles=400, extra_half_cycles=50)
+    kw = dict(half_time_cycles=400, extra_half_cycles=50, pen_before_setup_wait=2, pen_taken_wait=20, pen_nr_kicks=1, pen_max_extra_kicks=1)
+    a, b = fresh(n, **kw), fresh(n, **kw)                  # (short extra halves and a short shoot-out: most random matches are draws)
     for _ in range(1300):                                  # 800 cycles of play + the stopped ones (after goals, offside calls, half time)
         a.step(None); b.step(None)
     for f in MO.OBJ_FIELDS + MO.ENV_FIELDS:
