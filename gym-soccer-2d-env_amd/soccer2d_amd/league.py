@@ -31,7 +31,7 @@ def _wrap(a):
 def _barred(engine, side):
     """bool[N,11]: the player who put the ball into play from the last set play and whom nobody else has touched the ball
     after -- he must not play it again (FreeKickFault_, idl/service.proto:287), so the scripted policies let a team-mate go."""
-    taker = engine.set_play_taker.view(-1, 1).long() - 1 - (0 if side == 1 else 11)       # index inside the team, or out of range
+    taker = (engine.set_play_taker.view(-1, 1).long() & 0xff) - 1 - (0 if side == 1 else 11)   # index inside the team, or out of range (bit 8: the set play was an indirect free kick)
     in_play = (engine.mode == M.GM_PLAY_ON).view(-1, 1)
     return (torch.arange(11, device=engine.device).view(1, 11) == taker) & in_play
 

@@ -207,6 +207,17 @@ class MatchEngine:
               'world_model.last_kick_side': self.last_touch_side,
               'world_model.ball.position.x': self.x[:, M.MATCH_BALL], 'world_model.ball.position.y': self.y[:, M.MATCH_BALL],
               'world_model.ball.velocity.x': self.vx[:, M.MATCH_BALL], 'world_model.ball.velocity.y': self.vy[:, M.MATCH_BALL]}
+        # the penalty shoot-out (WorldModel.is_penalty_kick_mode, PenaltyKickState: idl/service.proto:336, 130-138), decoded from the
+        # set-play word the engine keeps it in (include/s2d_match.h); "our" = the left team
+        pen = (self.mode >= M.GM_PENALTY_SETUP) & (self.mode <= 29)
+        w = torch.where(pen, self.set_play_taker, torch.zeros_like(self.set_play_taker))
+        wm.update({'world_model.is_penalty_kick_mode': pen,
+                   'world_model.penalty_kick_state.on_field_side': torch.where(pen, 2, 0),
+                   'world_model.penalty_kick_state.current_taker_side': torch.where(pen & (self.mode != M.GM_PENALTY_ONFIELD), self.mode_side, 0),
+                   'world_model.penalty_kick_state.our_taker_counter': (w >> 12) & 15,
+                   'world_model.penalty_kick_state.their_taker_counter': (w >> 16) & 15,
+                   'world_model.penalty_kick_state.our_score': (w >> 20) & 15,
+                   'world_model.penalty_kick_state.their_score': (w >> 24) & 15})
         for team, sl in (('teammates', slice(0, 11)), ('opponents', slice(11, P))):
             for f, t in (('position.x', self.x), ('position.y', self.y), ('velocity.x', self.vx), ('velocity.y', self.vy),
                          ('body_direction', self.body), ('stamina', self.stamina), ('is_tackling', self.tackle_cycles)):

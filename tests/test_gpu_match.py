@@ -754,7 +754,13 @@ def test_penalty_shoot_out_on_device():
         for e in live:
             assert modes()[e] == (GM_PENALTY_SCORE if e == 0 else GM_PENALTY_MISS), (rnd, e, modes())
         seen.update(modes())
+        wm = eng.world_model()                             # PenaltyKickState (idl/service.proto:130-138) of the proto's WorldModel
+        assert bool(wm['world_model.is_penalty_kick_mode'][live[0]]) and int(wm['world_model.penalty_kick_state.current_taker_side'][live[0]]) == side
+        assert int(wm['world_model.penalty_kick_state.our_taker_counter'][live[0]]) == kicks[1] and \
+            int(wm['world_model.penalty_kick_state.their_taker_counter'][live[0]]) == kicks[2]
+        assert int(wm['world_model.penalty_kick_state.our_score'][live[0]]) == ((int(orc.get('set_play_taker')[live[0]]) >> 20) & 15)
     assert all(m == GM_TIME_OVER for m in modes()) and {GM_PENALTY_SETUP, GM_PENALTY_READY, GM_PENALTY_SCORE, GM_PENALTY_MISS} <= seen
+    assert not bool(eng.world_model()['world_model.is_penalty_kick_mode'].any())
     w = [int(v) for v in orc.get('set_play_taker')]
     assert ((w[0] >> 20) & 15) + ((w[0] >> 24) & 15) >= 2 and all(((x >> 20) & 15) == ((x >> 24) & 15) == 0 for x in w[1:])   # match 0 scored, the others never
     # whole shoot-outs under the in-kernel random policy (takers that kick or do not, goalies that dive): both instantiations see them
