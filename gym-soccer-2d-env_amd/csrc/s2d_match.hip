@@ -464,19 +464,16 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   bool kicked = false, by_kick = false;                    // by_kick: the impulse came from a Kick command (not a tackle)
   if (!is_player || o.tackle > 0 || mode0 == S2D_GM_TIME_OVER || o.card >= S2D_CARD_RED) cmd = S2D_MCMD_NONE;
   // the shoot-out: the taker acts once the kick is ready, the defending goalie once it is taken, nobody else at all
-  const bool pen = is_penalty(mode0);                      // (uniform per match)
-  int pen_goalie = -1;
-  if (pen) {
-    const int pen_taker = (gr.taker & 0xff) - 1;
-    pen_goalie = side0 == SIDE_LEFT ? S2D_MATCH_GOALIE_RIGHT : S2D_MATCH_GOALIE_LEFT;
-    if (!((l == pen_taker && (mode0 == S2D_GM_PENALTY_READY || mode0 == S2D_GM_PENALTY_TAKEN)) ||
-          (l == pen_goalie && mode0 == S2D_GM_PENALTY_TAKEN))) cmd = S2D_MCMD_NONE;
+  const bool pen_goalie_acts = mode0 == S2D_GM_PENALTY_TAKEN && l == (side0 == SIDE_LEFT ? S2D_MATCH_GOALIE_RIGHT : S2D_MATCH_GOALIE_LEFT);
+  if (is_penalty(mode0)) {                                 // (uniform per match)
+    const bool taker_acts = l == (gr.taker & 0xff) - 1 && (mode0 == S2D_GM_PENALTY_READY || mode0 == S2D_GM_PENALTY_TAKEN);
+    if (!(taker_acts || pen_goalie_acts)) cmd = S2D_MCMD_NONE;
   }
   // one noise block per object and cycle: x, y = movement noise; z, w = the command's own noise (a player sends ONE body
   // command per cycle: Turn uses z, Kick uses z and w)
   U4 nz{0, 0, 0, 0};
   if (p.noise) nz = m_draw(p, gl, gh, cyc, S2D_ST_NOISE, (uint32_t)l);
-  const bool may_touch = !is_setplay(mode0) || (side_of(l) == side0 && !ball_dead(mode0)) || (mode0 == S2D_GM_PENALTY_TAKEN && l == pen_goalie);   // announcements, after a goal, before the kick-off: the ball is dead
+  const bool may_touch = !is_setplay(mode0) || (side_of(l) == side0 && !ball_dead(mode0)) || pen_goalie_acts;   // announcements, after a goal, before the kick-off: the ball is dead
   bool foul_try = false, foul_seen_l = false;              // this lane's intentional tackle succeeded; the referee would see a foul of his
   bool caught = false, hold_moved = false;
   if (cmd == S2D_MCMD_DASH) m_dash(p, pt, l, o, a, bb, ax, ay);
@@ -587,8 +584,16 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
     const uint32_t kmask = hballot(kicked, half) & 0x3FFFFFu;
     any_kick = kmask != 0u;
     last_kicker = any_kick ? 31 - __clz(kmask) : -1;
-    for (int j = 0; j < NP; ++j) {
-      float kxj = hbcast(kx, j), kyj = hbcast(ky, j);
+    // the impulses in player order, kickers only: the union of the two matches' kicker masks is wave-uniform, so each kicker's
+    // (kx, ky) comes through v_readlane (the lane number in an SGPR) instead of 44 ds_bpermute per cycle with a kick in it
+    const unsigned long long kfull = __ballot(kicked);
+    uint32_t um = ((uint32_t)kfull | (uint32_t)(kfull >> kHalf)) & 0x3FFFFFu;
+    while (um != 0u) {
+      const int j = __ffs((int)um) - 1;
+      um &= um - 1u;
+      const int xl = __builtin_amdgcn_readlane(__float_as_int(kx), j), xh = __builtin_amdgcn_readlane(__float_as_int(kx), j + kHalf);
+      const int yl = __builtin_amdgcn_readlane(__float_as_int(ky), j), yh = __builtin_amdgcn_readlane(__float_as_int(ky), j + kHalf);
+      const float kxj = __int_as_float(half ? xh : xl), kyj = __int_as_float(half ? yh : yl);
       if ((kmask >> j) & 1u) { bax += kxj; bay += kyj; }
     }
     if (any_kick) g.last_touch = side_of(last_kicker);
