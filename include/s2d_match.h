@@ -40,7 +40,9 @@ enum { S2D_MCMD_NONE = 0, S2D_MCMD_DASH = 1, S2D_MCMD_TURN = 2, S2D_MCMD_KICK = 
  * that half's penalty spot) the side that takes it; for the ANNOUNCEMENTS (AfterGoal_, OffSide_, BackPass_,
  * FreeKickFault_, CatchFault_, FoulCharge_: rcssserver's goal_l, offside_l, back_pass_l, ...) the side the call is named after --
  * the scorer, the offender.  An announcement is a dead ball with the clock stopped; after announce_wait (after_goal_wait) cycles
- * the referee turns it into the restart for the other side. */
+ * the referee turns it into the restart for the other side.  FirstHalfOver / ExtendHalf: one stopped cycle at the end of a half /
+ * of a drawn normal time (side = who kicks off next).  The shoot-out's modes: side = the team of the current taker
+ * (PenaltyOnfield_: the half the kicks are taken in). */
 enum {
   S2D_GM_BEFORE_KICK_OFF = 0, S2D_GM_TIME_OVER = 1, S2D_GM_PLAY_ON = 2, S2D_GM_KICK_OFF = 3, S2D_GM_KICK_IN = 4,
   S2D_GM_FREE_KICK = 5, S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_AFTER_GOAL = 8, S2D_GM_OFF_SIDE = 9,
