@@ -91,7 +91,9 @@ def encode_ball(b):
 
 def encode_world_model(wm):
     """wm: dict(our_side, self, ball, teammates[list], opponents[list], cycle, game_mode_type,
-    left_team_score, right_team_score, stoped_cycle, our_team_score, their_team_score, game_mode_side)."""
+    left_team_score, right_team_score, stoped_cycle, our_team_score, their_team_score, game_mode_side, is_penalty_kick_mode,
+    penalty_kick_state = dict(on_field_side, current_taker_side, our_taker_counter, their_taker_counter, our_score, their_score,
+    is_kick_taker))."""
     out = _int(4, wm.get('our_side', 0))
     if wm.get('self') is not None:
         out += _msg(6, encode_self(wm['self']))
@@ -104,7 +106,13 @@ def encode_world_model(wm):
     out += (_int(21, wm.get('cycle', 0)) + _int(22, wm.get('game_mode_type', 0)) + _int(23, wm.get('left_team_score', 0))
             + _int(24, wm.get('right_team_score', 0)) + _int(27, wm.get('stoped_cycle', 0))
             + _int(28, wm.get('our_team_score', 0)) + _int(29, wm.get('their_team_score', 0))
-            + _int(42, wm.get('game_mode_side', 0)))
+            + _int(30, 1 if wm.get('is_penalty_kick_mode') else 0))
+    pk = wm.get('penalty_kick_state')
+    if pk is not None:                                     # PenaltyKickState (idl/service.proto:130-138; WorldModel field 38)
+        out += _msg(38, _int(1, pk.get('on_field_side', 0)) + _int(2, pk.get('current_taker_side', 0))
+                    + _int(3, pk.get('our_taker_counter', 0)) + _int(4, pk.get('their_taker_counter', 0))
+                    + _int(5, pk.get('our_score', 0)) + _int(6, pk.get('their_score', 0)) + _int(7, 1 if pk.get('is_kick_taker') else 0))
+    out += _int(42, wm.get('game_mode_side', 0))
     return out
 
 
@@ -258,7 +266,17 @@ def match_state_bytes(engine, index, player):
     me = dict(pl(player), stamina=st[player], effort=ef[player], recovery=rc[player], stamina_capacity=cp[player])
     ball = dict(x=x[22], y=y[22], vx=vx[22], vy=vy[22], rel_x=x[22] - x[player], rel_y=y[22] - y[player])
     sl, sr = int(engine.score_left[index]), int(engine.score_right[index])
-    return encode_state(dict(our_side=1 if left else 2, self=me, ball=ball,
+    mode, side, w = int(engine.mode[index]), int(engine.mode_side[index]), int(engine.set_play_taker[index])
+    pen = 22 <= mode <= 29                                 # the shoot-out: its state is in the set-play word (include/s2d_match.h)
+    pk = None
+    if pen:
+        kicks, goals = ((w >> 12) & 15, (w >> 16) & 15), ((w >> 20) & 15, (w >> 24) & 15)
+        mine_i = 0 if left else 1
+        pk = dict(on_field_side=2, current_taker_side=0 if mode == 28 else side, our_taker_counter=kicks[mine_i],
+                  their_taker_counter=kicks[1 - mine_i], our_score=goals[mine_i], their_score=goals[1 - mine_i],
+                  is_kick_taker=mode != 28 and (w & 0xff) - 1 == player)
+    return encode_state(dict(our_side=1 if left else 2, self=me, ball=ball, is_penalty_kick_mode=pen, penalty_kick_state=pk,
+                             stoped_cycle=int(engine.stopped_cycle[index]),
                              teammates=[pl(i) for i in mine if i != player], opponents=[pl(i) for i in theirs],
                              cycle=int(engine.cycle[index]), game_mode_type=int(engine.mode[index]),
                              game_mode_side=int(engine.mode_side[index]), left_team_score=sl, right_team_score=sr,

@@ -759,6 +759,10 @@ def test_penalty_shoot_out_on_device():
         assert int(wm['world_model.penalty_kick_state.our_taker_counter'][live[0]]) == kicks[1] and \
             int(wm['world_model.penalty_kick_state.their_taker_counter'][live[0]]) == kicks[2]
         assert int(wm['world_model.penalty_kick_state.our_score'][live[0]]) == ((int(orc.get('set_play_taker')[live[0]]) >> 20) & 15)
+        from soccer2d_amd import wire                      # ... and on the wire, seen by the taker (is_kick_taker) and by an opponent
+        sb = dict((f, v) for f, _w, v in wire.decode(dict((f, v) for f, _w, v in wire.decode(wire.match_state_bytes(eng, live[0], t)))[2]))
+        pk = dict((f, v) for f, _w, v in wire.decode(sb[38]))
+        assert sb[30] == 1 and pk[1] == 2 and pk[2] == side and pk.get(7) == 1 and pk.get(3, 0) == kicks[side] and pk.get(4, 0) == kicks[3 - side]
     assert all(m == GM_TIME_OVER for m in modes()) and {GM_PENALTY_SETUP, GM_PENALTY_READY, GM_PENALTY_SCORE, GM_PENALTY_MISS} <= seen
     assert not bool(eng.world_model()['world_model.is_penalty_kick_mode'].any())
     w = [int(v) for v in orc.get('set_play_taker')]

@@ -53,6 +53,19 @@ def test_proto3_zero_fields_are_omitted_and_negative_ints_roundtrip():
     assert wire.decode(wire.decode(s)[0][2])[0][0] == 6
 
 
+def test_penalty_kick_state_on_the_wire():
+    """WorldModel.is_penalty_kick_mode (field 30) and .penalty_kick_state (38; idl/service.proto:130-138, 336, 344): proto3 wire
+    bytes, fields in number order, zero members omitted (no reference fixture holds these fields: checked with the decoder)."""
+    b = wire.encode_world_model(dict(cycle=8000, game_mode_type=24, game_mode_side=1, is_penalty_kick_mode=True,
+                                     penalty_kick_state=dict(on_field_side=2, current_taker_side=1, our_taker_counter=3, their_taker_counter=2,
+                                                             our_score=2, their_score=0, is_kick_taker=True)))
+    f = wire.decode(b)
+    assert [x[0] for x in f] == [21, 22, 30, 38, 42] and dict((x[0], x[2]) for x in f)[30] == 1
+    pk = dict((x[0], x[2]) for x in wire.decode(dict((x[0], x[2]) for x in f)[38]))
+    assert pk == {1: 2, 2: 1, 3: 3, 4: 2, 5: 2, 7: 1}                    # their_score = 0 is not on the wire
+    assert 30 not in [x[0] for x in wire.decode(wire.encode_world_model(dict(cycle=5, game_mode_type=2)))]
+
+
 def test_rcg_round_trip(tmp_path):
     path = tmp_path / 'm.rcg'
     rs = np.random.RandomState(0)
