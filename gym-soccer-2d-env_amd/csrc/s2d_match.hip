@@ -87,27 +87,29 @@ typedef float PTab[kHalf];   // one row of the per-slot table
 #ifndef S2D_STOCK_EXTRA_HALFS
 #define S2D_STOCK_EXTRA_HALFS 2   // rcssserver's nr_extra_halfs
 #endif
-struct MStock {
-  static constexpr float half_l = (float)52.5, half_w = (float)34.0, ball_size = (float)0.085, player_rand = (float)0.1, ball_rand = (float)0.05;
-  static constexpr float player_accel_max = (float)1.0, player_accel_max2 = player_accel_max * player_accel_max;
-  static constexpr float ball_speed_max = (float)3.0, ball_speed_max2 = ball_speed_max * ball_speed_max;
-  static constexpr float ball_accel_max = (float)2.7, ball_accel_max2 = ball_accel_max * ball_accel_max;
-  static constexpr float stamina_max = (float)8000.0, stamina_capacity = (float)130600.0;
-  static constexpr float recover_init = (float)1.0, recover_dec_thr_value = (float)(0.3 * 8000.0), recover_min = (float)0.5, recover_dec = (float)0.002;
-  static constexpr float effort_dec_thr_value = (float)(0.3 * 8000.0), effort_dec = (float)0.005;
-  static constexpr float effort_inc_thr_value = (float)(0.6 * 8000.0), effort_inc = (float)0.01;
-  static constexpr float max_dash_power = (float)100.0, min_dash_power = (float)0.0, max_dash_angle = (float)180.0, min_dash_angle = (float)-180.0;
-  static constexpr float dash_angle_step = (float)1.0, inv_dash_angle_step = (float)(1.0 / 1.0);
-  static constexpr float side_dash_rate = (float)0.4, back_dash_rate = (float)0.6, max_moment = (float)180.0, min_moment = (float)-180.0;
-  static constexpr float collision_vel_rate = (float)-0.1;
-  static constexpr float max_power = (float)100.0, min_power = (float)-100.0, inv_max_power = (float)(1.0 / 100.0);
-  static constexpr float tackle_dist = (float)2.0, tackle_back_dist = (float)0.0, tackle_width = (float)1.25, tackle_power_rate = (float)0.027;
-  static constexpr float max_tackle_power = (float)100.0, max_back_tackle_power = (float)0.0;
-  static constexpr float tackle_reach2 = (float)(1.01 * (2.0 * 2.0 + 1.25 * 1.25));
-  static constexpr float goal_half_width = (float)(14.02 * 0.5), offside_area2 = (float)(2.5 * 2.5), free_kick_distance = (float)9.15;
-  static constexpr float inv_speed_decay = (float)(1.0 / (3.0 * 0.94));
-  static constexpr float catch_half_w = (float)(1.0 * 0.5), catch_probability = (float)1.0, max_catch_angle = (float)90.0, min_catch_angle = (float)-90.0;
+#define M_STOCK_PHYSICS \
+  static constexpr float half_l = (float)52.5, half_w = (float)34.0, ball_size = (float)0.085, player_rand = (float)0.1, ball_rand = (float)0.05; \
+  static constexpr float player_accel_max = (float)1.0, player_accel_max2 = player_accel_max * player_accel_max; \
+  static constexpr float ball_speed_max = (float)3.0, ball_speed_max2 = ball_speed_max * ball_speed_max; \
+  static constexpr float ball_accel_max = (float)2.7, ball_accel_max2 = ball_accel_max * ball_accel_max; \
+  static constexpr float stamina_max = (float)8000.0, stamina_capacity = (float)130600.0; \
+  static constexpr float recover_init = (float)1.0, recover_dec_thr_value = (float)(0.3 * 8000.0), recover_min = (float)0.5, recover_dec = (float)0.002; \
+  static constexpr float effort_dec_thr_value = (float)(0.3 * 8000.0), effort_dec = (float)0.005; \
+  static constexpr float effort_inc_thr_value = (float)(0.6 * 8000.0), effort_inc = (float)0.01; \
+  static constexpr float max_dash_power = (float)100.0, min_dash_power = (float)0.0, max_dash_angle = (float)180.0, min_dash_angle = (float)-180.0; \
+  static constexpr float dash_angle_step = (float)1.0, inv_dash_angle_step = (float)(1.0 / 1.0); \
+  static constexpr float side_dash_rate = (float)0.4, back_dash_rate = (float)0.6, max_moment = (float)180.0, min_moment = (float)-180.0; \
+  static constexpr float collision_vel_rate = (float)-0.1; \
+  static constexpr float max_power = (float)100.0, min_power = (float)-100.0, inv_max_power = (float)(1.0 / 100.0); \
+  static constexpr float tackle_dist = (float)2.0, tackle_back_dist = (float)0.0, tackle_width = (float)1.25, tackle_power_rate = (float)0.027; \
+  static constexpr float max_tackle_power = (float)100.0, max_back_tackle_power = (float)0.0; \
+  static constexpr float tackle_reach2 = (float)(1.01 * (2.0 * 2.0 + 1.25 * 1.25)); \
+  static constexpr float goal_half_width = (float)(14.02 * 0.5), offside_area2 = (float)(2.5 * 2.5), free_kick_distance = (float)9.15; \
+  static constexpr float inv_speed_decay = (float)(1.0 / (3.0 * 0.94)); \
+  static constexpr float catch_half_w = (float)(1.0 * 0.5), catch_probability = (float)1.0, max_catch_angle = (float)90.0, min_catch_angle = (float)-90.0; \
   static constexpr float pen_x = (float)(52.5 - 16.5), pen_half_w = (float)20.16;
+struct MStock {
+  M_STOCK_PHYSICS
   static constexpr int tackle_cycles = 10, half_time_cycles = 3000, nr_normal_halfs = 2, drop_ball_time = 100, use_offside = 1, catch_ban_cycle = 5;
   static constexpr int goalie_max_moves = 2, after_goal_wait = 50, kick_off_wait = 0, back_passes = 1, free_kick_faults = 1;
   static constexpr int stopped_clock = 1, announce_wait = 30, foul_cycles = 5;
@@ -119,6 +121,25 @@ struct MStock {
   int auto_reset, noise;
   int penalty_shoot_outs;   // per engine like the two above: an engine that differs from the stock rules only in this word keeps this kernel
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
+};
+// The same physics and rules with the SCHEDULE of the match -- how long things last, how many there are of them -- as per-engine
+// words: a learner's engine with short halves, no extra time or other waits differs from the stock configuration in these words
+// only and would otherwise run the general instantiation (1.79 G against 2.00 G, profiles/r04/match_schedule_words.txt).  They sit in
+// tests of rare branches and in one compare per cycle -- scalar registers -- but cost the fully constant kernel 2-6 %, so both exist.
+#define M_SCHEDULE_INTS(X) X(penalty_shoot_outs) X(half_time_cycles) X(nr_normal_halfs) X(drop_ball_time) X(after_goal_wait) X(kick_off_wait) \
+  X(announce_wait) X(nr_extra_halfs) X(extra_half_cycles) X(golden_goal) X(total_cycles) X(end_cycles) X(pen_before_setup_wait) \
+  X(pen_ready_wait) X(pen_taken_wait) X(pen_nr_kicks) X(pen_max_extra_kicks)
+struct MStockSched {
+  M_STOCK_PHYSICS
+  static constexpr int tackle_cycles = 10, use_offside = 1, catch_ban_cycle = 5, goalie_max_moves = 2, back_passes = 1, free_kick_faults = 1;
+  static constexpr int stopped_clock = 1, foul_cycles = 5;
+  static constexpr float foul_detect_probability = (float)0.5;
+  static constexpr float pen_spot_x = (float)(52.5 - 42.5);
+  int auto_reset, noise;
+  uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
+#define X(name) int name;
+  M_SCHEDULE_INTS(X)
+#undef X
 };
 #define M_CONFIG_FLOATS(X) X(half_l) X(half_w) X(ball_size) X(player_rand) X(ball_rand) X(player_accel_max) X(player_accel_max2) \
   X(ball_speed_max) X(ball_speed_max2) X(ball_accel_max) X(ball_accel_max2) X(stamina_max) X(stamina_capacity) X(recover_init) \
@@ -1223,7 +1244,8 @@ S2D_DEV void match_rollout_body(const P& p, const TY& pt, const MShared& sh, con
 
 // STOCK: the configuration words are MStock's constants (m_is_stock() said they equal this engine's); else they are read from LDS.
 // STOCK_TYPES (with STOCK): all 22 players of the stock PlayerType, the table's entries are constants too.
-template <bool STOCK, bool STOCK_TYPES>
+// SCHED (with STOCK and STOCK_TYPES): the schedule words are the engine's own (MStockSched).
+template <bool STOCK, bool STOCK_TYPES, bool SCHED = false>
 __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p_arg, MPtrs q, int64_t n, int n_steps,
                                                                      const float* __restrict__ actions, MRoll ro) {
   __shared__ float4 pos_tile[kEnvsPerBlock][kTileSlots];
@@ -1239,7 +1261,15 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
   if constexpr (!STOCK_TYPES)
     for (int k = threadIdx.x; k < PT_WORDS * kHalf; k += kMBlock) (&pt[0][0])[k] = q.ptab[k];
   if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0u;
-  if constexpr (STOCK) {
+  static_assert(!SCHED || (STOCK && STOCK_TYPES), "the engine's own schedule comes with constant rules and types");
+  if constexpr (SCHED) {
+    __syncthreads();
+#define X(name) , p_arg.name
+    const MStockSched p{p_arg.auto_reset, p_arg.noise, p_arg.seed_lo, p_arg.seed_hi, p_arg.gid_lo, p_arg.gid_hi M_SCHEDULE_INTS(X)};
+#undef X
+    const MStockTypes types{__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q.ptab[PT_KICKABLE_AREA2 * kHalf])))};
+    match_rollout_body(p, types, sh, q, n, n_steps, actions, ro);
+  } else if constexpr (STOCK) {
     __syncthreads();
     const MStock p{p_arg.auto_reset, p_arg.noise, p_arg.penalty_shoot_outs, p_arg.seed_lo, p_arg.seed_hi, p_arg.gid_lo, p_arg.gid_hi};
     if constexpr (STOCK_TYPES) {
@@ -1294,6 +1324,7 @@ struct S2DMatchEngine {
   S2DMatchConfig cfg; MParams mp; float ptab[PT_WORDS][kHalf]; int64_t n, stride; int device;
   bool stock = false;                                  // mp's configuration words equal MStock: launches use the constant-folded kernels
   bool stock_types = false;                            // ... and every player is of the stock PlayerType (ptab's entries equal MStockTypes)
+  bool stock_sched = false;                            // stock rules, physics and types, the engine's own schedule (MStockSched)
   char* arena; size_t arena_bytes; bool owns_arena;
   S2DMatchBuffers buf; MPtrs ptrs;
 };
@@ -1553,6 +1584,19 @@ static bool m_is_stock(const MParams& p) {
   return ok;
 }
 
+// ... all of them but the schedule words (MStockSched keeps those as variables)
+static bool m_rules_are_stock(const MParams& p) {
+  auto same = [](float a, float b) { return std::memcmp(&a, &b, sizeof a) == 0; };
+  bool ok = true;
+#define X(name) ok = ok && same(p.name, (float)MStockSched::name);
+  M_CONFIG_FLOATS(X)
+#undef X
+  return ok && p.tackle_cycles == MStockSched::tackle_cycles && p.use_offside == MStockSched::use_offside &&
+         p.catch_ban_cycle == MStockSched::catch_ban_cycle && p.goalie_max_moves == MStockSched::goalie_max_moves &&
+         p.back_passes == MStockSched::back_passes && p.free_kick_faults == MStockSched::free_kick_faults &&
+         p.stopped_clock == MStockSched::stopped_clock && p.foul_cycles == MStockSched::foul_cycles;
+}
+
 static bool m_types_are_stock(const float (*t)[kHalf]) {
   auto same = [](float a, float b) { return std::memcmp(&a, &b, sizeof a) == 0; };
   bool ok = same(t[PT_SIZE][BALL], MStock::ball_size) && same(t[PT_DECAY][BALL], MStockTypes::ball_decay);
@@ -1611,6 +1655,7 @@ S2D_API int s2d_match_create(const S2DMatchConfig* cfg, int64_t n_envs, int devi
     const char* general = std::getenv("S2D_MATCH_GENERAL_KERNEL");
     h->stock = m_is_stock(h->mp) && !(general && general[0] == '1');
     h->stock_types = h->stock && m_types_are_stock(h->ptab);
+    h->stock_sched = !h->stock && m_rules_are_stock(h->mp) && m_types_are_stock(h->ptab) && !(general && general[0] == '1');
   }
   if (arena_dev) {
     if (arena_bytes < L.total) { delete h; return mfail(S2D_ENOMEM, "arena smaller than s2d_match_arena_bytes()"); }
@@ -1691,7 +1736,10 @@ static int m_launch(S2DMatchHandle h, int n_steps, const float* actions, const S
   MRoll ro{nullptr, nullptr, nullptr, nullptr};
   if (out) ro = MRoll{out->obs, out->reward, out->mode, out->done};
   MDeviceGuard guard(h->device);
-  if (h->stock_types)
+  if (h->stock_sched)
+    hipLaunchKernelGGL((s2d_match_rollout_kernel<true, true, true>), dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
+                       h->ptrs, h->n, n_steps, actions, ro);
+  else if (h->stock_types)
     hipLaunchKernelGGL((s2d_match_rollout_kernel<true, true>), dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
                        h->ptrs, h->n, n_steps, actions, ro);
   else if (h->stock)
@@ -1705,6 +1753,7 @@ static int m_launch(S2DMatchHandle h, int n_steps, const float* actions, const S
 }
 S2D_API const char* s2d_match_kernel_name(S2DMatchHandle h) {
   if (!h) return "";
+  if (h->stock_sched) return "s2d_match_rollout_kernel<stock rules, own schedule>";
   return h->stock_types ? "s2d_match_rollout_kernel<stock, stock types>" : h->stock ? "s2d_match_rollout_kernel<stock>" : "s2d_match_rollout_kernel<general>";
 }
 S2D_API int s2d_match_relative(S2DMatchHandle h, float* dist_dev, float* angle_dev, void* stream) {

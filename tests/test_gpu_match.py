@@ -679,13 +679,18 @@ def test_extra_time_on_device(golden):
     assert all(((32, GM_TIME_OVER) in seen[e]) == (not golden) for e in (1, 2))
 
 
-def test_shoot_out_switch_keeps_the_stock_kernel():
-    """penalty_shoot_outs is a per-engine word of the stock instantiation (like auto_reset and noise): switching it off does not send an
-    engine to the general kernel; any other rule word does."""
+def test_schedule_words_keep_the_stock_kernel():
+    """penalty_shoot_outs is a per-engine word of the fully constant instantiation (like auto_reset and noise).  An engine that differs
+    from the stock configuration in its SCHEDULE only (lengths of halves and waits, numbers of halves and kicks) -- a learner's short
+    match -- runs the instantiation with the stock rules, physics and types as constants and the schedule as per-engine words; a
+    physics or rule word sends an engine to the general one."""
     from soccer2d_amd.match import MatchEngine
     assert MatchEngine(8, 'cuda:0', penalty_shoot_outs=0).kernel_name().endswith('<stock, stock types>')
-    assert MatchEngine(8, 'cuda:0', pen_taken_wait=100).kernel_name().endswith('<general>')
-    assert MatchEngine(8, 'cuda:0', nr_extra_halfs=0).kernel_name().endswith('<general>')
+    assert MatchEngine(8, 'cuda:0', half_time_cycles=300, nr_extra_halfs=0, pen_taken_wait=100, after_goal_wait=5, kick_off_wait=3,
+                       drop_ball_time=50, announce_wait=10).kernel_name().endswith('<stock rules, own schedule>')
+    assert MatchEngine(8, 'cuda:0', half_time_cycles=300, hetero_seed=3, player_type_id=[i % 18 for i in range(22)]).kernel_name().endswith('<general>')
+    assert MatchEngine(8, 'cuda:0', tackle_cycles=8).kernel_name().endswith('<general>')
+    assert MatchEngine(8, 'cuda:0', use_offside=0).kernel_name().endswith('<general>')
 
 
 def test_penalty_shoot_out_on_device():
@@ -800,11 +805,10 @@ def test_long_rollout_with_fouls_and_catches(general, monkeypatch):
     if general:
         monkeypatch.setenv('S2D_MATCH_GENERAL_KERNEL', '1')
     n, T, chunks = 512, 64, 6
+    # half time falls inside the run: with the general kernel forced, and through the instantiation with the stock rules and the
+    # engine's own schedule (a changed half time selects it)
     eng, orc = _pair(n, half_time_cycles=150)
-    assert eng.kernel_name().endswith('<general>')         # (a changed half time selects the general instantiation anyway)
-    if not general:
-        eng, orc = _pair(n)
-        assert eng.kernel_name().endswith('<stock, stock types>')
+    assert eng.kernel_name().endswith('<general>' if general else '<stock rules, own schedule>')
     rs = np.random.RandomState(21)
     seen_modes = set()
 
@@ -862,8 +866,26 @@ def test_stock_and_general_kernels_agree(monkeypatch):
         assert torch.equal(getattr(a, f), getattr(b, f)), f
     assert torch.equal(a.stats, b.stats)
     # a changed rule word selects the general kernel by itself
-    c = MatchEngine(8, 'cuda:0', cfg=make_match_config(half_time_cycles=100))
+    c = MatchEngine(8, 'cuda:0', cfg=make_match_config(use_offside=0))
     assert c.kernel_name().endswith('<general>')
+    # ... and a changed schedule the instantiation that keeps it in per-engine words: the same against the general kernel, through
+    # half times, extra time and shoot-outs
+    kw = dict(noise=True, half_time_cycles=40, extra_half_cycles=10, after_goal_wait=5, pen_before_setup_wait=2, pen_ready_wait=3,
+              pen_taken_wait=12, pen_nr_kicks=2, pen_max_extra_kicks=1)
+    a = MatchEngine(512, 'cuda:0', cfg=make_match_config(**kw))
+    monkeypatch.setenv('S2D_MATCH_GENERAL_KERNEL', '1')
+    b = MatchEngine(512, 'cuda:0', cfg=make_match_config(**kw))
+    monkeypatch.delenv('S2D_MATCH_GENERAL_KERNEL')
+    assert a.kernel_name().endswith('<stock rules, own schedule>') and b.kernel_name().endswith('<general>')
+    modes = set()
+    for k in range(5):
+        ra, rb = a.rollout(T), b.rollout(T)
+        torch.cuda.synchronize()
+        assert torch.equal(ra['obs'].view(torch.int32), rb['obs'].view(torch.int32)) and torch.equal(ra['mode'], rb['mode'])
+        modes.update(int(v) for v in ra['mode'].unique())
+    for f in MO.OBJ_FIELDS + ('catch_ban', 'card') + MO.ENV_FIELDS + ('ball_holder', 'goalie_moves', 'set_play_taker', 'last_kicker', 'stopped_cycle', 'tick'):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    assert torch.equal(a.stats, b.stats) and {11, 31, 22, 23, 25} <= modes      # FirstHalfOver, ExtendHalf, PenaltySetup_ / Ready_ / Miss_
 
 
 @pytest.mark.parametrize('stock', [True, False])
