@@ -70,6 +70,7 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
   int stopped_clock, announce_wait, foul_cycles; float foul_detect_probability;
   int nr_extra_halfs, extra_half_cycles, golden_goal;
   int penalty_shoot_outs, pen_before_setup_wait, pen_ready_wait, pen_taken_wait, pen_nr_kicks, pen_max_extra_kicks; float pen_spot_x;
+  int illegal_defense_number, illegal_defense_duration; float ill_x, ill_half_w;   // the strip: beyond ill_x on the own side, |y| < ill_half_w
   int total_cycles, end_cycles;   // derived: end of the normal time, end of the last period (= total_cycles without extra halves)
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
@@ -117,11 +118,18 @@ struct MStock {
   static constexpr int nr_extra_halfs = S2D_STOCK_EXTRA_HALFS, extra_half_cycles = 1000, golden_goal = 0;
   static constexpr int pen_before_setup_wait = 10, pen_ready_wait = 10, pen_taken_wait = 150, pen_nr_kicks = 5, pen_max_extra_kicks = 5;
   static constexpr float pen_spot_x = (float)(52.5 - 42.5);
+  static constexpr int illegal_defense_number = 0, illegal_defense_duration = 20;   // (off, as in the stock server: the rule's code folds away)
+  static constexpr float ill_x = (float)(52.5 - 16.5), ill_half_w = (float)(40.32 * 0.5);
   static constexpr int total_cycles = half_time_cycles * nr_normal_halfs, end_cycles = total_cycles + extra_half_cycles * nr_extra_halfs;
   int auto_reset, noise;
   int penalty_shoot_outs;   // per engine like the two above: an engine that differs from the stock rules only in this word keeps this kernel
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
 };
+// The general parameter block with the IllegalDefense_ rule compiled out (number = 0: the stock server's setting and nearly every
+// engine's): read through this type, `p.illegal_defense_number` is the constant below and the rule's per-cycle count folds away (as a
+// run-time test on an LDS word in front of the quick exit it cost the general kernel 4 %).  Same layout as MParams: no data members.
+struct MParamsNoIll : MParams { static constexpr int illegal_defense_number = 0; };
+static_assert(sizeof(MParamsNoIll) == sizeof(MParams), "MParamsNoIll adds no data");
 // The same physics and rules with the SCHEDULE of the match -- how long things last, how many there are of them -- as per-engine
 // words: a learner's engine with short halves, no extra time or other waits differs from the stock configuration in these words
 // only and would otherwise run the general instantiation (1.79 G against 2.00 G, profiles/r04/match_schedule_words.txt).  They sit in
@@ -135,6 +143,8 @@ struct MStockSched {
   static constexpr int stopped_clock = 1, foul_cycles = 5;
   static constexpr float foul_detect_probability = (float)0.5;
   static constexpr float pen_spot_x = (float)(52.5 - 42.5);
+  static constexpr int illegal_defense_number = 0, illegal_defense_duration = 20;   // (off, as in the stock server: the rule's code folds away)
+  static constexpr float ill_x = (float)(52.5 - 16.5), ill_half_w = (float)(40.32 * 0.5);
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
 #define X(name) int name;
@@ -148,13 +158,13 @@ struct MStockSched {
   X(back_dash_rate) X(max_moment) X(min_moment) X(collision_vel_rate) X(max_power) X(min_power) X(inv_max_power) X(tackle_dist) \
   X(tackle_back_dist) X(tackle_width) X(tackle_power_rate) X(max_tackle_power) X(max_back_tackle_power) X(tackle_reach2) \
   X(goal_half_width) X(offside_area2) X(free_kick_distance) X(inv_speed_decay) X(catch_half_w) X(catch_probability) \
-  X(max_catch_angle) X(min_catch_angle) X(pen_x) X(pen_half_w) X(foul_detect_probability) X(pen_spot_x)
+  X(max_catch_angle) X(min_catch_angle) X(pen_x) X(pen_half_w) X(foul_detect_probability) X(pen_spot_x) X(ill_x) X(ill_half_w)
 #define M_CONFIG_INTS(X) X(tackle_cycles) X(half_time_cycles) X(nr_normal_halfs) X(drop_ball_time) X(use_offside) X(catch_ban_cycle) \
   X(goalie_max_moves) X(after_goal_wait) X(kick_off_wait) X(back_passes) X(free_kick_faults) X(stopped_clock) X(announce_wait) X(foul_cycles) \
   X(nr_extra_halfs) X(extra_half_cycles) X(golden_goal) X(total_cycles) X(end_cycles) X(pen_before_setup_wait) \
-  X(pen_ready_wait) X(pen_taken_wait) X(pen_nr_kicks) X(pen_max_extra_kicks)
+  X(pen_ready_wait) X(pen_taken_wait) X(pen_nr_kicks) X(pen_max_extra_kicks) X(illegal_defense_number) X(illegal_defense_duration)
 // every configuration word of MParams is in one of the two lists (the remaining seven are the per-engine words)
-static_assert(sizeof(MParams) == 4 * (54 + 24 + 7), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
+static_assert(sizeof(MParams) == 4 * (56 + 26 + 7), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
 
 // The per-slot table of an engine whose 22 players are all of the stock PlayerType (the default: s2d_match_default_config), with the
 // same spelling as the LDS table -- types[ROW][lane] -- but every entry an immediate: a cycle reads about ten of them per lane, each
@@ -230,7 +240,7 @@ S2D_DEV bool is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D
 // Mode classes as bit masks over GameModeType (every value used is < 32): one shift + and instead of a chain of compares.
 // announcements: a dead ball named after the offending side; after announce_wait cycles the referee awards the restart
 constexpr uint32_t kAnnounceModes = (1u << S2D_GM_OFF_SIDE) | (1u << S2D_GM_BACK_PASS) | (1u << S2D_GM_FREE_KICK_FAULT) |
-                                    (1u << S2D_GM_CATCH_FAULT) | (1u << S2D_GM_FOUL_CHARGE);
+                                    (1u << S2D_GM_CATCH_FAULT) | (1u << S2D_GM_FOUL_CHARGE) | (1u << S2D_GM_ILLEGAL_DEFENSE);
 // modes in which nobody may play the ball
 constexpr uint32_t kPeriodEndModes = (1u << S2D_GM_FIRST_HALF_OVER) | (1u << S2D_GM_EXTEND_HALF);   // "half_time", "time_extended"
 // the shoot-out's modes (idl/service.proto:290-297)
@@ -777,7 +787,20 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   // pass in every cycle of a launch and finish long after the others (the launch lasts as long as its slowest wave: 305 us against
   // 215 us for a batch in which nothing happens, profiles/r03/match_quiet_rate.txt, with 95 % of all wave-cycles quiet).
   const int total_cycles = p.total_cycles, end_cycles = p.end_cycles;      // end of the normal time, end of the last period
-  const bool calm = !(any_kick || caught_by >= 0 || hold_move >= 0 || foul_call != 0) && g.offside == 0 &&
+  // IllegalDefense_ (idl/service.proto:295, 1637-1640; off when number = 0 -- the stock server, and then all of this folds away): the
+  // counters of a cycle played in PlayOn (oracle: match_step).  They live in the set-play timer, which PlayOn does not use.
+  int ill_timer = 0; bool ill_call = false;
+  if (p.illegal_defense_number > 0) {
+    const bool in_strip = is_player && o.card < S2D_CARD_RED && fabsf(o.y) < p.ill_half_w && (l < 11 ? o.x < -p.ill_x : o.x > p.ill_x);
+    const uint32_t zm = hballot(in_strip, half) & 0x3FFFFFu;
+    const int nl = __popc(zm & 0x7FFu), nr = __popc(zm >> 11);
+    int cl = g.timer & 0xff, cr = (g.timer >> 8) & 0xff;
+    cl = (g.last_touch == SIDE_RIGHT && nl >= p.illegal_defense_number) ? (cl < 255 ? cl + 1 : 255) : 0;
+    cr = (g.last_touch == SIDE_LEFT && nr >= p.illegal_defense_number) ? (cr < 255 ? cr + 1 : 255) : 0;
+    ill_timer = cl | (cr << 8);
+    ill_call = mode0 == S2D_GM_PLAY_ON && (cl >= p.illegal_defense_duration || cr >= p.illegal_defense_duration);
+  }
+  const bool calm = !(any_kick || caught_by >= 0 || hold_move >= 0 || foul_call != 0) && g.offside == 0 && !ill_call &&
                     !(advanced && (g.cycle >= end_cycles || g.to_half == 1));
   bool idle = mode0 == S2D_GM_PLAY_ON && fabsf(bx) <= p.half_l && fabsf(by) <= p.half_w;   // play goes on, the ball is on the pitch
   if (!PLAY && mode0 != S2D_GM_PLAY_ON) {
@@ -795,6 +818,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   if (__ballot(busy) == 0ull) {
     if (advanced) g.to_half -= 1;                          // the clock moved, and not onto a half's end
     if (mode0 != S2D_GM_PLAY_ON && mode0 != S2D_GM_TIME_OVER) g.timer += 1;
+    if (p.illegal_defense_number > 0 && mode0 == S2D_GM_PLAY_ON) g.timer = ill_timer;
     if (mode0 != S2D_GM_TIME_OVER && mode0 != S2D_GM_FREE_KICK) { gr.holder = 0; gr.moves = 0; }
   } else {
   float first = -1.0e9f, second = -1.0e9f;      // two largest dirS*x0 among the kicker's opponents
@@ -953,6 +977,14 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
           g.mode = S2D_GM_OFF_SIDE; g.mode_side = side_of(t); g.timer = 0;          // offside_l / _r: named after the offender
           g.offside = -1 - t;                       // marker: ball goes to player t (resolved below)
         }
+      }
+    }
+    if (p.illegal_defense_number > 0 && mode0 == S2D_GM_PLAY_ON && g.mode == S2D_GM_PLAY_ON) {   // no other call in this cycle
+      g.timer = ill_timer;
+      if (ill_call) {                                      // named after the offender; the ball on that half's penalty spot
+        const int offender = (ill_timer & 0xff) >= p.illegal_defense_duration ? SIDE_LEFT : SIDE_RIGHT;
+        g.mode = S2D_GM_ILLEGAL_DEFENSE; g.mode_side = offender; g.timer = 0; g.offside = 0;
+        place_ball = true; pbx = (offender == SIDE_LEFT ? -1.0f : 1.0f) * (p.half_l - 11.0f); pby = 0.0f;
       }
     }
     // half time / extra time / time over (ServerParam.nr_extra_halfs, extra_half_time, golden_goal: idl/service.proto:1601, 1622, 1635):
@@ -1244,8 +1276,9 @@ S2D_DEV void match_rollout_body(const P& p, const TY& pt, const MShared& sh, con
 
 // STOCK: the configuration words are MStock's constants (m_is_stock() said they equal this engine's); else they are read from LDS.
 // STOCK_TYPES (with STOCK): all 22 players of the stock PlayerType, the table's entries are constants too.
-// SCHED (with STOCK and STOCK_TYPES): the schedule words are the engine's own (MStockSched).
-template <bool STOCK, bool STOCK_TYPES, bool SCHED = false>
+// SCHED (with STOCK and STOCK_TYPES): the schedule words are the engine's own (MStockSched).  ILL (general only): the engine has
+// IllegalDefense_ switched on.
+template <bool STOCK, bool STOCK_TYPES, bool SCHED = false, bool ILL = false>
 __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p_arg, MPtrs q, int64_t n, int n_steps,
                                                                      const float* __restrict__ actions, MRoll ro) {
   __shared__ float4 pos_tile[kEnvsPerBlock][kTileSlots];
@@ -1282,7 +1315,9 @@ __global__ __launch_bounds__(kMBlock, 4) void s2d_match_rollout_kernel(MParams p
     // The ~70 uniform parameters are read from LDS (broadcast reads) where they are used instead of
     // occupying SGPRs for the whole kernel: as kernargs they cost 142 SGPR spills and 48 B of scratch at
     // the 128-VGPR cap (26 spills / 12 B this way, +14 % throughput).
-    __shared__ MParams p_lds;
+    static_assert(!ILL || !STOCK, "the stock configurations have the rule off");
+    using PBlock = std::conditional_t<ILL, MParams, MParamsNoIll>;
+    __shared__ PBlock p_lds;
     static_assert(sizeof(MParams) / 4 <= kMBlock, "one thread per parameter word");
     if (threadIdx.x < sizeof(MParams) / 4)
       reinterpret_cast<uint32_t*>(&p_lds)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&p_arg)[threadIdx.x];
@@ -1458,6 +1493,7 @@ S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
   m.nr_extra_halfs = S2D_STOCK_EXTRA_HALFS; m.extra_half_cycles = 1000; m.golden_goal = 0;
   m.penalty_shoot_outs = S2D_STOCK_SHOOT_OUTS; m.pen_before_setup_wait = 10; m.pen_ready_wait = 10; m.pen_taken_wait = 150; m.pen_nr_kicks = 5;
   m.pen_max_extra_kicks = 5; m.pen_dist_x = 42.5;
+  m.illegal_defense_number = 0; m.illegal_defense_duration = 20; m.illegal_defense_dist_x = 16.5; m.illegal_defense_width = 40.32;
   c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
   for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) c->player_types[t] = m_default_type(c->sp, m);   // homogeneous
 }
@@ -1483,6 +1519,8 @@ S2D_API int s2d_match_validate_config(const S2DMatchConfig* c) {
   if (c->mp.pen_before_setup_wait < 0 || c->mp.pen_ready_wait < 0 || c->mp.pen_taken_wait < 0 || c->mp.pen_nr_kicks < 1 ||
       c->mp.pen_max_extra_kicks < 0 || c->mp.pen_nr_kicks + c->mp.pen_max_extra_kicks > 15)
     return mfail(S2D_EINVAL, "pen_*_wait must be >= 0, pen_nr_kicks >= 1, pen_max_extra_kicks >= 0 and their sum <= 15");
+  if (c->mp.illegal_defense_number < 0 || c->mp.illegal_defense_duration < 1 || c->mp.illegal_defense_duration > 255)
+    return mfail(S2D_EINVAL, "illegal_defense_number must be >= 0 and illegal_defense_duration in [1, 255]");
   for (int i = 0; i < S2D_MATCH_PLAYERS; ++i)
     if (c->player_type_id[i] < 0 || c->player_type_id[i] >= S2D_MATCH_PLAYER_TYPES)
       return mfail(S2D_EINVAL, "player_type_id entries must be in [0, 18)");
@@ -1542,6 +1580,8 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   p.penalty_shoot_outs = m.penalty_shoot_outs != 0; p.pen_before_setup_wait = m.pen_before_setup_wait; p.pen_ready_wait = m.pen_ready_wait;
   p.pen_taken_wait = m.pen_taken_wait; p.pen_nr_kicks = m.pen_nr_kicks; p.pen_max_extra_kicks = m.pen_max_extra_kicks;
   p.pen_spot_x = (float)(s.pitch_half_length - m.pen_dist_x);
+  p.illegal_defense_number = m.illegal_defense_number; p.illegal_defense_duration = m.illegal_defense_duration;
+  p.ill_x = (float)(s.pitch_half_length - m.illegal_defense_dist_x); p.ill_half_w = (float)(m.illegal_defense_width * 0.5);
   p.total_cycles = m.half_time_cycles * m.nr_normal_halfs;
   p.end_cycles = p.total_cycles + (m.nr_extra_halfs > 0 ? m.extra_half_cycles * m.nr_extra_halfs : 0);
   p.auto_reset = c.auto_reset; p.noise = c.noise;
@@ -1594,7 +1634,8 @@ static bool m_rules_are_stock(const MParams& p) {
   return ok && p.tackle_cycles == MStockSched::tackle_cycles && p.use_offside == MStockSched::use_offside &&
          p.catch_ban_cycle == MStockSched::catch_ban_cycle && p.goalie_max_moves == MStockSched::goalie_max_moves &&
          p.back_passes == MStockSched::back_passes && p.free_kick_faults == MStockSched::free_kick_faults &&
-         p.stopped_clock == MStockSched::stopped_clock && p.foul_cycles == MStockSched::foul_cycles;
+         p.stopped_clock == MStockSched::stopped_clock && p.foul_cycles == MStockSched::foul_cycles &&
+         p.illegal_defense_number == MStockSched::illegal_defense_number && p.illegal_defense_duration == MStockSched::illegal_defense_duration;
 }
 
 static bool m_types_are_stock(const float (*t)[kHalf]) {
@@ -1745,6 +1786,9 @@ static int m_launch(S2DMatchHandle h, int n_steps, const float* actions, const S
   else if (h->stock)
     hipLaunchKernelGGL((s2d_match_rollout_kernel<true, false>), dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
                        h->ptrs, h->n, n_steps, actions, ro);
+  else if (h->mp.illegal_defense_number > 0)
+    hipLaunchKernelGGL((s2d_match_rollout_kernel<false, false, false, true>), dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream),
+                       h->mp, h->ptrs, h->n, n_steps, actions, ro);
   else
     hipLaunchKernelGGL((s2d_match_rollout_kernel<false, false>), dim3(m_grid(h->n)), dim3(kMBlock), 0, static_cast<hipStream_t>(stream), h->mp,
                        h->ptrs, h->n, n_steps, actions, ro);
@@ -1754,7 +1798,8 @@ static int m_launch(S2DMatchHandle h, int n_steps, const float* actions, const S
 S2D_API const char* s2d_match_kernel_name(S2DMatchHandle h) {
   if (!h) return "";
   if (h->stock_sched) return "s2d_match_rollout_kernel<stock rules, own schedule>";
-  return h->stock_types ? "s2d_match_rollout_kernel<stock, stock types>" : h->stock ? "s2d_match_rollout_kernel<stock>" : "s2d_match_rollout_kernel<general>";
+  return h->stock_types ? "s2d_match_rollout_kernel<stock, stock types>" : h->stock ? "s2d_match_rollout_kernel<stock>" :
+         h->mp.illegal_defense_number > 0 ? "s2d_match_rollout_kernel<general, illegal defense>" : "s2d_match_rollout_kernel<general>";
 }
 S2D_API int s2d_match_relative(S2DMatchHandle h, float* dist_dev, float* angle_dev, void* stream) {
   if (!h || !dist_dev || !angle_dev) return mfail(S2D_EINVAL, "NULL argument");

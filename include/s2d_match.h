@@ -51,7 +51,8 @@ enum {
   /* the penalty shoot-out after a drawn extra time (idl/service.proto:290-297; PenaltyFoul_ = 29 is not called: the defending
    * goalie stands still until the kick, the kicker may play the ball more than once -- rcssserver's pen_allow_mult_kicks) */
   S2D_GM_PENALTY_SETUP = 22, S2D_GM_PENALTY_READY = 23, S2D_GM_PENALTY_TAKEN = 24, S2D_GM_PENALTY_MISS = 25,
-  S2D_GM_PENALTY_SCORE = 26, S2D_GM_PENALTY_ONFIELD = 28
+  S2D_GM_PENALTY_SCORE = 26, S2D_GM_PENALTY_ONFIELD = 28,
+  S2D_GM_ILLEGAL_DEFENSE = 27   /* an announcement like OffSide_: named after the offending side (see illegal_defense_number) */
 };
 /* During the shoot-out the set-play word (S2DMatchBuffers.set_play_taker) carries its state -- PenaltyKickState of the proto
  * (idl/service.proto:130-138): bits 0-7 = 1 + index of the current taker, 12-15 / 16-19 = kicks taken by the left / right team,
@@ -113,6 +114,13 @@ typedef struct S2DMatchParams {
   int32_t pen_before_setup_wait, pen_ready_wait, pen_taken_wait;   /* 10 10 150 */
   int32_t pen_nr_kicks, pen_max_extra_kicks;                       /* 5 5 (their sum <= 15) */
   double pen_dist_x;                      /* 42.5 */
+  /* IllegalDefense_ (idl/service.proto:295; ServerParam.illegal_defense_number / _duration / _dist_x / _width :1637-1640; OFF in the
+   * stock server: number = 0).  While the ball is in play and the OTHER team was the last to play it, a team that keeps at least
+   * `number` players inside the strip of dist_x in front of its own goal line, width wide, for `duration` cycles on end is called:
+   * IllegalDefense_ named after it, the ball on that half's penalty spot, after announce_wait a FreeKick_ for the other team.
+   * (In PlayOn the two counters live in setplay_timer, bits 0-7 left / 8-15 right: the word is otherwise unused there.) */
+  int32_t illegal_defense_number, illegal_defense_duration;   /* 0 20 (duration <= 255) */
+  double illegal_defense_dist_x, illegal_defense_width;       /* 16.5 40.32 */
 } S2DMatchParams;
 
 /* PlayerType (idl/service.proto:1697-1732): the members that enter the dynamics.  Type 0 is the

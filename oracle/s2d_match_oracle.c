@@ -43,6 +43,7 @@ typedef struct MP {
   int stopped_clock, announce_wait, foul_cycles; REAL foul_detect_probability;
   int nr_extra_halfs, extra_half_cycles, golden_goal;
   int penalty_shoot_outs, pen_before_setup_wait, pen_ready_wait, pen_taken_wait, pen_nr_kicks, pen_max_extra_kicks; REAL pen_spot_x;
+  int illegal_defense_number, illegal_defense_duration; REAL ill_x, ill_half_w;   /* the strip: |x| > ill_x on the own side, |y| < ill_half_w */
   REAL catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
   /* heterogeneous players: the parameters of every player slot's PlayerType (idl/service.proto:1697-1732) */
@@ -102,6 +103,8 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   p->penalty_shoot_outs = m->penalty_shoot_outs; p->pen_before_setup_wait = m->pen_before_setup_wait; p->pen_ready_wait = m->pen_ready_wait;
   p->pen_taken_wait = m->pen_taken_wait; p->pen_nr_kicks = m->pen_nr_kicks; p->pen_max_extra_kicks = m->pen_max_extra_kicks;
   p->pen_spot_x = (REAL)(s->pitch_half_length - m->pen_dist_x);
+  p->illegal_defense_number = m->illegal_defense_number; p->illegal_defense_duration = m->illegal_defense_duration;
+  p->ill_x = (REAL)(s->pitch_half_length - m->illegal_defense_dist_x); p->ill_half_w = (REAL)(m->illegal_defense_width * 0.5);
   p->catch_half_w = (REAL)(m->catch_area_w * 0.5); p->catch_probability = (REAL)m->catch_probability;
   p->max_catch_angle = (REAL)m->max_catch_angle; p->min_catch_angle = (REAL)m->min_catch_angle;
   p->pen_x = (REAL)(s->pitch_half_length - m->penalty_area_length); p->pen_half_w = (REAL)m->penalty_area_half_width;
@@ -144,7 +147,7 @@ static int is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D_G
 /* announcements: a dead ball named after the offending side; after announce_wait cycles the referee awards the restart */
 static int is_announcement(int mode) {
   return mode == S2D_GM_OFF_SIDE || mode == S2D_GM_BACK_PASS || mode == S2D_GM_FREE_KICK_FAULT || mode == S2D_GM_CATCH_FAULT ||
-         mode == S2D_GM_FOUL_CHARGE;
+         mode == S2D_GM_FOUL_CHARGE || mode == S2D_GM_ILLEGAL_DEFENSE;
 }
 /* modes in which nobody may play the ball */
 /* the shoot-out's modes (idl/service.proto:290-297) */
@@ -697,6 +700,25 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
           }
         }
       }
+    }
+    /* IllegalDefense_ (idl/service.proto:295; ServerParam.illegal_defense_*: 1637-1640; rcssserver's IllegalDefenseRef restated; off when
+     * number = 0, as in the stock server).  Counted in the cycles played in PlayOn that leave the game in PlayOn: a team with at
+     * least `number` players (not sent off) inside the strip in front of its own goal while the other team was the last to play
+     * the ball adds a cycle, anything else starts again; `duration` cycles on end are called.  The two counters live in
+     * setplay_timer (bits 0-7 left, 8-15 right), which PlayOn does not use and every restart clears. */
+    if (p->illegal_defense_number > 0 && mode0 == S2D_GM_PLAY_ON && m->mode == S2D_GM_PLAY_ON) {
+      int nl = 0, nr = 0;
+      for (int i = 0; i < NP; ++i) {
+        const Obj *o = &m->o[i];
+        if (o->card >= S2D_CARD_RED || !(R(fabs)(o->y) < p->ill_half_w)) continue;
+        if (i < 11) { if (o->x < -p->ill_x) nl++; } else { if (o->x > p->ill_x) nr++; }
+      }
+      int cl = m->setplay_timer & 0xff, cr = (m->setplay_timer >> 8) & 0xff;
+      cl = (m->last_touch_side == SIDE_RIGHT && nl >= p->illegal_defense_number) ? (cl < 255 ? cl + 1 : 255) : 0;
+      cr = (m->last_touch_side == SIDE_LEFT && nr >= p->illegal_defense_number) ? (cr < 255 ? cr + 1 : 255) : 0;
+      m->setplay_timer = cl | (cr << 8);
+      if (cl >= p->illegal_defense_duration) restart(m, S2D_GM_ILLEGAL_DEFENSE, SIDE_LEFT, -(p->half_l - R(11.0)), R(0.0));
+      else if (cr >= p->illegal_defense_duration) restart(m, S2D_GM_ILLEGAL_DEFENSE, SIDE_RIGHT, p->half_l - R(11.0), R(0.0));
     }
     /* half time / extra time / time over (rcssserver's TimeReferee; ServerParam.nr_extra_halfs, extra_half_time, golden_goal:
      * idl/service.proto:1601, 1622, 1635): decided only when the clock has just moved.  Normal time = nr_normal_halfs halves; a

@@ -693,6 +693,54 @@ def test_schedule_words_keep_the_stock_kernel():
     assert MatchEngine(8, 'cuda:0', use_offside=0).kernel_name().endswith('<general>')
 
 
+def test_illegal_defense_on_device():
+    """IllegalDefense_ (idl/service.proto:295, 1637-1640; off in the stock configuration): the scripted scene of
+    tests/test_match_oracle.py::test_illegal_defense and a random-policy run with a rule tight enough to be called often -- device ==
+    oracle in every word after every cycle (the counters live in setplay_timer during PlayOn).  Restated rule: parity unpinned."""
+    from soccer2d_amd._capi_match import GM_FREE_KICK, GM_ILLEGAL_DEFENSE, GM_PLAY_ON
+    n = 6
+    eng, orc = _pair(n, auto_reset=0, announce_wait=3, illegal_defense_number=4, illegal_defense_duration=5)
+    assert eng.kernel_name().endswith('<general, illegal defense>')
+    a = np.zeros((n, 22, 3), dtype=np.float32)
+
+    def put(e, slot, **kv):
+        orc.set_obj(e, slot, **kv)
+        for f, v in kv.items():
+            getattr(eng, f)[e, slot] = v
+    for e in range(n):
+        orc.set_game(e, mode=GM_PLAY_ON, mode_side=0, last_touch_side=2 if e != 4 else 1); eng.mode[e] = GM_PLAY_ON; eng.mode_side[e] = 0
+        eng.last_touch_side[e] = 2 if e != 4 else 1
+        for i in range(22):
+            put(e, i, x=(-20.0 if i < 11 else 20.0) - (i % 11), y=-25.0 + 2.0 * (i % 11), vx=0.0, vy=0.0)
+        for k, i in enumerate((1, 2, 3, 4) if e != 5 else (1, 2, 3)):      # match 5: three defenders are not enough
+            put(e, i, x=-45.0 - k, y=-6.0 + 4.0 * k)
+        if e == 3:                                                           # match 3: the right team packs its goal mouth instead
+            orc.set_game(e, last_touch_side=1); eng.last_touch_side[e] = 1
+            for k, i in enumerate((12, 13, 14, 15)):
+                put(e, i, x=45.0 + k, y=-6.0 + 4.0 * k)
+            for i in (1, 2, 3, 4):
+                put(e, i, x=-20.0, y=10.0 + i)
+        put(e, 22, x=0.0, y=30.0, vx=0.0, vy=0.0)
+    seen = []
+    for t in range(10):
+        eng.step(torch.as_tensor(a, device='cuda:0')); orc.step(a)
+        assert_match_same(eng, orc, f'illegal defense t={t}')
+        seen.append([int(v) for v in orc.get('mode')])
+    assert seen[3] == [GM_PLAY_ON] * n and seen[4][:4] == [GM_ILLEGAL_DEFENSE] * 4 and seen[4][4:] == [GM_PLAY_ON] * 2
+    assert [int(v) for v in orc.get('mode_side')[:4]] == [2, 2, 2, 1] and seen[7][:4] == [GM_FREE_KICK] * 4      # the others restart
+    assert seen[9][4:] == [GM_PLAY_ON] * 2 and int(orc.get('setplay_timer')[4]) == 0 and int(orc.get('setplay_timer')[5]) == 0
+    # the in-kernel random policy with a rule that fires: one player in the strip for three cycles
+    eng, orc = _pair(48, half_time_cycles=300, illegal_defense_number=1, illegal_defense_duration=3, illegal_defense_dist_x=30.0, noise=True)
+    modes = set()
+    for t in range(200):
+        eng.step(None); orc.step(None)
+        if t % 5 == 0 or t < 20:
+            assert_match_same(eng, orc, f'illegal defense, random policy t={t}')
+        modes.update(int(v) for v in orc.get('mode'))
+    assert_match_same(eng, orc, 'illegal defense, random policy, end')
+    assert GM_ILLEGAL_DEFENSE in modes
+
+
 def test_penalty_shoot_out_on_device():
     """The shoot-out (idl/service.proto:290-297, 1602-1613) on the device, every word equal to the oracle's after every cycle: scripted
     kicks (a goal, a miss by waiting, a ball over the side line, a catch, a kick that runs out of time; decided early in some matches,

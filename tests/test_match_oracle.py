@@ -370,6 +370,56 @@ def test_penalty_shoot_out():
     assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1
 
 
+def test_illegal_defense():
+    """IllegalDefense_ (idl/service.proto:295; ServerParam.illegal_defense_number / _duration / _dist_x / _width :1637-1640): off in the
+    stock server (number = 0).  Switched on: a team that packs its own goal mouth while the other team has the ball is called after
+    `duration` cycles on end -- announcement named after it, ball on that half's penalty spot, then a FreeKick_ for the others; the
+    count starts again when the defenders play the ball or leave.  rcssserver's IllegalDefenseRef restated: parity unpinned."""
+    from soccer2d_amd._capi_match import GM_FREE_KICK, GM_ILLEGAL_DEFENSE
+    def scene(**kw):
+        m = fresh(auto_reset=0, announce_wait=3, **kw); play_on(m)
+        for i in range(22):                                             # everybody far from the ball and from both goal mouths
+            m.set_obj(0, i, x=(-20.0 if i < 11 else 20.0) - (i % 11), y=-25.0 + 2.0 * (i % 11), vx=0.0, vy=0.0)
+        for k, i in enumerate((1, 2, 3, 4)):                            # four left defenders inside their own strip
+            m.set_obj(0, i, x=-45.0 - k, y=-6.0 + 4.0 * k)
+        m.set_obj(0, 22, x=0.0, y=30.0, vx=0.0, vy=0.0)
+        m.set_game(0, last_touch_side=RIGHT)
+        return m
+    m = scene()                                                         # stock: the rule is off
+    for _ in range(30):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('setplay_timer')[0] == 0
+    m = scene(illegal_defense_number=4, illegal_defense_duration=5)
+    for k in range(4):
+        m.step(acts())
+        assert m.get('mode')[0] == GM_PLAY_ON and m.get('setplay_timer')[0] == k + 1          # the left team's count (bits 0-7)
+    m.step(acts())
+    assert m.get('mode')[0] == GM_ILLEGAL_DEFENSE and m.get('mode_side')[0] == LEFT and m.get('setplay_timer')[0] == 0
+    assert (m.get('x')[0][22], m.get('y')[0][22]) == (np.float32(-41.5), 0.0)
+    for _ in range(3):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == RIGHT
+    # three defenders are not enough; neither are four while their own team was the last to play the ball
+    m = scene(illegal_defense_number=4, illegal_defense_duration=5); m.set_obj(0, 4, x=-20.0, y=0.0)
+    for _ in range(12):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('setplay_timer')[0] == 0
+    m = scene(illegal_defense_number=4, illegal_defense_duration=5); m.set_game(0, last_touch_side=LEFT)
+    for _ in range(12):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_PLAY_ON and m.get('setplay_timer')[0] == 0
+    # the count starts again when a defender leaves the strip for a cycle; the right team is counted in bits 8-15
+    m = scene(illegal_defense_number=4, illegal_defense_duration=5)
+    for _ in range(3):
+        m.step(acts())
+    m.set_obj(0, 1, x=-30.0, y=0.0); m.step(acts()); assert m.get('setplay_timer')[0] == 0
+    m.set_obj(0, 1, x=-45.0, y=-6.0); m.step(acts()); assert m.get('setplay_timer')[0] == 1
+    m = scene(illegal_defense_number=2, illegal_defense_duration=9); m.set_game(0, last_touch_side=LEFT)
+    m.set_obj(0, 12, x=50.0, y=3.0); m.set_obj(0, 13, x=40.0, y=-19.0)
+    m.step(acts()); m.step(acts())
+    assert m.get('setplay_timer')[0] == 2 << 8 and m.get('mode')[0] == GM_PLAY_ON
+
+
 def test_random_matches_are_deterministic_and_eventful():
     n = 64
     kw = dict(half_time_cycles=400, extra_half_cycles=50, pen_before_setup_wait=2, pen_taken_wait=20, pen_nr_kicks=1, pen_max_extra_kicks=1)
