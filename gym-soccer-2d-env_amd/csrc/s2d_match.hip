@@ -71,6 +71,7 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
   int nr_extra_halfs, extra_half_cycles, golden_goal;
   int penalty_shoot_outs, pen_before_setup_wait, pen_ready_wait, pen_taken_wait, pen_nr_kicks, pen_max_extra_kicks; float pen_spot_x;
   int illegal_defense_number, illegal_defense_duration; float ill_x, ill_half_w;   // the strip: beyond ill_x on the own side, |y| < ill_half_w
+  int pen_allow_mult_kicks;
   int total_cycles, end_cycles;   // derived: end of the normal time, end of the last period (= total_cycles without extra halves)
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
@@ -119,6 +120,7 @@ struct MStock {
   static constexpr int pen_before_setup_wait = 10, pen_ready_wait = 10, pen_taken_wait = 150, pen_nr_kicks = 5, pen_max_extra_kicks = 5;
   static constexpr float pen_spot_x = (float)(52.5 - 42.5);
   static constexpr int illegal_defense_number = 0, illegal_defense_duration = 20;   // (off, as in the stock server: the rule's code folds away)
+  static constexpr int pen_allow_mult_kicks = 1;
   static constexpr float ill_x = (float)(52.5 - 16.5), ill_half_w = (float)(40.32 * 0.5);
   static constexpr int total_cycles = half_time_cycles * nr_normal_halfs, end_cycles = total_cycles + extra_half_cycles * nr_extra_halfs;
   int auto_reset, noise;
@@ -144,6 +146,7 @@ struct MStockSched {
   static constexpr float foul_detect_probability = (float)0.5;
   static constexpr float pen_spot_x = (float)(52.5 - 42.5);
   static constexpr int illegal_defense_number = 0, illegal_defense_duration = 20;   // (off, as in the stock server: the rule's code folds away)
+  static constexpr int pen_allow_mult_kicks = 1;
   static constexpr float ill_x = (float)(52.5 - 16.5), ill_half_w = (float)(40.32 * 0.5);
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
@@ -162,9 +165,9 @@ struct MStockSched {
 #define M_CONFIG_INTS(X) X(tackle_cycles) X(half_time_cycles) X(nr_normal_halfs) X(drop_ball_time) X(use_offside) X(catch_ban_cycle) \
   X(goalie_max_moves) X(after_goal_wait) X(kick_off_wait) X(back_passes) X(free_kick_faults) X(stopped_clock) X(announce_wait) X(foul_cycles) \
   X(nr_extra_halfs) X(extra_half_cycles) X(golden_goal) X(total_cycles) X(end_cycles) X(pen_before_setup_wait) \
-  X(pen_ready_wait) X(pen_taken_wait) X(pen_nr_kicks) X(pen_max_extra_kicks) X(illegal_defense_number) X(illegal_defense_duration)
+  X(pen_ready_wait) X(pen_taken_wait) X(pen_nr_kicks) X(pen_max_extra_kicks) X(illegal_defense_number) X(illegal_defense_duration) X(pen_allow_mult_kicks)
 // every configuration word of MParams is in one of the two lists (the remaining seven are the per-engine words)
-static_assert(sizeof(MParams) == 4 * (56 + 26 + 7), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
+static_assert(sizeof(MParams) == 4 * (56 + 27 + 7), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
 
 // The per-slot table of an engine whose 22 players are all of the stock PlayerType (the default: s2d_match_default_config), with the
 // same spelling as the LDS table -- types[ROW][lane] -- but every entry an immediate: a cycle reads about ten of them per lane, each
@@ -245,7 +248,8 @@ constexpr uint32_t kAnnounceModes = (1u << S2D_GM_OFF_SIDE) | (1u << S2D_GM_BACK
 constexpr uint32_t kPeriodEndModes = (1u << S2D_GM_FIRST_HALF_OVER) | (1u << S2D_GM_EXTEND_HALF);   // "half_time", "time_extended"
 // the shoot-out's modes (idl/service.proto:290-297)
 constexpr uint32_t kPenaltyModes = (1u << S2D_GM_PENALTY_SETUP) | (1u << S2D_GM_PENALTY_READY) | (1u << S2D_GM_PENALTY_TAKEN) |
-                                   (1u << S2D_GM_PENALTY_MISS) | (1u << S2D_GM_PENALTY_SCORE) | (1u << S2D_GM_PENALTY_ONFIELD);
+                                   (1u << S2D_GM_PENALTY_MISS) | (1u << S2D_GM_PENALTY_SCORE) | (1u << S2D_GM_PENALTY_ONFIELD) |
+                                   (1u << S2D_GM_PENALTY_FOUL);
 constexpr uint32_t kDeadBallModes = kAnnounceModes | (1u << S2D_GM_AFTER_GOAL) | (1u << S2D_GM_BEFORE_KICK_OFF) |
                                     kPeriodEndModes | (1u << S2D_GM_GOALIE_CATCH) |
                                     (kPenaltyModes & ~((1u << S2D_GM_PENALTY_READY) | (1u << S2D_GM_PENALTY_TAKEN)));
@@ -864,7 +868,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
         }
       }
     } else if (is_penalty(mode0)) {                        // the shoot-out's own sequence (oracle: match_step, same order)
-      int result = -1;                                     // 0 / 1: this cycle ends the kick with a miss / a goal
+      int result = -1;                                     // 0 / 1 / 2: this cycle ends the kick with a miss / a goal / a foul of the kicker (a miss)
       if (mode0 == S2D_GM_PENALTY_ONFIELD) {
         g.timer += 1;
         if (g.timer >= p.pen_before_setup_wait) { g.mode = S2D_GM_PENALTY_SETUP; g.mode_side = SIDE_LEFT; }   // the left team kicks first (placed below)
@@ -875,10 +879,11 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
         else { g.timer += 1; if (g.timer >= p.pen_ready_wait) result = 0; }
       } else if (mode0 == S2D_GM_PENALTY_TAKEN) {
         if (caught_by >= 0) result = 0;
+        else if (!p.pen_allow_mult_kicks && ((hballot(kicked, half) >> ((gr.taker & 0xff) - 1)) & 1u)) result = 2;   // PenaltyFoul_: a second touch
         else if (bx > p.half_l && fabsf(by) < p.goal_half_width) result = 1;
         else if (fabsf(bx) > p.half_l || fabsf(by) > p.half_w) result = 0;
         else { g.timer += 1; if (g.timer > p.pen_taken_wait) result = 0; }
-      } else {                                             // PenaltyScore_ / PenaltyMiss_: the verdict stands for a while
+      } else {                                             // PenaltyScore_ / PenaltyMiss_ / PenaltyFoul_: the verdict stands for a while
         g.timer += 1;
         if (g.timer >= p.pen_before_setup_wait) {
           if (pen_over(p, gr.taker)) {
@@ -888,9 +893,9 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
       }
       if (result >= 0) {                                   // counted, announced; the ball is dead
         int w = gr.taker + (1 << (side0 == SIDE_LEFT ? 12 : 16));
-        if (result) { w += 1 << (side0 == SIDE_LEFT ? 20 : 24); g.reward = side0 == SIDE_LEFT ? 1.0f : -1.0f; }
+        if (result == 1) { w += 1 << (side0 == SIDE_LEFT ? 20 : 24); g.reward = side0 == SIDE_LEFT ? 1.0f : -1.0f; }
         gr.taker = w;
-        g.mode = result ? S2D_GM_PENALTY_SCORE : S2D_GM_PENALTY_MISS; g.timer = 0;
+        g.mode = result == 1 ? S2D_GM_PENALTY_SCORE : result == 2 ? S2D_GM_PENALTY_FOUL : S2D_GM_PENALTY_MISS; g.timer = 0;
         if (is_ball) { o.vx = 0.0f; o.vy = 0.0f; }
       }
     } else if (is_setplay(mode0)) {
@@ -1493,6 +1498,7 @@ S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
   m.nr_extra_halfs = S2D_STOCK_EXTRA_HALFS; m.extra_half_cycles = 1000; m.golden_goal = 0;
   m.penalty_shoot_outs = S2D_STOCK_SHOOT_OUTS; m.pen_before_setup_wait = 10; m.pen_ready_wait = 10; m.pen_taken_wait = 150; m.pen_nr_kicks = 5;
   m.pen_max_extra_kicks = 5; m.pen_dist_x = 42.5;
+  m.pen_allow_mult_kicks = 1; m.reserved_mp2 = 0;
   m.illegal_defense_number = 0; m.illegal_defense_duration = 20; m.illegal_defense_dist_x = 16.5; m.illegal_defense_width = 40.32;
   c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
   for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) c->player_types[t] = m_default_type(c->sp, m);   // homogeneous
@@ -1581,6 +1587,7 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   p.pen_taken_wait = m.pen_taken_wait; p.pen_nr_kicks = m.pen_nr_kicks; p.pen_max_extra_kicks = m.pen_max_extra_kicks;
   p.pen_spot_x = (float)(s.pitch_half_length - m.pen_dist_x);
   p.illegal_defense_number = m.illegal_defense_number; p.illegal_defense_duration = m.illegal_defense_duration;
+  p.pen_allow_mult_kicks = m.pen_allow_mult_kicks != 0;
   p.ill_x = (float)(s.pitch_half_length - m.illegal_defense_dist_x); p.ill_half_w = (float)(m.illegal_defense_width * 0.5);
   p.total_cycles = m.half_time_cycles * m.nr_normal_halfs;
   p.end_cycles = p.total_cycles + (m.nr_extra_halfs > 0 ? m.extra_half_cycles * m.nr_extra_halfs : 0);
@@ -1635,7 +1642,8 @@ static bool m_rules_are_stock(const MParams& p) {
          p.catch_ban_cycle == MStockSched::catch_ban_cycle && p.goalie_max_moves == MStockSched::goalie_max_moves &&
          p.back_passes == MStockSched::back_passes && p.free_kick_faults == MStockSched::free_kick_faults &&
          p.stopped_clock == MStockSched::stopped_clock && p.foul_cycles == MStockSched::foul_cycles &&
-         p.illegal_defense_number == MStockSched::illegal_defense_number && p.illegal_defense_duration == MStockSched::illegal_defense_duration;
+         p.illegal_defense_number == MStockSched::illegal_defense_number && p.illegal_defense_duration == MStockSched::illegal_defense_duration &&
+         p.pen_allow_mult_kicks == MStockSched::pen_allow_mult_kicks;
 }
 
 static bool m_types_are_stock(const float (*t)[kHalf]) {

@@ -9,13 +9,13 @@ MATCH_PLAYER_TYPES, GOALIE_LEFT, GOALIE_RIGHT = 18, 0, 11
 GM_TIME_OVER, GM_PLAY_ON, GM_KICK_OFF, GM_KICK_IN, GM_FREE_KICK, GM_CORNER_KICK, GM_GOAL_KICK, GM_AFTER_GOAL, GM_OFF_SIDE = 1, 2, 3, 4, 5, 6, 7, 8, 9
 GM_BEFORE_KICK_OFF, GM_BACK_PASS, GM_FREE_KICK_FAULT = 0, 18, 19          # idl/service.proto:268, 286-287
 GM_FIRST_HALF_OVER, GM_FOUL_CHARGE, GM_CATCH_FAULT, GM_IND_FREE_KICK, GM_GOALIE_CATCH, GM_EXTEND_HALF = 11, 14, 20, 21, 30, 31   # :279, 282, 288-289, 298-299
-GM_PENALTY_SETUP, GM_PENALTY_READY, GM_PENALTY_TAKEN, GM_PENALTY_MISS, GM_PENALTY_SCORE, GM_PENALTY_ONFIELD = 22, 23, 24, 25, 26, 28   # :290-297
+GM_PENALTY_SETUP, GM_PENALTY_READY, GM_PENALTY_TAKEN, GM_PENALTY_MISS, GM_PENALTY_SCORE, GM_PENALTY_ONFIELD, GM_PENALTY_FOUL = 22, 23, 24, 25, 26, 28, 29   # :290-297
 GM_ILLEGAL_DEFENSE = 27                                # :295 (off in the stock server)
 GM_PENALTY_KICK = 10                                   # :278 (a foul inside the offender's own penalty area; the shoot-out modes are not built)
 GM_NAMES = {0: 'BeforeKickOff', 1: 'TimeOver', 2: 'PlayOn', 3: 'KickOff_', 4: 'KickIn_', 5: 'FreeKick_', 6: 'CornerKick_', 7: 'GoalKick_',
             8: 'AfterGoal_', 9: 'OffSide_', 11: 'FirstHalfOver', 14: 'FoulCharge_', 18: 'BackPass_', 19: 'FreeKickFault_',
             20: 'CatchFault_', 21: 'IndFreeKick_', 22: 'PenaltySetup_', 23: 'PenaltyReady_', 24: 'PenaltyTaken_',
-            25: 'PenaltyMiss_', 26: 'PenaltyScore_', 27: 'IllegalDefense_', 28: 'PenaltyOnfield_', 30: 'GoalieCatch_', 31: 'ExtendHalf'}
+            25: 'PenaltyMiss_', 26: 'PenaltyScore_', 27: 'IllegalDefense_', 28: 'PenaltyOnfield_', 29: 'PenaltyFoul_', 30: 'GoalieCatch_', 31: 'ExtendHalf'}
 CARD_NONE, CARD_YELLOW, CARD_RED = 0, 1, 2
 
 
@@ -35,7 +35,8 @@ class S2DMatchParams(C.Structure):
                     ('penalty_shoot_outs', C.c_int32), ('pen_before_setup_wait', C.c_int32), ('pen_ready_wait', C.c_int32),
                     ('pen_taken_wait', C.c_int32), ('pen_nr_kicks', C.c_int32), ('pen_max_extra_kicks', C.c_int32),
                     ('pen_dist_x', C.c_double), ('illegal_defense_number', C.c_int32), ('illegal_defense_duration', C.c_int32),
-                    ('illegal_defense_dist_x', C.c_double), ('illegal_defense_width', C.c_double)]
+                    ('illegal_defense_dist_x', C.c_double), ('illegal_defense_width', C.c_double),
+                    ('pen_allow_mult_kicks', C.c_int32), ('reserved_mp2', C.c_int32)]
 
 
 PLAYER_TYPE_FIELDS = ('player_speed_max', 'stamina_inc_max', 'player_decay', 'inertia_moment', 'dash_power_rate',

@@ -48,10 +48,11 @@ enum {
   S2D_GM_FREE_KICK = 5, S2D_GM_CORNER_KICK = 6, S2D_GM_GOAL_KICK = 7, S2D_GM_AFTER_GOAL = 8, S2D_GM_OFF_SIDE = 9,
   S2D_GM_PENALTY_KICK = 10, S2D_GM_FIRST_HALF_OVER = 11, S2D_GM_FOUL_CHARGE = 14, S2D_GM_BACK_PASS = 18, S2D_GM_FREE_KICK_FAULT = 19,
   S2D_GM_CATCH_FAULT = 20, S2D_GM_IND_FREE_KICK = 21, S2D_GM_GOALIE_CATCH = 30, S2D_GM_EXTEND_HALF = 31,
-  /* the penalty shoot-out after a drawn extra time (idl/service.proto:290-297; PenaltyFoul_ = 29 is not called: the defending
-   * goalie stands still until the kick, the kicker may play the ball more than once -- rcssserver's pen_allow_mult_kicks) */
+  /* the penalty shoot-out after a drawn extra time (idl/service.proto:290-297).  PenaltyFoul_: the kicker played the ball a second
+   * time although pen_allow_mult_kicks is off -- the kick counts as missed (the defending goalie cannot infringe: he stands still
+   * until the kick) */
   S2D_GM_PENALTY_SETUP = 22, S2D_GM_PENALTY_READY = 23, S2D_GM_PENALTY_TAKEN = 24, S2D_GM_PENALTY_MISS = 25,
-  S2D_GM_PENALTY_SCORE = 26, S2D_GM_PENALTY_ONFIELD = 28,
+  S2D_GM_PENALTY_SCORE = 26, S2D_GM_PENALTY_ONFIELD = 28, S2D_GM_PENALTY_FOUL = 29,
   S2D_GM_ILLEGAL_DEFENSE = 27   /* an announcement like OffSide_: named after the offending side (see illegal_defense_number) */
 };
 /* During the shoot-out the set-play word (S2DMatchBuffers.set_play_taker) carries its state -- PenaltyKickState of the proto
@@ -106,7 +107,8 @@ typedef struct S2DMatchParams {
    * kick PenaltySetup_ (one cycle: the ball on the spot pen_dist_x from the right goal line, the taker behind it, the other team's
    * goalie on the line, everybody else inside the centre circle, all placed by the referee = pen_coach_moves_players), PenaltyReady_
    * (the taker has pen_ready_wait cycles to play the ball), PenaltyTaken_ (taker against goalie, at most pen_taken_wait cycles:
-   * ball in the goal = PenaltyScore_; out, caught or out of time = PenaltyMiss_), the verdict for pen_before_setup_wait cycles.
+   * ball in the goal = PenaltyScore_; out, caught or out of time = PenaltyMiss_; a second touch with pen_allow_mult_kicks off =
+   * PenaltyFoul_), the verdict for pen_before_setup_wait cycles.
    * The left team kicks first, takers from index 10 downwards; pen_nr_kicks each (decided early when one side cannot catch up),
    * then pairs of kicks until one pair decides or pen_max_extra_kicks more are used up (then the draw stands: pen_random_winner
    * is not built).  The clock stands throughout. */
@@ -121,6 +123,9 @@ typedef struct S2DMatchParams {
    * (In PlayOn the two counters live in setplay_timer, bits 0-7 left / 8-15 right: the word is otherwise unused there.) */
   int32_t illegal_defense_number, illegal_defense_duration;   /* 0 20 (duration <= 255) */
   double illegal_defense_dist_x, illegal_defense_width;       /* 16.5 40.32 */
+  int32_t pen_allow_mult_kicks;           /* 1 (ServerParam.pen_allow_mult_kicks, idl/service.proto:1611): the taker may play the ball
+                                             again during PenaltyTaken_; 0 = a second touch of his is PenaltyFoul_, the kick is missed */
+  int32_t reserved_mp2;
 } S2DMatchParams;
 
 /* PlayerType (idl/service.proto:1697-1732): the members that enter the dynamics.  Type 0 is the

@@ -43,6 +43,7 @@ typedef struct MP {
   int stopped_clock, announce_wait, foul_cycles; REAL foul_detect_probability;
   int nr_extra_halfs, extra_half_cycles, golden_goal;
   int penalty_shoot_outs, pen_before_setup_wait, pen_ready_wait, pen_taken_wait, pen_nr_kicks, pen_max_extra_kicks; REAL pen_spot_x;
+  int pen_allow_mult_kicks;
   int illegal_defense_number, illegal_defense_duration; REAL ill_x, ill_half_w;   /* the strip: |x| > ill_x on the own side, |y| < ill_half_w */
   REAL catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
@@ -103,6 +104,7 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   p->penalty_shoot_outs = m->penalty_shoot_outs; p->pen_before_setup_wait = m->pen_before_setup_wait; p->pen_ready_wait = m->pen_ready_wait;
   p->pen_taken_wait = m->pen_taken_wait; p->pen_nr_kicks = m->pen_nr_kicks; p->pen_max_extra_kicks = m->pen_max_extra_kicks;
   p->pen_spot_x = (REAL)(s->pitch_half_length - m->pen_dist_x);
+  p->pen_allow_mult_kicks = m->pen_allow_mult_kicks;
   p->illegal_defense_number = m->illegal_defense_number; p->illegal_defense_duration = m->illegal_defense_duration;
   p->ill_x = (REAL)(s->pitch_half_length - m->illegal_defense_dist_x); p->ill_half_w = (REAL)(m->illegal_defense_width * 0.5);
   p->catch_half_w = (REAL)(m->catch_area_w * 0.5); p->catch_probability = (REAL)m->catch_probability;
@@ -153,7 +155,7 @@ static int is_announcement(int mode) {
 /* the shoot-out's modes (idl/service.proto:290-297) */
 static int is_penalty(int mode) {
   return mode == S2D_GM_PENALTY_SETUP || mode == S2D_GM_PENALTY_READY || mode == S2D_GM_PENALTY_TAKEN || mode == S2D_GM_PENALTY_MISS ||
-         mode == S2D_GM_PENALTY_SCORE || mode == S2D_GM_PENALTY_ONFIELD;
+         mode == S2D_GM_PENALTY_SCORE || mode == S2D_GM_PENALTY_ONFIELD || mode == S2D_GM_PENALTY_FOUL;
 }
 static int is_period_end(int mode) { return mode == S2D_GM_FIRST_HALF_OVER || mode == S2D_GM_EXTEND_HALF; }   /* "half_time", "time_extended" */
 static int ball_dead(int mode) {
@@ -610,10 +612,13 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
       } else if (mode0 == S2D_GM_PENALTY_TAKEN) {
         const REAL bx = b->x, by = b->y;
         if (caught_by >= 0) pen_result(m, side0, 0);
+        else if (!p->pen_allow_mult_kicks && kicked[pen_taker]) {   /* PenaltyFoul_ (:297): the kicker played the ball a second time */
+          pen_result(m, side0, 0); m->mode = S2D_GM_PENALTY_FOUL;
+        }
         else if (bx > p->half_l && R(fabs)(by) < p->goal_half_width) pen_result(m, side0, 1);
         else if (R(fabs)(bx) > p->half_l || R(fabs)(by) > p->half_w) pen_result(m, side0, 0);
         else { m->setplay_timer += 1; if (m->setplay_timer > p->pen_taken_wait) pen_result(m, side0, 0); }
-      } else {                                             /* PenaltyScore_ / PenaltyMiss_: the verdict stands for a while */
+      } else {                                             /* PenaltyScore_ / PenaltyMiss_ / PenaltyFoul_: the verdict stands for a while */
         m->setplay_timer += 1;
         if (m->setplay_timer >= p->pen_before_setup_wait) {
           if (pen_over(p, m->set_play_taker)) {

@@ -693,6 +693,23 @@ def test_schedule_words_keep_the_stock_kernel():
     assert MatchEngine(8, 'cuda:0', use_offside=0).kernel_name().endswith('<general>')
 
 
+def test_penalty_foul_on_device():
+    """PenaltyFoul_ (idl/service.proto:297) with pen_allow_mult_kicks = 0 (:1611): the kicker's second touch ends his kick as a miss;
+    device == oracle after every cycle (general kernel: the stock rules allow repeated touches), random policy through whole shoot-outs."""
+    from soccer2d_amd._capi_match import GM_PENALTY_FOUL, GM_PENALTY_TAKEN
+    eng, orc = _pair(40, half_time_cycles=8, nr_extra_halfs=0, pen_before_setup_wait=2, pen_ready_wait=4, pen_taken_wait=15, pen_nr_kicks=2,
+                     pen_max_extra_kicks=1, pen_allow_mult_kicks=0, noise=True)
+    assert eng.kernel_name().endswith('<general>')
+    seen = set()
+    for t in range(500):
+        eng.step(None); orc.step(None)
+        if t % 5 == 0 or t < 25:
+            assert_match_same(eng, orc, f'penalty foul t={t}')
+        seen.update(int(v) for v in orc.get('mode'))
+    assert_match_same(eng, orc, 'penalty foul, end')
+    assert {GM_PENALTY_TAKEN, GM_PENALTY_FOUL} <= seen and list(eng.stats.cpu().numpy()) == list(orc.stats())
+
+
 def test_illegal_defense_on_device():
     """IllegalDefense_ (idl/service.proto:295, 1637-1640; off in the stock configuration): the scripted scene of
     tests/test_match_oracle.py::test_illegal_defense and a random-policy run with a rule tight enough to be called often -- device ==

@@ -363,6 +363,22 @@ def test_penalty_shoot_out():
     for _ in range(2):
         m.step(acts())
     assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1 and _pen_word(m) == dict(taker=9, kicks=(2, 1), goals=(2, 0))
+    # pen_allow_mult_kicks = 0 (idl/service.proto:1611): a second touch of the kicker is PenaltyFoul_ (:297) and the kick is missed
+    from soccer2d_amd._capi_match import GM_PENALTY_FOUL
+    for allow in (1, 0):
+        m = fresh(pen_allow_mult_kicks=allow, **kw)
+        for _ in range(13):
+            m.step(acts())
+        to_ready(m, LEFT, 10)
+        m.step(acts(p10=[MCMD_KICK, 20, 0]))
+        assert m.get('mode')[0] == GM_PENALTY_TAKEN
+        m.set_obj(0, 22, x=float(m.get('x')[0][10]) + 0.6, y=0.0, vx=0.0, vy=0.0)      # the ball at his feet again
+        m.step(acts(p10=[MCMD_KICK, 100, 0]))
+        assert m.get('mode')[0] == (GM_PENALTY_TAKEN if allow else GM_PENALTY_FOUL)
+        assert _pen_word(m)['kicks'] == ((0, 0) if allow else (1, 0)) and _pen_word(m)['goals'] == (0, 0)
+        if not allow:
+            assert m.get('vx')[0][22] == 0
+            to_ready(m, RIGHT, 21)                                       # the verdict stands, then the other side's kick
     # penalty_shoot_outs = 0: the draw stands at once
     m = fresh(penalty_shoot_outs=0, **{k: v for k, v in kw.items()})
     for _ in range(13):
