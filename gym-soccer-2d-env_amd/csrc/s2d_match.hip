@@ -239,7 +239,11 @@ template <class P> S2D_DEV U4 m_draw(const P& p, uint32_t gl, uint32_t gh, uint3
 }
 S2D_DEV int side_of(int i) { return i < 11 ? SIDE_LEFT : SIDE_RIGHT; }
 S2D_DEV int other_side(int s) { return s == SIDE_LEFT ? SIDE_RIGHT : SIDE_LEFT; }
-S2D_DEV bool is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D_GM_TIME_OVER; }
+// TimeOver, and the two modes only an operator sets (Pause, Human: idl/service.proto:280-281 -- write them into the mode plane to hold
+// a match, PlayOn or a set play to let it go on): nobody acts, nothing is decided, the clock stands
+constexpr uint32_t kHaltedModes = (1u << S2D_GM_TIME_OVER) | (1u << S2D_GM_PAUSE) | (1u << S2D_GM_HUMAN);
+S2D_DEV bool is_halted(int mode) { return ((kHaltedModes >> (mode & 31)) & 1u) != 0u; }
+S2D_DEV bool is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && !is_halted(mode); }
 // Mode classes as bit masks over GameModeType (every value used is < 32): one shift + and instead of a chain of compares.
 // announcements: a dead ball named after the offending side; after announce_wait cycles the referee awards the restart
 constexpr uint32_t kAnnounceModes = (1u << S2D_GM_OFF_SIDE) | (1u << S2D_GM_BACK_PASS) | (1u << S2D_GM_FREE_KICK_FAULT) |
@@ -255,7 +259,7 @@ constexpr uint32_t kDeadBallModes = kAnnounceModes | (1u << S2D_GM_AFTER_GOAL) |
                                     (kPenaltyModes & ~((1u << S2D_GM_PENALTY_READY) | (1u << S2D_GM_PENALTY_TAKEN)));
 // modes in which the clock stands still (with stopped_clock): WorldModel.cycle keeps its value, stoped_cycle counts
 constexpr uint32_t kClockStandsModes = kAnnounceModes | (1u << S2D_GM_BEFORE_KICK_OFF) | (1u << S2D_GM_AFTER_GOAL) |
-                                       kPeriodEndModes | (1u << S2D_GM_TIME_OVER) | kPenaltyModes;
+                                       kPeriodEndModes | kHaltedModes | kPenaltyModes;
 static_assert(S2D_GM_EXTEND_HALF < 32, "mode masks are 32 bits wide");
 S2D_DEV bool in_modes(int mode, uint32_t mask) { return ((mask >> (mode & 31)) & 1u) != 0u; }
 S2D_DEV bool is_announcement(int mode) { return in_modes(mode, kAnnounceModes); }
@@ -497,7 +501,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   // ---- 1. commands + player movement (lane-local)
   float ax = 0.0f, ay = 0.0f, kx = 0.0f, ky = 0.0f;
   bool kicked = false, by_kick = false;                    // by_kick: the impulse came from a Kick command (not a tackle)
-  if (!is_player || o.tackle > 0 || mode0 == S2D_GM_TIME_OVER || o.card >= S2D_CARD_RED) cmd = S2D_MCMD_NONE;
+  if (!is_player || o.tackle > 0 || is_halted(mode0) || o.card >= S2D_CARD_RED) cmd = S2D_MCMD_NONE;
   // the shoot-out: the taker acts once the kick is ready, the defending goalie once it is taken, nobody else at all
   const bool pen_goalie_acts = mode0 == S2D_GM_PENALTY_TAKEN && l == (side0 == SIDE_LEFT ? S2D_MATCH_GOALIE_RIGHT : S2D_MATCH_GOALIE_LEFT);
   if (is_penalty(mode0)) {                                 // (uniform per match)
@@ -808,7 +812,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
                     !(advanced && (g.cycle >= end_cycles || g.to_half == 1));
   bool idle = mode0 == S2D_GM_PLAY_ON && fabsf(bx) <= p.half_l && fabsf(by) <= p.half_w;   // play goes on, the ball is on the pitch
   if (!PLAY && mode0 != S2D_GM_PLAY_ON) {
-    if (mode0 == S2D_GM_TIME_OVER) {
+    if (is_halted(mode0)) {
       idle = true;
     } else {                                               // the value the timer has to stay below after this cycle's increment
       const int pen_limit = mode0 == S2D_GM_PENALTY_READY ? p.pen_ready_wait : mode0 == S2D_GM_PENALTY_TAKEN ? p.pen_taken_wait + 1 :
@@ -821,9 +825,9 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   const bool busy = !(calm && idle);
   if (__ballot(busy) == 0ull) {
     if (advanced) g.to_half -= 1;                          // the clock moved, and not onto a half's end
-    if (mode0 != S2D_GM_PLAY_ON && mode0 != S2D_GM_TIME_OVER) g.timer += 1;
+    if (mode0 != S2D_GM_PLAY_ON && !is_halted(mode0)) g.timer += 1;
     if (p.illegal_defense_number > 0 && mode0 == S2D_GM_PLAY_ON) g.timer = ill_timer;
-    if (mode0 != S2D_GM_TIME_OVER && mode0 != S2D_GM_FREE_KICK) { gr.holder = 0; gr.moves = 0; }
+    if (!is_halted(mode0) && mode0 != S2D_GM_FREE_KICK) { gr.holder = 0; gr.moves = 0; }
   } else {
   float first = -1.0e9f, second = -1.0e9f;      // two largest dirS*x0 among the kicker's opponents
   const int S = any_kick ? side_of(last_kicker) : SIDE_LEFT;
@@ -838,7 +842,7 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
   bool restart_form = false; int form_side = SIDE_LEFT;      // formation placement requested
   bool place_ball = false; float pbx = 0.0f, pby = 0.0f;     // ball placement requested
   bool recover_half = false;
-  if (mode0 != S2D_GM_TIME_OVER) {
+  if (!is_halted(mode0)) {
     if (mode0 == S2D_GM_AFTER_GOAL) {                      // dead ball until the wait is over, then the conceding side kicks off
       g.timer += 1;
       if (g.timer >= p.after_goal_wait) {

@@ -53,6 +53,8 @@ enum {
    * until the kick) */
   S2D_GM_PENALTY_SETUP = 22, S2D_GM_PENALTY_READY = 23, S2D_GM_PENALTY_TAKEN = 24, S2D_GM_PENALTY_MISS = 25,
   S2D_GM_PENALTY_SCORE = 26, S2D_GM_PENALTY_ONFIELD = 28, S2D_GM_PENALTY_FOUL = 29,
+  S2D_GM_PAUSE = 12, S2D_GM_HUMAN = 13,   /* never entered by the engine: an operator writes them into the mode plane to HOLD a match
+                                             (nobody acts, nothing is decided, the clock stands) and another mode to let it go on */
   S2D_GM_ILLEGAL_DEFENSE = 27   /* an announcement like OffSide_: named after the offending side (see illegal_defense_number) */
 };
 /* During the shoot-out the set-play word (S2DMatchBuffers.set_play_taker) carries its state -- PenaltyKickState of the proto

@@ -145,7 +145,9 @@ typedef struct Match {
 
 static int side_of(int i) { return i < 11 ? SIDE_LEFT : SIDE_RIGHT; }
 static int other_side(int s) { return s == SIDE_LEFT ? SIDE_RIGHT : SIDE_LEFT; }
-static int is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && mode != S2D_GM_TIME_OVER; }
+/* TimeOver, and the two modes only an operator sets (Pause, Human: idl/service.proto:280-281): nobody acts, nothing is decided, the clock stands */
+static int is_halted(int mode) { return mode == S2D_GM_TIME_OVER || mode == S2D_GM_PAUSE || mode == S2D_GM_HUMAN; }
+static int is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && !is_halted(mode); }
 /* announcements: a dead ball named after the offending side; after announce_wait cycles the referee awards the restart */
 static int is_announcement(int mode) {
   return mode == S2D_GM_OFF_SIDE || mode == S2D_GM_BACK_PASS || mode == S2D_GM_FREE_KICK_FAULT || mode == S2D_GM_CATCH_FAULT ||
@@ -164,7 +166,7 @@ static int ball_dead(int mode) {
 }
 /* modes in which the clock stands still (with stopped_clock): WorldModel.cycle keeps its value, stoped_cycle counts */
 static int clock_stands(int mode) {
-  return mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_AFTER_GOAL || is_period_end(mode) || mode == S2D_GM_TIME_OVER ||
+  return mode == S2D_GM_BEFORE_KICK_OFF || mode == S2D_GM_AFTER_GOAL || is_period_end(mode) || is_halted(mode) ||
          is_announcement(mode) || is_penalty(mode);
 }
 /* where a sent-off player waits: beside the halfway line, outside the pitch, one spot per uniform number */
@@ -403,7 +405,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     ax[i] = ay[i] = kx[i] = ky[i] = R(0.0); kicked[i] = 0; by_kick[i] = 0;
     int cmd = (int)act[i * 3 + 0];
     REAL a = (REAL)act[i * 3 + 1], bb = (REAL)act[i * 3 + 2];
-    if (o->tackle > 0 || mode0 == S2D_GM_TIME_OVER || o->card >= S2D_CARD_RED) cmd = S2D_MCMD_NONE;
+    if (o->tackle > 0 || is_halted(mode0) || o->card >= S2D_CARD_RED) cmd = S2D_MCMD_NONE;
     /* the shoot-out: the taker acts once the kick is ready, the defending goalie once it is taken, nobody else at all */
     if (pen && !((i == pen_taker && (mode0 == S2D_GM_PENALTY_READY || mode0 == S2D_GM_PENALTY_TAKEN)) ||
                  (i == pen_goalie && mode0 == S2D_GM_PENALTY_TAKEN))) cmd = S2D_MCMD_NONE;
@@ -574,7 +576,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
   const int advanced = !(p->stopped_clock && clock_stands(mode0));
   if (advanced) { m->cycle = (int32_t)((uint32_t)m->cycle + 1u); m->stopped_cycle = 0; }
   else m->stopped_cycle += 1;
-  if (mode0 != S2D_GM_TIME_OVER) {
+  if (!is_halted(mode0)) {
     if (mode0 == S2D_GM_AFTER_GOAL) {                   /* the ball is dead until the wait is over, then the conceding side kicks off */
       m->setplay_timer += 1;
       if (m->setplay_timer >= p->after_goal_wait) {
@@ -739,7 +741,7 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
     if (p->golden_goal && p->nr_extra_halfs > 0 && m->cycle > total && m->reward_left != R(0.0)) over = 1;   /* a goal (this cycle) in extra time */
     if (pen) over = 0;                                   /* (the shoot-out ends by its own count; its clock stands) */
     const int last_end = advanced && m->cycle == ext_total;       /* (= total without extra halves) */
-    if (over && last_end && tied && p->penalty_shoot_outs && mode0 != S2D_GM_TIME_OVER) {
+    if (over && last_end && tied && p->penalty_shoot_outs) {
       /* a draw after the last period: PenaltyOnfield_, named after the half the kicks are taken in (the right one) */
       restart(m, S2D_GM_PENALTY_ONFIELD, SIDE_RIGHT, b->x, b->y); m->last_touch_side = SIDE_NONE;
     } else if (over) {

@@ -710,6 +710,31 @@ def test_penalty_foul_on_device():
     assert {GM_PENALTY_TAKEN, GM_PENALTY_FOUL} <= seen and list(eng.stats.cpu().numpy()) == list(orc.stats())
 
 
+def test_pause_holds_matches_on_device():
+    """Pause / Human written into the mode plane hold a match (idl/service.proto:280-281): device == oracle while some matches are held and
+    the others play on (random policy), and after they are let go."""
+    from soccer2d_amd._capi_match import GM_HUMAN, GM_PAUSE, GM_PLAY_ON
+    n = 30
+    eng, orc = _pair(n, noise=True)
+    for t in range(20):
+        eng.step(None); orc.step(None)
+    held = {e: (GM_PAUSE if e % 2 else GM_HUMAN) for e in range(0, n, 3)}
+    back = {e: (int(orc.get('mode')[e]), int(orc.get('mode_side')[e])) for e in held}
+    for e, md in held.items():
+        orc.set_game(e, mode=md); eng.mode[e] = md
+    cyc = orc.get('cycle').copy()
+    for t in range(25):
+        eng.step(None); orc.step(None)
+        assert_match_same(eng, orc, f'held t={t}')
+    assert all(int(orc.get('cycle')[e]) == int(cyc[e]) and int(orc.get('mode')[e]) == held[e] for e in held)
+    for e, (md, sd) in back.items():
+        orc.set_game(e, mode=md, mode_side=sd); eng.mode[e] = md; eng.mode_side[e] = sd
+    for t in range(25):
+        eng.step(None); orc.step(None)
+        assert_match_same(eng, orc, f'let go t={t}')
+    assert eng.kernel_name().endswith('<stock, stock types>')
+
+
 def test_illegal_defense_on_device():
     """IllegalDefense_ (idl/service.proto:295, 1637-1640; off in the stock configuration): the scripted scene of
     tests/test_match_oracle.py::test_illegal_defense and a random-policy run with a rule tight enough to be called often -- device ==

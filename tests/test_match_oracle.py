@@ -386,6 +386,26 @@ def test_penalty_shoot_out():
     assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1
 
 
+def test_pause_and_human_hold_a_match():
+    """Pause / Human (idl/service.proto:280-281): modes only an operator sets.  Written into the mode word they hold the match -- commands
+    ignored, nothing decided, the clock stands, no timer counts -- until another mode is written."""
+    from soccer2d_amd._capi_match import GM_HUMAN, GM_PAUSE
+    for held in (GM_PAUSE, GM_HUMAN):
+        m = fresh(auto_reset=0); play_on(m)
+        for _ in range(5):
+            m.step(acts(p3=[MCMD_DASH, 100, 0]))
+        x3, cyc = float(m.get('x')[0][3]), int(m.get('cycle')[0])
+        m.set_game(0, mode=held)
+        m.set_obj(0, 3, vx=0.0, vy=0.0)
+        for k in range(7):
+            m.step(acts(p3=[MCMD_DASH, 100, 0], p9=[MCMD_KICK, 100, 0]))
+            assert m.get('mode')[0] == held and m.get('cycle')[0] == cyc and m.get('stopped_cycle')[0] == k + 1 and m.get('done')[0] == 0
+        assert float(m.get('x')[0][3]) == x3 and m.get('setplay_timer')[0] == 0
+        play_on(m)
+        m.step(acts(p3=[MCMD_DASH, 100, 0]))
+        assert m.get('cycle')[0] == cyc + 1 and float(m.get('x')[0][3]) > x3
+
+
 def test_illegal_defense():
     """IllegalDefense_ (idl/service.proto:295; ServerParam.illegal_defense_number / _duration / _dist_x / _width :1637-1640): off in the
     stock server (number = 0).  Switched on: a team that packs its own goal mouth while the other team has the ball is called after
