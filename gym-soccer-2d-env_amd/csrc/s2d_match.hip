@@ -247,7 +247,8 @@ S2D_DEV bool is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && !is_halted(
 // Mode classes as bit masks over GameModeType (every value used is < 32): one shift + and instead of a chain of compares.
 // announcements: a dead ball named after the offending side; after announce_wait cycles the referee awards the restart
 constexpr uint32_t kAnnounceModes = (1u << S2D_GM_OFF_SIDE) | (1u << S2D_GM_BACK_PASS) | (1u << S2D_GM_FREE_KICK_FAULT) |
-                                    (1u << S2D_GM_CATCH_FAULT) | (1u << S2D_GM_FOUL_CHARGE) | (1u << S2D_GM_ILLEGAL_DEFENSE);
+                                    (1u << S2D_GM_CATCH_FAULT) | (1u << S2D_GM_FOUL_CHARGE) | (1u << S2D_GM_ILLEGAL_DEFENSE) |
+                                    (1u << S2D_GM_FOUL_PUSH) | (1u << S2D_GM_FOUL_MULTIPLE_ATTACKER) | (1u << S2D_GM_FOUL_BALL_OUT);
 // modes in which nobody may play the ball
 constexpr uint32_t kPeriodEndModes = (1u << S2D_GM_FIRST_HALF_OVER) | (1u << S2D_GM_EXTEND_HALF);   // "half_time", "time_extended"
 // the shoot-out's modes (idl/service.proto:290-297)

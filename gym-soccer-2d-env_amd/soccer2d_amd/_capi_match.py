@@ -10,11 +10,12 @@ GM_TIME_OVER, GM_PLAY_ON, GM_KICK_OFF, GM_KICK_IN, GM_FREE_KICK, GM_CORNER_KICK,
 GM_BEFORE_KICK_OFF, GM_BACK_PASS, GM_FREE_KICK_FAULT = 0, 18, 19          # idl/service.proto:268, 286-287
 GM_FIRST_HALF_OVER, GM_FOUL_CHARGE, GM_CATCH_FAULT, GM_IND_FREE_KICK, GM_GOALIE_CATCH, GM_EXTEND_HALF = 11, 14, 20, 21, 30, 31   # :279, 282, 288-289, 298-299
 GM_PENALTY_SETUP, GM_PENALTY_READY, GM_PENALTY_TAKEN, GM_PENALTY_MISS, GM_PENALTY_SCORE, GM_PENALTY_ONFIELD, GM_PENALTY_FOUL = 22, 23, 24, 25, 26, 28, 29   # :290-297
+GM_FOUL_PUSH, GM_FOUL_MULTIPLE_ATTACKER, GM_FOUL_BALL_OUT = 15, 16, 17   # :283-285 (an operator's calls: played like FoulCharge_)
 GM_PAUSE, GM_HUMAN = 12, 13                            # :280-281 (an operator's: written into eng.mode to hold a match)
 GM_ILLEGAL_DEFENSE = 27                                # :295 (off in the stock server)
 GM_PENALTY_KICK = 10                                   # :278 (a foul inside the offender's own penalty area; the shoot-out modes are not built)
 GM_NAMES = {0: 'BeforeKickOff', 1: 'TimeOver', 2: 'PlayOn', 3: 'KickOff_', 4: 'KickIn_', 5: 'FreeKick_', 6: 'CornerKick_', 7: 'GoalKick_',
-            8: 'AfterGoal_', 9: 'OffSide_', 11: 'FirstHalfOver', 12: 'Pause', 13: 'Human', 14: 'FoulCharge_', 18: 'BackPass_', 19: 'FreeKickFault_',
+            8: 'AfterGoal_', 9: 'OffSide_', 11: 'FirstHalfOver', 12: 'Pause', 13: 'Human', 14: 'FoulCharge_', 15: 'FoulPush_', 16: 'FoulMultipleAttacker_', 17: 'FoulBallOut_', 18: 'BackPass_', 19: 'FreeKickFault_',
             20: 'CatchFault_', 21: 'IndFreeKick_', 22: 'PenaltySetup_', 23: 'PenaltyReady_', 24: 'PenaltyTaken_',
             25: 'PenaltyMiss_', 26: 'PenaltyScore_', 27: 'IllegalDefense_', 28: 'PenaltyOnfield_', 29: 'PenaltyFoul_', 30: 'GoalieCatch_', 31: 'ExtendHalf'}
 CARD_NONE, CARD_YELLOW, CARD_RED = 0, 1, 2

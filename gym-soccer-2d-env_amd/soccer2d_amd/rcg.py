@@ -9,7 +9,7 @@ are not available offline, so the writer is checked by its own reader (round tri
 """
 PLAYMODE_NAMES = {1: 'time_over', 2: 'play_on', 3: 'kick_off_{s}', 4: 'kick_in_{s}', 5: 'free_kick_{s}',
                   6: 'corner_kick_{s}', 7: 'goal_kick_{s}', 8: 'goal_{s}', 9: 'offside_{s}', 0: 'before_kick_off',
-                  10: 'penalty_kick_{s}', 11: 'first_half_over', 12: 'pause', 13: 'human_judge', 14: 'foul_charge_{s}', 18: 'back_pass_{s}',
+                  10: 'penalty_kick_{s}', 11: 'first_half_over', 12: 'pause', 13: 'human_judge', 14: 'foul_charge_{s}', 15: 'foul_push_{s}', 16: 'foul_multiple_attack_{s}', 17: 'foul_ballout_{s}', 18: 'back_pass_{s}',
                   19: 'free_kick_fault_{s}', 20: 'catch_fault_{s}', 21: 'indirect_free_kick_{s}', 27: 'illegal_defense_{s}', 30: 'goalie_catch_ball_{s}',
                   31: 'time_extended'}
 

@@ -53,6 +53,9 @@ enum {
    * until the kick) */
   S2D_GM_PENALTY_SETUP = 22, S2D_GM_PENALTY_READY = 23, S2D_GM_PENALTY_TAKEN = 24, S2D_GM_PENALTY_MISS = 25,
   S2D_GM_PENALTY_SCORE = 26, S2D_GM_PENALTY_ONFIELD = 28, S2D_GM_PENALTY_FOUL = 29,
+  S2D_GM_FOUL_PUSH = 15, S2D_GM_FOUL_MULTIPLE_ATTACKER = 16, S2D_GM_FOUL_BALL_OUT = 17,   /* announcements the engine's own referee never
+                                             makes (rcssserver defines them and calls only FoulCharge_): written into the mode plane with the
+                                             offending side they are played like one -- dead ball, then a FreeKick_ for the other side */
   S2D_GM_PAUSE = 12, S2D_GM_HUMAN = 13,   /* never entered by the engine: an operator writes them into the mode plane to HOLD a match
                                              (nobody acts, nothing is decided, the clock stands) and another mode to let it go on */
   S2D_GM_ILLEGAL_DEFENSE = 27   /* an announcement like OffSide_: named after the offending side (see illegal_defense_number) */

@@ -151,7 +151,8 @@ static int is_setplay(int mode) { return mode != S2D_GM_PLAY_ON && !is_halted(mo
 /* announcements: a dead ball named after the offending side; after announce_wait cycles the referee awards the restart */
 static int is_announcement(int mode) {
   return mode == S2D_GM_OFF_SIDE || mode == S2D_GM_BACK_PASS || mode == S2D_GM_FREE_KICK_FAULT || mode == S2D_GM_CATCH_FAULT ||
-         mode == S2D_GM_FOUL_CHARGE || mode == S2D_GM_ILLEGAL_DEFENSE;
+         mode == S2D_GM_FOUL_CHARGE || mode == S2D_GM_ILLEGAL_DEFENSE ||
+         mode == S2D_GM_FOUL_PUSH || mode == S2D_GM_FOUL_MULTIPLE_ATTACKER || mode == S2D_GM_FOUL_BALL_OUT;   /* (an operator's calls) */
 }
 /* modes in which nobody may play the ball */
 /* the shoot-out's modes (idl/service.proto:290-297) */

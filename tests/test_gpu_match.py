@@ -733,6 +733,20 @@ def test_pause_holds_matches_on_device():
         eng.step(None); orc.step(None)
         assert_match_same(eng, orc, f'let go t={t}')
     assert eng.kernel_name().endswith('<stock, stock types>')
+    # FoulPush_ / FoulMultipleAttacker_ / FoulBallOut_ written by an operator are played like announcements: the same on the device
+    from soccer2d_amd._capi_match import GM_FOUL_BALL_OUT, GM_FOUL_MULTIPLE_ATTACKER, GM_FOUL_PUSH, GM_FREE_KICK
+    called = {}
+    for k, e in enumerate(range(1, n, 4)):
+        md = (GM_FOUL_PUSH, GM_FOUL_MULTIPLE_ATTACKER, GM_FOUL_BALL_OUT)[k % 3]
+        called[e] = md
+        orc.set_game(e, mode=md, mode_side=1 + k % 2, setplay_timer=0); eng.mode[e] = md; eng.mode_side[e] = 1 + k % 2; eng.setplay_timer[e] = 0
+    seen = {e: set() for e in called}
+    for t in range(40):
+        eng.step(None); orc.step(None)
+        assert_match_same(eng, orc, f'operator-called fouls t={t}')
+        for e in called:
+            seen[e].add(int(orc.get('mode')[e]))
+    assert all(called[e] in seen[e] and GM_FREE_KICK in seen[e] for e in called)
 
 
 def test_illegal_defense_on_device():

@@ -386,6 +386,24 @@ def test_penalty_shoot_out():
     assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1
 
 
+def test_operator_called_fouls_are_played_like_announcements():
+    """FoulPush_ / FoulMultipleAttacker_ / FoulBallOut_ (idl/service.proto:283-285): rcssserver defines them, its referees call only
+    FoulCharge_, and so does this engine's.  Written into the mode word with the offending side they are played as an announcement:
+    dead ball, the offenders cleared from it, after announce_wait a FreeKick_ for the other side."""
+    from soccer2d_amd._capi_match import GM_FOUL_BALL_OUT, GM_FOUL_MULTIPLE_ATTACKER, GM_FOUL_PUSH, GM_FREE_KICK
+    for md in (GM_FOUL_PUSH, GM_FOUL_MULTIPLE_ATTACKER, GM_FOUL_BALL_OUT):
+        m = fresh(auto_reset=0, announce_wait=4); play_on(m)
+        m.set_obj(0, 22, x=10.0, y=5.0, vx=0.0, vy=0.0); m.set_obj(0, 14, x=10.5, y=5.0); m.set_obj(0, 9, x=9.0, y=5.0)
+        m.set_game(0, mode=md, mode_side=RIGHT)
+        cyc = int(m.get('cycle')[0])
+        for k in range(3):
+            m.step(acts(p14=[MCMD_KICK, 100, 0], p9=[MCMD_KICK, 100, 180]))
+            assert m.get('mode')[0] == md and m.get('cycle')[0] == cyc and m.get('vx')[0][22] == 0       # nobody plays a dead ball
+        assert np.hypot(m.get('x')[0][14] - 10.0, m.get('y')[0][14] - 5.0) >= 9.15 - 1e-3                  # the offenders keep away
+        m.step(acts())
+        assert m.get('mode')[0] == GM_FREE_KICK and m.get('mode_side')[0] == LEFT
+
+
 def test_pause_and_human_hold_a_match():
     """Pause / Human (idl/service.proto:280-281): modes only an operator sets.  Written into the mode word they hold the match -- commands
     ignored, nothing decided, the clock stands, no timer counts -- until another mode is written."""
