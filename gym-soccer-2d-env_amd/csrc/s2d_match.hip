@@ -71,7 +71,7 @@ struct MParams {   // every field rounded once on the host (double -> float); pe
   int nr_extra_halfs, extra_half_cycles, golden_goal;
   int penalty_shoot_outs, pen_before_setup_wait, pen_ready_wait, pen_taken_wait, pen_nr_kicks, pen_max_extra_kicks; float pen_spot_x;
   int illegal_defense_number, illegal_defense_duration; float ill_x, ill_half_w;   // the strip: beyond ill_x on the own side, |y| < ill_half_w
-  int pen_allow_mult_kicks;
+  int pen_allow_mult_kicks, pen_random_winner;
   int total_cycles, end_cycles;   // derived: end of the normal time, end of the last period (= total_cycles without extra halves)
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
@@ -120,7 +120,7 @@ struct MStock {
   static constexpr int pen_before_setup_wait = 10, pen_ready_wait = 10, pen_taken_wait = 150, pen_nr_kicks = 5, pen_max_extra_kicks = 5;
   static constexpr float pen_spot_x = (float)(52.5 - 42.5);
   static constexpr int illegal_defense_number = 0, illegal_defense_duration = 20;   // (off, as in the stock server: the rule's code folds away)
-  static constexpr int pen_allow_mult_kicks = 1;
+  static constexpr int pen_allow_mult_kicks = 1, pen_random_winner = 0;
   static constexpr float ill_x = (float)(52.5 - 16.5), ill_half_w = (float)(40.32 * 0.5);
   static constexpr int total_cycles = half_time_cycles * nr_normal_halfs, end_cycles = total_cycles + extra_half_cycles * nr_extra_halfs;
   int auto_reset, noise;
@@ -146,7 +146,7 @@ struct MStockSched {
   static constexpr float foul_detect_probability = (float)0.5;
   static constexpr float pen_spot_x = (float)(52.5 - 42.5);
   static constexpr int illegal_defense_number = 0, illegal_defense_duration = 20;   // (off, as in the stock server: the rule's code folds away)
-  static constexpr int pen_allow_mult_kicks = 1;
+  static constexpr int pen_allow_mult_kicks = 1, pen_random_winner = 0;
   static constexpr float ill_x = (float)(52.5 - 16.5), ill_half_w = (float)(40.32 * 0.5);
   int auto_reset, noise;
   uint32_t seed_lo, seed_hi, gid_lo, gid_hi;
@@ -165,9 +165,9 @@ struct MStockSched {
 #define M_CONFIG_INTS(X) X(tackle_cycles) X(half_time_cycles) X(nr_normal_halfs) X(drop_ball_time) X(use_offside) X(catch_ban_cycle) \
   X(goalie_max_moves) X(after_goal_wait) X(kick_off_wait) X(back_passes) X(free_kick_faults) X(stopped_clock) X(announce_wait) X(foul_cycles) \
   X(nr_extra_halfs) X(extra_half_cycles) X(golden_goal) X(total_cycles) X(end_cycles) X(pen_before_setup_wait) \
-  X(pen_ready_wait) X(pen_taken_wait) X(pen_nr_kicks) X(pen_max_extra_kicks) X(illegal_defense_number) X(illegal_defense_duration) X(pen_allow_mult_kicks)
+  X(pen_ready_wait) X(pen_taken_wait) X(pen_nr_kicks) X(pen_max_extra_kicks) X(illegal_defense_number) X(illegal_defense_duration) X(pen_allow_mult_kicks) X(pen_random_winner)
 // every configuration word of MParams is in one of the two lists (the remaining seven are the per-engine words)
-static_assert(sizeof(MParams) == 4 * (56 + 27 + 7), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
+static_assert(sizeof(MParams) == 4 * (56 + 28 + 7), "a field was added to MParams: list it in M_CONFIG_FLOATS / M_CONFIG_INTS and in MStock");
 
 // The per-slot table of an engine whose 22 players are all of the stock PlayerType (the default: s2d_match_default_config), with the
 // same spelling as the LDS table -- types[ROW][lane] -- but every entry an immediate: a cycle reads about ten of them per lane, each
@@ -892,6 +892,9 @@ template <class P, class TY> S2D_DEV void match_cycle(const P& p, const TY& pt, 
         g.timer += 1;
         if (g.timer >= p.pen_before_setup_wait) {
           if (pen_over(p, gr.taker)) {
+            // pen_random_winner: a level shoot-out is decided by a coin (oracle: same draw, TACKLE stream, the ball's block)
+            if (p.pen_random_winner && pen_goals(gr.taker, SIDE_LEFT) == pen_goals(gr.taker, SIDE_RIGHT))
+              gr.taker |= (rnd_u01(m_draw(p, gl, gh, cyc, S2D_ST_TACKLE, (uint32_t)BALL).x) < 0.5f ? 1 : 2) << 28;
             g.mode = S2D_GM_TIME_OVER; g.mode_side = SIDE_NONE; g.done = 1; if (is_ball) ev |= EV_FINISHED;
           } else { g.mode = S2D_GM_PENALTY_SETUP; g.mode_side = other_side(side0); }
         }
@@ -1503,7 +1506,7 @@ S2D_API void s2d_match_default_config(S2DMatchConfig* c) {
   m.nr_extra_halfs = S2D_STOCK_EXTRA_HALFS; m.extra_half_cycles = 1000; m.golden_goal = 0;
   m.penalty_shoot_outs = S2D_STOCK_SHOOT_OUTS; m.pen_before_setup_wait = 10; m.pen_ready_wait = 10; m.pen_taken_wait = 150; m.pen_nr_kicks = 5;
   m.pen_max_extra_kicks = 5; m.pen_dist_x = 42.5;
-  m.pen_allow_mult_kicks = 1; m.reserved_mp2 = 0;
+  m.pen_allow_mult_kicks = 1; m.pen_random_winner = 0;
   m.illegal_defense_number = 0; m.illegal_defense_duration = 20; m.illegal_defense_dist_x = 16.5; m.illegal_defense_width = 40.32;
   c->seed = 0x5EEDull; c->env_id_offset = 0; c->auto_reset = 1; c->noise = 0;
   for (int t = 0; t < S2D_MATCH_PLAYER_TYPES; ++t) c->player_types[t] = m_default_type(c->sp, m);   // homogeneous
@@ -1592,7 +1595,7 @@ static void mparams_from_config(const S2DMatchConfig& c, MParams& p, float (*pta
   p.pen_taken_wait = m.pen_taken_wait; p.pen_nr_kicks = m.pen_nr_kicks; p.pen_max_extra_kicks = m.pen_max_extra_kicks;
   p.pen_spot_x = (float)(s.pitch_half_length - m.pen_dist_x);
   p.illegal_defense_number = m.illegal_defense_number; p.illegal_defense_duration = m.illegal_defense_duration;
-  p.pen_allow_mult_kicks = m.pen_allow_mult_kicks != 0;
+  p.pen_allow_mult_kicks = m.pen_allow_mult_kicks != 0; p.pen_random_winner = m.pen_random_winner != 0;
   p.ill_x = (float)(s.pitch_half_length - m.illegal_defense_dist_x); p.ill_half_w = (float)(m.illegal_defense_width * 0.5);
   p.total_cycles = m.half_time_cycles * m.nr_normal_halfs;
   p.end_cycles = p.total_cycles + (m.nr_extra_halfs > 0 ? m.extra_half_cycles * m.nr_extra_halfs : 0);
@@ -1648,7 +1651,7 @@ static bool m_rules_are_stock(const MParams& p) {
          p.back_passes == MStockSched::back_passes && p.free_kick_faults == MStockSched::free_kick_faults &&
          p.stopped_clock == MStockSched::stopped_clock && p.foul_cycles == MStockSched::foul_cycles &&
          p.illegal_defense_number == MStockSched::illegal_defense_number && p.illegal_defense_duration == MStockSched::illegal_defense_duration &&
-         p.pen_allow_mult_kicks == MStockSched::pen_allow_mult_kicks;
+         p.pen_allow_mult_kicks == MStockSched::pen_allow_mult_kicks && p.pen_random_winner == MStockSched::pen_random_winner;
 }
 
 static bool m_types_are_stock(const float (*t)[kHalf]) {

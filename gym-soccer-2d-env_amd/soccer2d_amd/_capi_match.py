@@ -38,7 +38,7 @@ class S2DMatchParams(C.Structure):
                     ('pen_taken_wait', C.c_int32), ('pen_nr_kicks', C.c_int32), ('pen_max_extra_kicks', C.c_int32),
                     ('pen_dist_x', C.c_double), ('illegal_defense_number', C.c_int32), ('illegal_defense_duration', C.c_int32),
                     ('illegal_defense_dist_x', C.c_double), ('illegal_defense_width', C.c_double),
-                    ('pen_allow_mult_kicks', C.c_int32), ('reserved_mp2', C.c_int32)]
+                    ('pen_allow_mult_kicks', C.c_int32), ('pen_random_winner', C.c_int32)]
 
 
 PLAYER_TYPE_FIELDS = ('player_speed_max', 'stamina_inc_max', 'player_decay', 'inertia_moment', 'dash_power_rate',

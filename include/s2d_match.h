@@ -115,8 +115,8 @@ typedef struct S2DMatchParams {
    * ball in the goal = PenaltyScore_; out, caught or out of time = PenaltyMiss_; a second touch with pen_allow_mult_kicks off =
    * PenaltyFoul_), the verdict for pen_before_setup_wait cycles.
    * The left team kicks first, takers from index 10 downwards; pen_nr_kicks each (decided early when one side cannot catch up),
-   * then pairs of kicks until one pair decides or pen_max_extra_kicks more are used up (then the draw stands: pen_random_winner
-   * is not built).  The clock stands throughout. */
+   * then pairs of kicks until one pair decides or pen_max_extra_kicks more are used up (then the draw stands, unless pen_random_winner
+   * below tosses a coin).  The clock stands throughout. */
   int32_t penalty_shoot_outs;             /* 1 */
   int32_t pen_before_setup_wait, pen_ready_wait, pen_taken_wait;   /* 10 10 150 */
   int32_t pen_nr_kicks, pen_max_extra_kicks;                       /* 5 5 (their sum <= 15) */
@@ -130,7 +130,10 @@ typedef struct S2DMatchParams {
   double illegal_defense_dist_x, illegal_defense_width;       /* 16.5 40.32 */
   int32_t pen_allow_mult_kicks;           /* 1 (ServerParam.pen_allow_mult_kicks, idl/service.proto:1611): the taker may play the ball
                                              again during PenaltyTaken_; 0 = a second touch of his is PenaltyFoul_, the kick is missed */
-  int32_t reserved_mp2;
+  int32_t pen_random_winner;              /* 0 (ServerParam.pen_random_winner, idl/service.proto:1610): a shoot-out that ends level is decided
+                                             by a coin (one Philox draw in the cycle the match ends): bits 28-29 of the set-play word =
+                                             1 left / 2 right won the toss; the score is not touched.  (The field took the place of
+                                             reserved_mp2: the struct's size and every other offset are unchanged.) */
 } S2DMatchParams;
 
 /* PlayerType (idl/service.proto:1697-1732): the members that enter the dynamics.  Type 0 is the

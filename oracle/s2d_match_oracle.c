@@ -43,7 +43,7 @@ typedef struct MP {
   int stopped_clock, announce_wait, foul_cycles; REAL foul_detect_probability;
   int nr_extra_halfs, extra_half_cycles, golden_goal;
   int penalty_shoot_outs, pen_before_setup_wait, pen_ready_wait, pen_taken_wait, pen_nr_kicks, pen_max_extra_kicks; REAL pen_spot_x;
-  int pen_allow_mult_kicks;
+  int pen_allow_mult_kicks, pen_random_winner;
   int illegal_defense_number, illegal_defense_duration; REAL ill_x, ill_half_w;   /* the strip: |x| > ill_x on the own side, |y| < ill_half_w */
   REAL catch_half_w, catch_probability, max_catch_angle, min_catch_angle, pen_x, pen_half_w;
   uint64_t seed; int64_t env_id_offset; int auto_reset, noise;
@@ -104,7 +104,7 @@ static void mp_from_config(const S2DMatchConfig *c, MP *p) {
   p->penalty_shoot_outs = m->penalty_shoot_outs; p->pen_before_setup_wait = m->pen_before_setup_wait; p->pen_ready_wait = m->pen_ready_wait;
   p->pen_taken_wait = m->pen_taken_wait; p->pen_nr_kicks = m->pen_nr_kicks; p->pen_max_extra_kicks = m->pen_max_extra_kicks;
   p->pen_spot_x = (REAL)(s->pitch_half_length - m->pen_dist_x);
-  p->pen_allow_mult_kicks = m->pen_allow_mult_kicks;
+  p->pen_allow_mult_kicks = m->pen_allow_mult_kicks; p->pen_random_winner = m->pen_random_winner != 0;
   p->illegal_defense_number = m->illegal_defense_number; p->illegal_defense_duration = m->illegal_defense_duration;
   p->ill_x = (REAL)(s->pitch_half_length - m->illegal_defense_dist_x); p->ill_half_w = (REAL)(m->illegal_defense_width * 0.5);
   p->catch_half_w = (REAL)(m->catch_area_w * 0.5); p->catch_probability = (REAL)m->catch_probability;
@@ -625,6 +625,13 @@ static void match_step(const MP *p, Match *m, uint64_t gid, const float *act, Ma
         m->setplay_timer += 1;
         if (m->setplay_timer >= p->pen_before_setup_wait) {
           if (pen_over(p, m->set_play_taker)) {
+            /* ServerParam.pen_random_winner (idl/service.proto:1610): a shoot-out that ends level is decided by the toss of a coin --
+             * one draw (TACKLE stream, the ball's block: no tackle uses it), below one half = the left team; the winner is written
+             * into bits 28-29 of the set-play word (1 left, 2 right), the score stays as it is */
+            if (p->pen_random_winner && pen_goals(m->set_play_taker, SIDE_LEFT) == pen_goals(m->set_play_taker, SIDE_RIGHT)) {
+              uint32_t w[4]; draw(p->seed, gid, cyc, ST_TACKLE, BALL, w);
+              m->set_play_taker |= (rnd_u01(w[0]) < R(0.5) ? 1 : 2) << 28;
+            }
             m->mode = S2D_GM_TIME_OVER; m->mode_side = SIDE_NONE; m->done = 1; st->v[3]++;
           } else pen_setup(p, m, other_side(side0));
         }

@@ -20,7 +20,7 @@ MATCH_DEFAULTS = dict(
     foul_detect_probability=0.5, nr_extra_halfs=2, extra_half_cycles=1000, golden_goal=0,
     penalty_shoot_outs=1, pen_before_setup_wait=10, pen_ready_wait=10, pen_taken_wait=150, pen_nr_kicks=5, pen_max_extra_kicks=5,
     pen_dist_x=42.5, illegal_defense_number=0, illegal_defense_duration=20, illegal_defense_dist_x=16.5, illegal_defense_width=40.32,
-    pen_allow_mult_kicks=1)
+    pen_allow_mult_kicks=1, pen_random_winner=0)
 
 
 def default_player_type(sp, mp):

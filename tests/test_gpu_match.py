@@ -710,6 +710,33 @@ def test_penalty_foul_on_device():
     assert {GM_PENALTY_TAKEN, GM_PENALTY_FOUL} <= seen and list(eng.stats.cpu().numpy()) == list(orc.stats())
 
 
+def test_pen_random_winner_on_device():
+    """ServerParam.pen_random_winner (idl/service.proto:1610): level shoot-outs are decided by a coin; device == oracle after every
+    cycle through whole shoot-outs of the random policy (general kernel: the stock rules let a draw stand), and the toss is seen."""
+    eng, orc = _pair(48, half_time_cycles=6, nr_extra_halfs=0, pen_before_setup_wait=2, pen_ready_wait=3, pen_taken_wait=8, pen_nr_kicks=1,
+                     pen_max_extra_kicks=0, pen_random_winner=1, auto_reset=False, noise=True)
+    assert eng.kernel_name().endswith('<general>')
+    for t in range(90):
+        eng.step(None); orc.step(None)
+        assert_match_same(eng, orc, f'coin t={t}')
+    w = orc.get('set_play_taker').astype(np.int64)
+    level = ((w >> 20) & 15) == ((w >> 24) & 15)
+    from soccer2d_amd._capi_match import GM_TIME_OVER
+    over = orc.get('mode') == GM_TIME_OVER                 # (a stopped clock can keep a match from its end a little longer)
+    shot = over & (((w >> 12) & 15) > 0)                   # ... and a match that a goal decided has no shoot-out
+    assert over.sum() >= 40 and (level & shot).sum() >= 10
+    assert ((((w >> 28) & 3) != 0) == (level & shot))[over].all() and len(set(((w >> 28) & 3)[level & shot].tolist())) == 2
+    # with auto_reset the toss lives for the one cycle in which the match ends: the long run stays bit-exact
+    eng, orc = _pair(40, half_time_cycles=6, nr_extra_halfs=0, pen_before_setup_wait=2, pen_ready_wait=3, pen_taken_wait=8, pen_nr_kicks=1,
+                     pen_max_extra_kicks=1, pen_random_winner=1, noise=True)
+    for t in range(300):
+        eng.step(None); orc.step(None)
+        if t % 7 == 0:
+            assert_match_same(eng, orc, f'coin, auto reset t={t}')
+    assert_match_same(eng, orc, 'coin, auto reset, end')
+    assert list(eng.stats.cpu().numpy()) == list(orc.stats())
+
+
 def test_pause_holds_matches_on_device():
     """Pause / Human written into the mode plane hold a match (idl/service.proto:280-281): device == oracle while some matches are held and
     the others play on (random policy), and after they are let go."""

@@ -386,6 +386,43 @@ def test_penalty_shoot_out():
     assert m.get('mode')[0] == GM_TIME_OVER and m.get('done')[0] == 1
 
 
+def test_pen_random_winner_tosses_a_coin():
+    """ServerParam.pen_random_winner (idl/service.proto:1610): a shoot-out that ends level after every kick is decided by a coin --
+    here bits 28-29 of the set-play word (1 = left, 2 = right) in the cycle the match ends; the score is untouched.  One kick each,
+    nobody plays the ball: every match ends 0-0.  rcssserver's PenaltyRef restated (drand < 0.5 = left): parity unpinned."""
+    kw = dict(half_time_cycles=4, nr_extra_halfs=0, auto_reset=0, pen_before_setup_wait=1, pen_ready_wait=2, pen_taken_wait=5,
+              pen_nr_kicks=1, pen_max_extra_kicks=0)
+    n = 400
+    for on in (0, 1):
+        m = fresh(n, pen_random_winner=on, **kw)
+        for _ in range(40):
+            m.step(acts(n))
+        assert (m.get('mode') == GM_TIME_OVER).all()
+        w = m.get('set_play_taker').astype(np.int64)
+        assert (((w >> 12) & 15) == 1).all() and (((w >> 16) & 15) == 1).all() and (((w >> 20) & 255) == 0).all()
+        win = (w >> 28) & 3
+        if not on:
+            assert (win == 0).all()                                    # the draw stands
+        else:
+            left, right = int((win == 1).sum()), int((win == 2).sum())
+            assert left + right == n and abs(left - n / 2) < 4 * (n / 4) ** 0.5      # a fair coin, four sigma
+    # a shoot-out that the kicks decide is not tossed for
+    m = fresh(1, pen_random_winner=1, **kw)
+    for _ in range(9):
+        m.step(acts())
+    from soccer2d_amd._capi_match import GM_PENALTY_READY, GM_PENALTY_TAKEN, GM_PENALTY_SCORE
+    while m.get('mode')[0] != GM_PENALTY_READY:
+        m.step(acts())
+    m.step(acts(p10=[MCMD_KICK, 100, 0]))
+    assert m.get('mode')[0] == GM_PENALTY_TAKEN
+    m.set_obj(0, 22, x=52.0, y=0.0, vx=2.0, vy=0.0)
+    m.step(acts())
+    assert m.get('mode')[0] == GM_PENALTY_SCORE
+    for _ in range(30):
+        m.step(acts())
+    assert m.get('mode')[0] == GM_TIME_OVER and _pen_word(m)['goals'] == (1, 0) and (int(m.get('set_play_taker')[0]) >> 28) == 0
+
+
 def test_operator_called_fouls_are_played_like_announcements():
     """FoulPush_ / FoulMultipleAttacker_ / FoulBallOut_ (idl/service.proto:283-285): rcssserver defines them, its referees call only
     FoulCharge_, and so does this engine's.  Written into the mode word with the offending side they are played as an announcement:
