@@ -1065,7 +1065,9 @@ static ArenaLayout layout_for(int64_t n) {
   return L;
 }
 
-S2D_API const char* s2d_version(void) { return "s2d-hip 0.3 (gfx950, abi 3)"; }
+#define S2D_STR2(x) #x
+#define S2D_STR(x) S2D_STR2(x)
+S2D_API const char* s2d_version(void) { return "s2d-hip 0.4 (gfx950, abi " S2D_STR(S2D_ABI_VERSION) ")"; }
 S2D_API const char* s2d_last_error(void) { return g_err.c_str(); }
 
 S2D_API void s2d_default_config(S2DConfig* c) {

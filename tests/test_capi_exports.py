@@ -107,7 +107,7 @@ def test_default_config_and_validation(lib):
     cfg.abi_version = 99
     assert lib.s2d_validate_config(C.byref(cfg)) == _capi.S2D_EINVAL
     assert b'abi_version' in lib.s2d_last_error()
-    assert lib.s2d_version().startswith(b's2d-hip')
+    assert lib.s2d_version().startswith(b's2d-hip') and b'abi %d)' % _capi.S2D_ABI_VERSION in lib.s2d_version()
 
 
 def test_no_gpu_no_fallback(lib):
