@@ -158,10 +158,10 @@ def cpu_baseline(n_envs, sample_steps, noise=False):
 
     probe = run(1, 4)
     per_step_1t = probe / 4
-    s1 = sample_steps or max(8, min(256, int(6.0 / per_step_1t)))
+    s1 = sample_steps or max(8, min(1024, int(6.0 / per_step_1t)))
     t1 = run(1, s1)
     v1 = n_envs * s1 / t1
-    sN = sample_steps or max(8, min(2048, int(8.0 / (per_step_1t / threads))))
+    sN = sample_steps or max(8, min(16384, int(8.0 / (per_step_1t / threads))))
     tN = run(threads, sN) if threads > 1 else t1
     vN = n_envs * sN / tN if threads > 1 else v1
     return {'value': vN, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
