@@ -1,6 +1,6 @@
 """Round-4 fuzz soak of the reach-ball engine against its C oracle: random ServerParam / task settings per seed (the generator of
 tests/test_gpu_parity.py::test_random_server_parameters_parity, more seeds, more envs, longer runs), every kernel family in turn --
-the four-wave pipeline, the unified kernel, s2d_step, s2d_step_k -- with the whole record and every state word compared.
+the four-wave pipeline, the unified kernel, s2d_step, s2d_step_k, masked s2d_reset -- with the whole record and every state word compared.
 Usage (GPU box, repo root): python profiles/experiments/soak_round4_reach.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, 'gym-soccer-2d-env_amd'); sys.path.insert(0, 'tests')
@@ -50,7 +50,19 @@ while time.time() - t_start < budget:
         o_obs, o_rew, o_done, o_res = orc.step(a)
         P.assert_same(obs, o_obs, f'seed {seed} step {t} obs'); P.assert_same(rew, o_rew, f'seed {seed} step {t} reward')
         P.assert_same(done, o_done, f'seed {seed} step {t} done'); P.assert_same(res, o_res, f'seed {seed} step {t} result')
-    for t in range(20):
+    for k in (int(rs.choice([1, 2, 3])), int(rs.choice([4, 7, 16])), int(rs.choice([2, 5, 33]))):   # s2d_step_k, caller actions and in-kernel policy
+        if rs.rand() < 0.5:
+            a = np.stack([P._random_actions(rs, kw, n) for _ in range(k)])
+            out, ref = eng.step_k(k, torch.as_tensor(a, device='cuda:0')), orc.rollout(k, a)
+        else:
+            out, ref = eng.step_k(k), orc.rollout(k)
+        P._compare_rollout(out, ref, f'seed {seed} step_k k={k}')
+        P.assert_state_same(eng, orc, f'seed {seed} after step_k k={k}')
+    for t in range(10):                                         # masked resets between steps
+        eng.step(None); orc.step(None)
+        m = (rs.rand(n) < 0.3).astype(np.uint8)
+        P.assert_same(eng.reset(torch.as_tensor(m, device='cuda:0')), orc.reset(m), f'seed {seed} masked reset {t}')
+    for t in range(10):
         eng.step(None); orc.step(None)
     P.assert_state_same(eng, orc, f'seed {seed} after steps')
     P.assert_same(eng.obs, orc.obs(), f'seed {seed} obs')
