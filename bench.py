@@ -387,7 +387,8 @@ def roofline_of(alg_bytes_launch, launch_s, launch_s_events, kernel, traffic_key
          'algorithmic_bytes_per_env_step': alg_bytes_launch / (n * steps_per_launch),
          # what limits the kernel (HBM traffic equals the algorithmic bytes): in the fused kernels the slowest workgroup's dependent
          # chain at the clock the chip grants, launch + memory latency in the one-cycle kernel
-         'limiter': ("slowest workgroup's instruction chain x the shader clock granted under the kernel's power draw (1.5-2.0 GHz, DESIGN section 7)"
+         'limiter': ("slowest workgroup's instruction chain x the shader clock granted at the socket's 1400 W power cap, which this kernel reaches "
+                     "(about 2.0 of 2.4 GHz on the faster boxes, profiles/r04/power_probe.txt; DESIGN section 7)"
                      if steps_per_launch > 1 else 'launch-latency')}
     if launch_s_events:
         r['launch_us_events'] = launch_s_events * 1e6
