@@ -1,7 +1,7 @@
 """Round-4 fuzz soak of the reach-ball engine against its C oracle: random ServerParam / task settings per seed (the generator of
 tests/test_gpu_parity.py::test_random_server_parameters_parity, more seeds, more envs, longer runs), every kernel family in turn --
 the four-wave pipeline, the unified kernel, s2d_step, s2d_step_k, masked s2d_reset -- with the whole record and every state word compared.
-Usage (GPU box, repo root): python profiles/experiments/soak_round4_reach.py [seconds]"""
+Usage (GPU box, repo root): [SOAK_N=65536,600000 SOAK_T=64] python profiles/experiments/soak_round4_reach.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, 'gym-soccer-2d-env_amd'); sys.path.insert(0, 'tests')
 import numpy as np
@@ -32,14 +32,14 @@ while time.time() - t_start < budget:
               ball_speed=float(rs.uniform(0, 2.5)), ball_direction=float(rs.uniform(-180, 180)),
               use_continuous_action=mode != 0, use_turning=mode == 2, action_space_size=int(rs.choice([3, 8, 16, 36])),
               noise=bool(rs.randint(2)), seed=int(rs.randint(1, 2 ** 31)))
-    n = int(rs.choice([63, 257, 1000, 4097]))
+    n = int(rs.choice([int(v) for v in os.environ.get('SOAK_N', '63,257,1000,4097').split(',')]))
     ws = str(int(rs.randint(2)))
     os.environ['S2D_ROLLOUT_WS'] = ws
     eng, orc = P._engine(n, **dict(kw)), P._oracle(n, **dict(kw))
     eng.reset(); orc.reset()
     P.assert_state_same(eng, orc, f'seed {seed} reset')
     names = set()
-    for T in (int(rs.choice([1, 2, 5, 64])), 256, int(rs.choice([3, 100]))):
+    for T in (int(rs.choice([1, 2, 5, 64])), int(os.environ.get('SOAK_T', '256')), int(rs.choice([3, 100]))):
         out, ref = eng.rollout(T), orc.rollout(T)
         P._compare_rollout(out, ref, f'seed {seed} rollout T={T}')
         names.add(eng.kernel_name().split('<')[0])
